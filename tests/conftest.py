@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+    gold = os.path.join(ROOT, "tests", "golden")
+    return {name: np.load(os.path.join(gold, name + ".npz")) for name in ("kat", "synth", "audiofft")}
+
+
+def fixture_of(npz, prefix):
+    return {k: npz[f"{prefix}/{k}"] for k in ("n", "dec", "head", "tail", "rms", "sum")}
