@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the partitioned-convolution hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): stereo, 10 s IR @ 48 kHz, host block 512
+(-> head 512 / tail 8192, StereoConvolver.cpp:11-15), synthetic white-noise input,
+decaying-noise IR with the reference's auto-gain (reevr_amd/synth.py).
+
+A "step" is one pass of the hot path over one batch of input: ONE process() call of
+`--frames` frames per channel (default 40 s = 1 920 000 frames = 3750 blocks of 512) with
+input and output resident in HBM. process() takes any length, and its result does not
+depend on how the stream is cut into calls (tests/test_gpu_parity.py), so this is the same
+function the plugin calls per 512-sample block -- batched in time because a single
+512-frame block (2 KB per channel) cannot fill a 256-CU GPU. The strictly block-by-block
+rate (one call per 512 frames) is reported beside it as "streaming".
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+N > 1: every rank owns one independent stereo instance (its own IR, `inst = rank`), no
+data-path collective (weak scaling; `--gather` adds the optional RCCL all_gather of the
+output batch). One JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+SR = 48000
+IR_LEN = 10 * SR
+HOST_BLOCK = 512
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes_block(B: int, P: int) -> int:
+    """algorithmic bytes of one block of one reference sub-convolver."""
+    return 16 * P * (B + 1) + 8 * (B + 1) + 16 * B
+
+
+def alg_bytes_per_sample(head: int, tail: int, ir_len: int) -> float:
+    """Per channel-sample, reference structure head / tail0 / tail (TwoStageFFTConvolver.cpp:117-138)."""
+    p_head = -(-min(ir_len, tail) // head)
+    p_t0 = -(-min(max(ir_len - tail, 0), tail) // head)
+    p_t = -(-max(ir_len - 2 * tail, 0) // tail)
+    per_tail_block = (tail // head) * (alg_bytes_block(head, p_head) + (alg_bytes_block(head, p_t0) if p_t0 else 0))
+    per_tail_block += alg_bytes_block(tail, p_t) if p_t else 0
+    return per_tail_block / tail
+
+
+def cpu_baseline(irs: np.ndarray, x: np.ndarray, budget_s: float) -> dict:
+    """The reference itself (oracle/_ref, kind "reference") or the C restatement (kind "port")
+    on this host's cores, 512-frame process() calls, tail inline, bounded to ~budget_s."""
+    from oracle import oracle_py as O
+    which = "ref" if O.have_ref() else "orc"
+    nch, frames = x.shape
+    frames -= frames % HOST_BLOCK
+
+    def run_channel(c: int, stop_at: float, counter: list):
+        conv = O.TwoStageFFTConvolver(which)
+        assert conv.init(HOST_BLOCK, 8192, irs[c % irs.shape[0]])
+        fn = conv._b.fn("twostage_process")
+        xin = np.ascontiguousarray(x[c % nch])
+        out = np.empty(HOST_BLOCK, np.float32)
+        import ctypes as C
+        fp = C.POINTER(C.c_float)
+        outp = out.ctypes.data_as(fp)
+        base = xin.ctypes.data
+        done = 0
+        while True:
+            for i in range(0, frames, HOST_BLOCK):
+                fn(conv._h, C.cast(base + 4 * i, fp), outp, HOST_BLOCK)
+            done += frames
+            if time.perf_counter() >= stop_at:
+                break
+        counter[c] = done
+
+    # (i) one thread, channels one after the other -- comparable with BASELINE.md section 2
+    t0 = time.perf_counter()
+    cnt = [0] * nch
+    per = budget_s / (2 * nch)
+    for c in range(nch):
+        run_channel(c, time.perf_counter() + per, cnt)
+    t1 = time.perf_counter()
+    single = sum(cnt) / (t1 - t0) / 1e6
+    # (ii) all host cores, one convolver instance per thread (ctypes releases the GIL)
+    cores = os.cpu_count() or 1
+    cntm = [0] * cores
+    t2 = time.perf_counter()
+    stop = t2 + budget_s / 2
+    th = [threading.Thread(target=run_channel, args=(c, stop, cntm)) for c in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    t3 = time.perf_counter()
+    multi = sum(cntm) / (t3 - t2) / 1e6
+    return {
+        "value": round(single, 3), "unit": "Msamples/s", "cores": 1,
+        "kind": "reference" if which == "ref" else "port",
+        "sample": f"stereo 10 s IR, head 512 / tail 8192, {HOST_BLOCK}-frame process() calls, tail inline, "
+                  f"{sum(cnt)} channel-samples in {t1 - t0:.1f} s on 1 thread",
+        "all_cores": {"value": round(multi, 3), "cores": cores,
+                      "sample": f"{cores} independent mono instances, one per thread, {t3 - t2:.1f} s"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=40 * SR, help="frames per channel per step (one process() call)")
+    ap.add_argument("--gather", action="store_true", help="RCCL all_gather of the output batch each step")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--stream-calls", type=int, default=3000, help="512-frame calls of the streaming side measurement")
+    args = ap.parse_args()
+
+    import torch
+    import reevr_amd
+    from reevr_amd import KERNEL_NAMES, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    frames = int(args.frames)
+    nch = 2
+    irs = synth.synth_ir(IR_LEN, nch, inst=rank)                 # this rank's stereo instance
+    x = np.stack([synth.synth_input(frames, c + 2 * rank) for c in range(nch)])
+    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=False)
+    t_init = time.perf_counter()
+    if not conv.init(HOST_BLOCK, 8192, list(irs), max_len=frames):
+        raise SystemExit(f"init failed: {conv.last_error_string}")
+    conv.sync()
+    init_ms = (time.perf_counter() - t_init) * 1e3
+    head, tail = conv.head_block, conv.tail_block
+    d_in = torch.from_numpy(x).to(dev)
+    d_out = torch.empty_like(d_in)
+    gathered = torch.empty((world,) + tuple(d_out.shape), device=dev) if (args.gather and world > 1) else None
+    torch.cuda.synchronize()
+
+    def step():
+        conv.process_device(d_in, d_out, sync=False)
+        if gathered is not None:
+            conv.sync()
+            dist.all_gather_into_tensor(gathered, d_out)
+
+    def fence():
+        conv.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    conv.check()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_samples = world * nch * frames * args.steps
+    value = total_samples / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- per-kernel durations, live, with HIP events on the stream the kernels run on ----
+    conv.set_timing(True)
+    conv.kernel_time_reset()
+    ksteps = min(args.steps, 10)
+    for _ in range(ksteps):
+        conv.process_device(d_in, d_out, sync=True)
+    kern = {}
+    for kid, name in enumerate(KERNEL_NAMES):
+        n, ms = conv.kernel_time(kid)
+        if n:
+            kern[name] = {"launches": n, "avg_ms": ms / n}
+    conv.set_timing(False)
+    conv.kernel_time_reset()
+    PA, PT = conv.partitions(0), conv.partitions(1)
+    rows_A = -(-frames // head) + (1 if frames % head else 0)
+    # algorithmic bytes per launch of each kernel family:
+    #   FIR:  16 B per (partition, bin) pair  = read one IR bin + one delay-line bin (8 B each)
+    blocksA, blocksT = frames / head, frames / tail
+    alg = {
+        "fir_head": 16.0 * PA * (head + 1) * blocksA * nch,
+        "fir_tail": 16.0 * PT * (tail + 1) * blocksT * nch,
+        "fft_fwd_head": (4.0 * head + 8.0 * (head + 1)) * blocksA * nch,
+        "fft_inv_head": (8.0 * (head + 1) + 12.0 * head) * blocksA * nch,
+        "fft_fwd_tail": (4.0 * tail + 8.0 * (tail + 1)) * blocksT * nch,
+        "fft_inv_tail": (8.0 * (tail + 1) + 12.0 * tail) * blocksT * nch,
+        "ingest": 8.0 * frames * nch,
+    }
+    dominant = max(kern, key=lambda k: kern[k]["avg_ms"]) if kern else None
+    roof = None
+    if dominant:
+        ach = alg[dominant] / (kern[dominant]["avg_ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": alg[dominant], "avg_launch_ms": round(kern[dominant]["avg_ms"], 5)}
+    bps = alg_bytes_per_sample(head, tail, IR_LEN)
+    path_gbs = value / world * 1e6 * bps / 1e9
+
+    # ---- streaming side measurement: one process() call per 512-frame host block --------
+    streaming = None
+    if args.stream_calls > 0:
+        sconv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=True)
+        assert sconv.init(HOST_BLOCK, 8192, list(irs), max_len=HOST_BLOCK)
+        blk_in = d_in[:, :HOST_BLOCK * 64].contiguous().view(nch, 64, HOST_BLOCK)
+        blk_out = torch.empty(nch, HOST_BLOCK, device=dev)
+        ins = [blk_in[:, i, :] for i in range(64)]
+        for i in range(200):
+            sconv.process_device(ins[i % 64], blk_out, sync=False)
+        sconv.sync()
+        ts = time.perf_counter()
+        for i in range(args.stream_calls):
+            sconv.process_device(ins[i % 64], blk_out, sync=False)
+        sconv.sync()
+        te = time.perf_counter() - ts
+        streaming = {"value": round(nch * HOST_BLOCK * args.stream_calls / te / 1e6, 3), "unit": "Msamples/s",
+                     "us_per_block": round(te / args.stream_calls * 1e6, 2),
+                     "note": "one process_device() call per 512-frame block, tail on the second stream"}
+        sconv.close()
+
+    cpu = cpu_baseline(irs, x[:, :20 * SR], args.cpu_seconds) if (world == 1 and args.cpu_seconds > 0) else None
+
+    line = {
+        "metric": "Msamples/s convolved (stereo, 10s IR, block=512); % HBM roofline",
+        "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "stereo, 10 s IR @ 48 kHz, block=512 (head 512 / tail 8192), TwoStage convolver",
+                   "frames_per_step": frames, "channels_per_gpu": nch, "instances": world,
+                   "partitions": {"head+tail0": PA, "tail": PT},
+                   "call": "one process() per step, device-resident I/O", "gather": bool(gathered is not None)},
+        "roofline": roof,
+        "path_roofline": {"alg_bytes_per_sample": round(bps, 1), "achieved_GBs_per_gpu": round(path_gbs, 1),
+                          "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4),
+                          "x_realtime_per_gpu": round(value / world * 1e6 / (SR * nch), 1)},
+        "kernels_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()},
+        "streaming": streaming,
+        "cpu_baseline": cpu,
+        "init_ms": round(init_ms, 2),
+    }
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+// StereoConvolver.h -- header-only C++ drop-in for the reference's StereoConvolver
+// (reference src/dsp/StereoConvolver.h:7-46, StereoConvolver.cpp:3-62): LL/RR (+LR/RL for
+// quad impulses) convolvers and their public output buffers, same member names. The LL/RR
+// pair is one 2-channel set (one launch per stage for both); LR/RL a second one, because the
+// reference skips them under force2Chans (StereoConvolver.cpp:38-41) and their clocks must
+// then stand still.
+#pragma once
+
+#include <algorithm>
+#include <cstddef>
+#include <vector>
+
+#include "rvc.h"
+
+#ifndef REEVR_AMD_HAVE_IMPULSE
+// Minimal stand-in for the fields of the reference's Impulse (src/dsp/Impulse.h) that
+// loadImpulse reads; define REEVR_AMD_HAVE_IMPULSE when the real class is in scope.
+struct Impulse {
+  std::vector<float> bufferLL, bufferRR, bufferLR, bufferRL;
+  bool isQuad = false;
+};
+#endif
+
+class StereoConvolver {
+ public:
+  explicit StereoConvolver(int device = 0)
+      : _main(rvc_set_create(2, device, RVC_FLAG_BG_STREAM)),
+        _cross(rvc_set_create(2, device, RVC_FLAG_BG_STREAM)) {}
+  ~StereoConvolver() {
+    rvc_set_destroy(_main);
+    rvc_set_destroy(_cross);
+  }
+
+  void loadImpulse(Impulse &imp) {   // StereoConvolver.cpp:22-31
+    {
+      const float *irs[2] = {imp.bufferLL.data(), imp.bufferRR.data()};
+      const size_t lens[2] = {imp.bufferLL.size(), imp.bufferRR.size()};
+      rvc_set_init(_main, headBlockSize, tailBlockSize, irs, lens, (size_t)size);
+    }
+    isQuad = imp.isQuad;
+    if (isQuad) {
+      const float *irs[2] = {imp.bufferLR.data(), imp.bufferRL.data()};
+      const size_t lens[2] = {imp.bufferLR.size(), imp.bufferRL.size()};
+      rvc_set_init(_cross, headBlockSize, tailBlockSize, irs, lens, (size_t)size);
+    }
+  }
+
+  void prepare(int samplesPerBlock) {   // StereoConvolver.cpp:8-20
+    size = samplesPerBlock;
+    headBlockSize = 1;
+    while (headBlockSize < static_cast<size_t>(samplesPerBlock)) headBlockSize *= 2;
+    tailBlockSize = std::max(size_t(8192), 2 * headBlockSize);
+    bufferLL.resize(samplesPerBlock, 0.0f);
+    bufferRR.resize(samplesPerBlock, 0.0f);
+    bufferLR.resize(samplesPerBlock, 0.0f);
+    bufferRL.resize(samplesPerBlock, 0.0f);
+  }
+
+  void process(const float *dataL, const float *dataR, size_t nsamples, bool force2Chans = false) {
+    // StereoConvolver.cpp:33-42
+    const float *in[2] = {dataL, dataR};
+    float *out[2] = {bufferLL.data(), bufferRR.data()};
+    rvc_set_process(_main, in, out, nsamples);
+    if (isQuad && !force2Chans) {
+      float *outx[2] = {bufferLR.data(), bufferRL.data()};   // LR is fed L, RL is fed R
+      rvc_set_process(_cross, in, outx, nsamples);
+    }
+  }
+
+  void reset() {   // StereoConvolver.cpp:44-54
+    rvc_set_reset(_main);
+    rvc_set_reset(_cross);
+    bufferLL.clear();
+    bufferRR.clear();
+    bufferLR.clear();
+    bufferRL.clear();
+  }
+
+  void clear() {   // StereoConvolver.cpp:56-62
+    rvc_set_clear(_main);
+    rvc_set_clear(_cross);
+  }
+
+  bool finishedLoading() { return rvc_set_is_finished(_main) != 0; }   // StereoConvolver.cpp:3-6
+
+  std::vector<float> bufferLL = {};
+  std::vector<float> bufferRR = {};
+  std::vector<float> bufferLR = {};
+  std::vector<float> bufferRL = {};
+  int size = 0;
+  bool isQuad = false;
+
+ protected:
+  size_t headBlockSize = 0;
+  size_t tailBlockSize = 0;
+
+ private:
+  rvc_set *_main;
+  rvc_set *_cross;
+  StereoConvolver(const StereoConvolver &);
+  StereoConvolver &operator=(const StereoConvolver &);
+};

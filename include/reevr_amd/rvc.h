@@ -1,0 +1,159 @@
+/*
+ * rvc.h -- C ABI of the MI355X partitioned-convolution engine (libreevr_amd.so).
+ *
+ * This is the drop-in boundary for the reference's convolution hot path
+ * (tiagolr/reevr; paths below are relative to the reference tree):
+ *
+ *   fftconvolver::TwoStageFFTConvolver   libs/FFTConvolver/TwoStageFFTConvolver.h:54-83
+ *   fftconvolver::FFTConvolver           libs/FFTConvolver/FFTConvolver.h:52-80
+ *   Convolver (threaded tail)            src/dsp/Convolver.h:28-45
+ *   StereoConvolver (2-4 channel fan-out) src/dsp/StereoConvolver.h:7-46
+ *
+ * Plain pointers and sizes only; no C++/torch types. All functions are thread-compatible:
+ * one thread at a time per handle, different handles concurrently from different threads
+ * (the reference's contract). No function throws; HIP failures are recorded
+ * in a sticky per-handle error (rvc_last_error) and process() on a failed handle writes
+ * zeros. There is NO CPU fallback: without a usable GPU every init fails with
+ * RVC_ERR_NO_DEVICE.
+ *
+ * A handle is a *set* of n independent mono convolvers (channels) that share one block
+ * geometry and advance in lock-step, so that stereo / quad / 64-channel work is one
+ * launch per stage. rvc_create() is the n == 1 case and mirrors one `Convolver`.
+ */
+#ifndef REEVR_AMD_RVC_H
+#define REEVR_AMD_RVC_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rvc_set rvc_set;
+
+enum {
+  RVC_OK = 0,
+  RVC_ERR_NO_DEVICE = 1,   /* no HIP device / hipSetDevice failed */
+  RVC_ERR_HIP = 2,         /* a HIP call failed; rvc_last_error_string has the detail */
+  RVC_ERR_BAD_ARG = 3,     /* zero block size, len > max_len, NULL pointer ... */
+  RVC_ERR_UNSUPPORTED = 4, /* block size above RVC_MAX_BLOCK */
+  RVC_ERR_NOT_INIT = 5
+};
+
+/* Largest partition (block) size after rounding up to a power of two. The 2*block-point
+ * real FFT of one partition lives in one CU's LDS (block * 8 bytes <= 128 KiB). */
+#define RVC_MAX_BLOCK 16384
+
+/* flags for rvc_set_create */
+#define RVC_FLAG_BG_STREAM 1u   /* run the tail stage on a second HIP stream, synchronised with
+                                   events at the reference's start/waitForBackgroundProcessing
+                                   hook points (TwoStageFFTConvolver.cpp:213-222, Convolver.cpp:84-95) */
+#define RVC_FLAG_TIMING 2u      /* bracket every kernel launch with HIP events (rvc_set_kernel_time) */
+#define RVC_FLAG_FFT_F64 4u     /* run the FFTs in double, spectra still stored as float -- the reference's
+                                   precision (Ooura in double, AudioFFT.cpp:114-159). Default is float32
+                                   transforms (~1e-7 relative, 100x inside the 1e-5 RMS parity bound and
+                                   faster). Limits the block size to RVC_MAX_BLOCK/2. IR spectra are computed
+                                   in double at init in either mode. */
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+
+/* Replaces `new Convolver()` x n (StereoConvolver.h:12-17). `device` is the HIP ordinal.
+ * Never returns NULL for n_channels >= 1 unless out of host memory; device problems are
+ * reported by the first init. */
+rvc_set *rvc_set_create(int n_channels, int device, unsigned flags);
+/* Replaces ~Convolver (Convolver.cpp:72-75). Waits for outstanding GPU work. */
+void rvc_set_destroy(rvc_set *s);
+
+/* ---- init -------------------------------------------------------------------------- */
+
+/* Replaces TwoStageFFTConvolver::init (TwoStageFFTConvolver.cpp:87-148) for every channel of
+ * the set, as StereoConvolver::loadImpulse does (StereoConvolver.cpp:22-31).
+ *   irs[c]     caller-owned host array of ir_lens[c] floats, fully consumed before return
+ *   max_len    largest `len` any later process call will pass (0 -> head block size);
+ *              sizes the device rings, no allocation happens in process()
+ * Returns 1 on success, 0 on failure -- the reference's bool: 0 iff a block size is 0
+ * (:94-97) -- or on a device error (see rvc_last_error). Implies reset() first (:92).
+ * Trailing |x| < 1e-6 samples are ignored (:107-110), an empty / all-zero IR gives 1 and a
+ * convolver that outputs zeros (:112-115), head > tail is swapped (:100-104), sizes are
+ * rounded up to powers of two (:117-118). */
+int rvc_set_init(rvc_set *s, size_t head_block, size_t tail_block,
+                 const float *const *irs, const size_t *ir_lens, size_t max_len);
+
+/* Replaces FFTConvolver::init (FFTConvolver.cpp:93-152): one uniform partition size for the
+ * whole IR (BASELINE config 1). Same conventions as above. */
+int rvc_set_init_uniform(rvc_set *s, size_t block, const float *const *irs,
+                         const size_t *ir_lens, size_t max_len);
+
+/* ---- process ----------------------------------------------------------------------- */
+
+/* Replaces TwoStageFFTConvolver::process / FFTConvolver::process
+ * (TwoStageFFTConvolver.cpp:151-233, FFTConvolver.cpp:155-212) for all channels:
+ * in[c] / out[c] are caller-owned HOST arrays of len floats; out is fully overwritten and
+ * valid on return (zero added latency, FFTConvolver.h:40-42). Any len in [0, max_len],
+ * including calls that end inside a partition. Before init, after a failed init, or with
+ * an empty IR: zeros (FFTConvolver.cpp:157-161). */
+void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size_t len);
+
+/* Same, with DEVICE-resident buffers: channel c reads d_in + c*in_stride and writes
+ * d_out + c*out_stride (strides in floats). Asynchronous on the set's stream
+ * (rvc_set_stream); call rvc_set_sync or synchronise that stream before reading d_out
+ * from another stream. */
+void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride,
+                            float *d_out, size_t out_stride, size_t len);
+
+/* ---- state ------------------------------------------------------------------------- */
+
+/* Replaces TwoStageFFTConvolver::clear / FFTConvolver::clear (TwoStageFFTConvolver.cpp:69-84,
+ * FFTConvolver.cpp:80-90): forget all signal history, keep the IR. O(1): the engine indexes
+ * everything by absolute sample time and restarts that clock. Divergence from the reference,
+ * documented in DESIGN.md: a clear() in the middle of a head block also drops the stale
+ * pre-multiplied accumulator the reference keeps. */
+void rvc_set_clear(rvc_set *s);
+/* Replaces reset() (TwoStageFFTConvolver.cpp:51-67): free everything; process() gives zeros. */
+void rvc_set_reset(rvc_set *s);
+/* Replaces Convolver::isFinished (Convolver.cpp:79): 1 when no tail work is in flight. */
+int rvc_set_is_finished(rvc_set *s);
+/* Block until all enqueued work of this set has completed. */
+void rvc_set_sync(rvc_set *s);
+
+/* ---- introspection ----------------------------------------------------------------- */
+
+int rvc_set_channels(const rvc_set *s);
+size_t rvc_set_head_block(const rvc_set *s);   /* after rounding; 0 before init */
+size_t rvc_set_tail_block(const rvc_set *s);   /* 0 for a uniform (single-stage) set */
+size_t rvc_set_max_len(const rvc_set *s);
+/* partitions of the zero-latency stage (head + tail0 merged) and of the tail stage */
+int rvc_set_partitions(const rvc_set *s, int stage /*0 = head, 1 = tail*/);
+/* hipStream_t of the foreground stream, as void*; (stage 1: the tail stream) */
+void *rvc_set_stream(rvc_set *s, int which);
+int rvc_last_error(const rvc_set *s);
+const char *rvc_last_error_string(const rvc_set *s);
+
+/* With RVC_FLAG_TIMING: accumulated HIP-event time of one kernel family since the last
+ * rvc_set_kernel_time_reset. kernel: 0 ingest, 1 fft_fwd(head) 2 fir(head) 3 fft_inv(head),
+ * 4 fft_fwd(tail) 5 fir(tail) 6 fft_inv(tail). Synchronises the set. Returns launches. */
+long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms);
+void rvc_set_kernel_time_reset(rvc_set *s);
+/* Switch per-launch event timing on/off at run time (same as creating with RVC_FLAG_TIMING). */
+void rvc_set_timing(rvc_set *s, int enable);
+
+/* ---- single convolver (n == 1): mirrors `Convolver` one to one ---------------------- */
+
+rvc_set *rvc_create(int device);                                               /* Convolver() */
+int rvc_init(rvc_set *h, size_t head_block, size_t tail_block, const float *ir, size_t ir_len);
+void rvc_process(rvc_set *h, const float *in, float *out, size_t len);
+void rvc_clear(rvc_set *h);
+void rvc_reset(rvc_set *h);
+int rvc_is_finished(rvc_set *h);
+void rvc_destroy(rvc_set *h);
+
+/* ---- library ----------------------------------------------------------------------- */
+
+/* Number of visible HIP devices (0 when there is none or the runtime cannot start). */
+int rvc_device_count(void);
+const char *rvc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REEVR_AMD_RVC_H */

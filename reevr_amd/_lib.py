@@ -1,0 +1,79 @@
+"""ctypes binding of the C ABI (include/reevr_amd/rvc.h). No fallback: if the HIP library
+is missing this raises, and if there is no GPU every init() fails with RVC_ERR_NO_DEVICE."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libreevr_amd.so")
+
+F32P = C.POINTER(C.c_float)
+F32PP = C.POINTER(F32P)
+SZP = C.POINTER(C.c_size_t)
+
+RVC_OK, RVC_ERR_NO_DEVICE, RVC_ERR_HIP, RVC_ERR_BAD_ARG, RVC_ERR_UNSUPPORTED, RVC_ERR_NOT_INIT = range(6)
+RVC_FLAG_BG_STREAM = 1
+RVC_FLAG_TIMING = 2
+RVC_FLAG_FFT_F64 = 4
+RVC_MAX_BLOCK = 16384
+
+# name -> (restype, argtypes); must list every symbol declared in include/reevr_amd/rvc.h
+SIGNATURES = {
+    "rvc_set_create": (C.c_void_p, [C.c_int, C.c_int, C.c_uint]),
+    "rvc_set_destroy": (None, [C.c_void_p]),
+    "rvc_set_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, F32PP, SZP, C.c_size_t]),
+    "rvc_set_init_uniform": (C.c_int, [C.c_void_p, C.c_size_t, F32PP, SZP, C.c_size_t]),
+    "rvc_set_process": (None, [C.c_void_p, F32PP, F32PP, C.c_size_t]),
+    "rvc_set_process_device": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "rvc_set_clear": (None, [C.c_void_p]),
+    "rvc_set_reset": (None, [C.c_void_p]),
+    "rvc_set_is_finished": (C.c_int, [C.c_void_p]),
+    "rvc_set_sync": (None, [C.c_void_p]),
+    "rvc_set_channels": (C.c_int, [C.c_void_p]),
+    "rvc_set_head_block": (C.c_size_t, [C.c_void_p]),
+    "rvc_set_tail_block": (C.c_size_t, [C.c_void_p]),
+    "rvc_set_max_len": (C.c_size_t, [C.c_void_p]),
+    "rvc_set_partitions": (C.c_int, [C.c_void_p, C.c_int]),
+    "rvc_set_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "rvc_last_error": (C.c_int, [C.c_void_p]),
+    "rvc_last_error_string": (C.c_char_p, [C.c_void_p]),
+    "rvc_set_kernel_time": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "rvc_set_kernel_time_reset": (None, [C.c_void_p]),
+    "rvc_set_timing": (None, [C.c_void_p, C.c_int]),
+    "rvc_create": (C.c_void_p, [C.c_int]),
+    "rvc_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, F32P, C.c_size_t]),
+    "rvc_process": (None, [C.c_void_p, F32P, F32P, C.c_size_t]),
+    "rvc_clear": (None, [C.c_void_p]),
+    "rvc_reset": (None, [C.c_void_p]),
+    "rvc_is_finished": (C.c_int, [C.c_void_p]),
+    "rvc_destroy": (None, [C.c_void_p]),
+    "rvc_device_count": (C.c_int, []),
+    "rvc_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -m reevr_amd.build, or __graft_entry__.build()). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch bundles its own libamdhip64.so (same SONAME,
+        # libamdhip64.so.7). If it is already loaded the dynamic loader hands that copy to our
+        # library too; loaded the other way round the process ends up with two runtimes and
+        # torch then reports "No HIP GPUs are available". So when torch is installed, import it
+        # first. (C/C++ clients that never load torch just get /opt/rocm's runtime.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        _lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib

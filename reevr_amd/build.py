@@ -1,0 +1,50 @@
+"""Build libreevr_amd.so (HIP kernels + C ABI) in-tree with hipcc for gfx950.
+
+    python -m reevr_amd.build          # or: from reevr_amd.build import build_lib; build_lib()
+
+The shared object lands next to the sources (reevr_amd/csrc/libreevr_amd.so). It is
+git-ignored but travels with the working tree to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libreevr_amd.so")
+SOURCES = ["rvc_kernels.hip", "rvc_engine.cpp"]
+HEADERS = ["rvc_internal.h", os.path.join("..", "..", "include", "reevr_amd", "rvc.h")]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-x", "hip", "-ffp-contract=fast", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+           "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's convolver classes on top of the C ABI.
+
+Same names, argument meaning and error behaviour as the reference (paths relative to the
+reference tree) so parity tests read like the reference's own:
+
+  FFTConvolver            libs/FFTConvolver/FFTConvolver.h:52-80      init/process/clear/reset
+  TwoStageFFTConvolver    libs/FFTConvolver/TwoStageFFTConvolver.h:54-83
+  Convolver               src/dsp/Convolver.h:28-45                   (+ isFinished)
+  StereoConvolver         src/dsp/StereoConvolver.h:7-46              prepare/loadImpulse/process/...
+
+plus ConvolverSet, the batched form the GPU wants (n channels in lock-step, host or
+device-resident buffers). All arithmetic happens in libreevr_amd.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+
+class RvcError(RuntimeError):
+    pass
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class ConvolverSet:
+    """n independent mono convolvers sharing one block geometry (one launch per stage)."""
+
+    def __init__(self, n_channels: int, device: int = 0, bg_stream: bool = False, timing: bool = False,
+                 fft_f64: bool = False):
+        self._lib = L.lib()
+        flags = ((L.RVC_FLAG_BG_STREAM if bg_stream else 0) | (L.RVC_FLAG_TIMING if timing else 0)
+                 | (L.RVC_FLAG_FFT_F64 if fft_f64 else 0))
+        self.n_channels = int(n_channels)
+        self.device = int(device)
+        self._h = self._lib.rvc_set_create(self.n_channels, self.device, flags)
+        if not self._h:
+            raise RvcError("rvc_set_create failed")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rvc_set_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- init ---------------------------------------------------------------------------
+    def _ir_args(self, irs: Sequence[np.ndarray]):
+        if len(irs) != self.n_channels:
+            raise ValueError(f"need {self.n_channels} impulse responses, got {len(irs)}")
+        keep = [_f32(ir).reshape(-1) for ir in irs]   # keep alive during the call
+        ptrs = (L.F32P * self.n_channels)(*[ir.ctypes.data_as(L.F32P) for ir in keep])
+        lens = (C.c_size_t * self.n_channels)(*[ir.size for ir in keep])
+        return keep, ptrs, lens
+
+    def init(self, headBlockSize: int, tailBlockSize: int, irs: Sequence[np.ndarray], max_len: int = 0) -> bool:
+        keep, ptrs, lens = self._ir_args(irs)
+        ok = bool(self._lib.rvc_set_init(self._h, headBlockSize, tailBlockSize, ptrs, lens, max_len))
+        del keep
+        return ok
+
+    def init_uniform(self, blockSize: int, irs: Sequence[np.ndarray], max_len: int = 0) -> bool:
+        keep, ptrs, lens = self._ir_args(irs)
+        ok = bool(self._lib.rvc_set_init_uniform(self._h, blockSize, ptrs, lens, max_len))
+        del keep
+        return ok
+
+    # -- process ------------------------------------------------------------------------
+    def process(self, x: np.ndarray) -> np.ndarray:
+        """x: (n_channels, len) host array -> (n_channels, len) float32."""
+        x = _f32(x)
+        if x.ndim == 1:
+            x = x[None, :]
+        assert x.shape[0] == self.n_channels
+        out = np.empty_like(x)
+        n = x.shape[1]
+        if n == 0:
+            return out
+        ins = (L.F32P * self.n_channels)(*[x[c].ctypes.data_as(L.F32P) for c in range(self.n_channels)])
+        outs = (L.F32P * self.n_channels)(*[out[c].ctypes.data_as(L.F32P) for c in range(self.n_channels)])
+        self._lib.rvc_set_process(self._h, ins, outs, n)
+        return out
+
+    def process_device(self, d_in, d_out=None, sync: bool = True):
+        """d_in / d_out: torch float32 CUDA tensors (n_channels, len), last dim contiguous.
+        Runs on the set's own HIP stream; with sync=True waits for completion."""
+        import torch
+        assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
+        assert d_in.shape[0] == self.n_channels
+        if d_out is None:
+            d_out = torch.empty_like(d_in)
+        assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.shape == d_in.shape and d_out.stride(1) == 1
+        self._lib.rvc_set_process_device(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(),
+                                         d_out.stride(0), d_in.shape[1])
+        if sync:
+            self.sync()
+            self.check()
+        return d_out
+
+    # -- state --------------------------------------------------------------------------
+    def clear(self):
+        self._lib.rvc_set_clear(self._h)
+
+    def reset(self):
+        self._lib.rvc_set_reset(self._h)
+
+    def isFinished(self) -> bool:
+        return bool(self._lib.rvc_set_is_finished(self._h))
+
+    def sync(self):
+        self._lib.rvc_set_sync(self._h)
+
+    # -- introspection ------------------------------------------------------------------
+    @property
+    def head_block(self) -> int:
+        return int(self._lib.rvc_set_head_block(self._h))
+
+    @property
+    def tail_block(self) -> int:
+        return int(self._lib.rvc_set_tail_block(self._h))
+
+    @property
+    def max_len(self) -> int:
+        return int(self._lib.rvc_set_max_len(self._h))
+
+    def partitions(self, stage: int) -> int:
+        return int(self._lib.rvc_set_partitions(self._h, stage))
+
+    def stream(self, which: int = 0) -> int:
+        return int(self._lib.rvc_set_stream(self._h, which) or 0)
+
+    @property
+    def last_error(self) -> int:
+        return int(self._lib.rvc_last_error(self._h))
+
+    @property
+    def last_error_string(self) -> str:
+        return (self._lib.rvc_last_error_string(self._h) or b"").decode()
+
+    def check(self):
+        if self.last_error != L.RVC_OK:
+            raise RvcError(f"rvc error {self.last_error}: {self.last_error_string}")
+
+    def set_timing(self, on: bool):
+        self._lib.rvc_set_timing(self._h, int(on))
+
+    def kernel_time(self, kernel: int):
+        """(launches, total_ms) of one kernel family since the last reset."""
+        ms = C.c_double(0.0)
+        n = self._lib.rvc_set_kernel_time(self._h, kernel, C.byref(ms))
+        return int(n), float(ms.value)
+
+    def kernel_time_reset(self):
+        self._lib.rvc_set_kernel_time_reset(self._h)
+
+
+KERNEL_NAMES = ["ingest", "fft_fwd_head", "fir_head", "fft_inv_head", "fft_fwd_tail", "fir_tail", "fft_inv_tail"]
+
+
+class _Mono:
+    """One mono convolver: the reference's per-object surface on a 1-channel set."""
+
+    def __init__(self, device: int = 0, bg_stream: bool = True, fft_f64: bool = False):
+        self._set = ConvolverSet(1, device, bg_stream=bg_stream, fft_f64=fft_f64)
+
+    def process(self, input: np.ndarray) -> np.ndarray:
+        x = _f32(input).reshape(-1)
+        return self._set.process(x[None, :])[0]
+
+    def clear(self):
+        self._set.clear()
+
+    def reset(self):
+        self._set.reset()
+
+    @property
+    def last_error(self) -> int:
+        return self._set.last_error
+
+
+class FFTConvolver(_Mono):
+    """fftconvolver::FFTConvolver (FFTConvolver.h:52-80)."""
+
+    def __init__(self, device: int = 0, fft_f64: bool = False):
+        super().__init__(device, bg_stream=False, fft_f64=fft_f64)
+
+    def init(self, blockSize: int, ir: np.ndarray, max_len: int = 0) -> bool:
+        return self._set.init_uniform(blockSize, [ir], max_len)
+
+
+class TwoStageFFTConvolver(_Mono):
+    """fftconvolver::TwoStageFFTConvolver (TwoStageFFTConvolver.h:54-83); tail inline on one stream."""
+
+    def __init__(self, device: int = 0, bg_stream: bool = False, fft_f64: bool = False):
+        super().__init__(device, bg_stream=bg_stream, fft_f64=fft_f64)
+
+    def init(self, headBlockSize: int, tailBlockSize: int, ir: np.ndarray, max_len: int = 0) -> bool:
+        return self._set.init(headBlockSize, tailBlockSize, [ir], max_len)
+
+
+class Convolver(TwoStageFFTConvolver):
+    """src/dsp/Convolver.h:28-45: the two-stage convolver whose tail runs in the background
+    (there a juce::Thread, here a second HIP stream with events at the same hook points)."""
+
+    def __init__(self, device: int = 0, fft_f64: bool = False):
+        super().__init__(device, bg_stream=True, fft_f64=fft_f64)
+
+    def isFinished(self) -> bool:
+        return self._set.isFinished()
+
+
+class StereoConvolver:
+    """src/dsp/StereoConvolver.{h,cpp}: LL/RR (+LR/RL when the impulse is quad) convolvers and
+    their output buffers. `imp` is any object with bufferLL/bufferRR[/bufferLR/bufferRL] arrays
+    and an isQuad flag (the reference's Impulse, src/dsp/Impulse.h)."""
+
+    def __init__(self, device: int = 0):
+        self._device = device
+        self._main = ConvolverSet(2, device, bg_stream=True)    # LL, RR
+        self._cross = ConvolverSet(2, device, bg_stream=True)   # LR, RL
+        self.bufferLL = np.zeros(0, np.float32)
+        self.bufferRR = np.zeros(0, np.float32)
+        self.bufferLR = np.zeros(0, np.float32)
+        self.bufferRL = np.zeros(0, np.float32)
+        self.size = 0
+        self.isQuad = False
+        self.headBlockSize = 0
+        self.tailBlockSize = 0
+
+    def finishedLoading(self) -> bool:           # StereoConvolver.cpp:3-6
+        return self._main.isFinished()
+
+    def prepare(self, samplesPerBlock: int):     # StereoConvolver.cpp:8-20
+        self.size = int(samplesPerBlock)
+        self.headBlockSize = 1
+        while self.headBlockSize < samplesPerBlock:
+            self.headBlockSize *= 2
+        self.tailBlockSize = max(8192, 2 * self.headBlockSize)
+        for name in ("bufferLL", "bufferRR", "bufferLR", "bufferRL"):
+            setattr(self, name, np.zeros(self.size, np.float32))
+
+    def loadImpulse(self, imp):                  # StereoConvolver.cpp:22-31
+        self._main.init(self.headBlockSize, self.tailBlockSize, [imp.bufferLL, imp.bufferRR], self.size)
+        self.isQuad = bool(imp.isQuad)
+        if self.isQuad:
+            self._cross.init(self.headBlockSize, self.tailBlockSize, [imp.bufferLR, imp.bufferRL], self.size)
+
+    def process(self, dataL: np.ndarray, dataR: np.ndarray, nsamples: int, force2Chans: bool = False):
+        # StereoConvolver.cpp:33-42
+        x = np.stack([_f32(dataL)[:nsamples], _f32(dataR)[:nsamples]])
+        y = self._main.process(x)
+        self.bufferLL[:nsamples] = y[0]
+        self.bufferRR[:nsamples] = y[1]
+        if self.isQuad and not force2Chans:
+            z = self._cross.process(x)           # LR is fed L, RL is fed R
+            self.bufferLR[:nsamples] = z[0]
+            self.bufferRL[:nsamples] = z[1]
+
+    def reset(self):                             # StereoConvolver.cpp:44-54
+        self._main.reset()
+        self._cross.reset()
+        for name in ("bufferLL", "bufferRR", "bufferLR", "bufferRL"):
+            setattr(self, name, np.zeros(0, np.float32))
+
+    def clear(self):                             # StereoConvolver.cpp:56-62
+        self._main.clear()
+        self._cross.clear()

@@ -1,0 +1,644 @@
+// rvc_engine.cpp -- host side of the MI355X partitioned-convolution engine: device state,
+// the absolute-time block scheduler, streams/events, and the C ABI of include/reevr_amd/rvc.h.
+//
+// What it replaces in the reference (paths relative to the reference tree):
+//   TwoStageFFTConvolver::{init,process,clear,reset}   libs/FFTConvolver/TwoStageFFTConvolver.cpp:51-233
+//   FFTConvolver::{init,process,clear,reset}           libs/FFTConvolver/FFTConvolver.cpp:56-212
+//   Convolver's background thread + WaitableEvent      src/dsp/Convolver.cpp:21-95  -> second HIP stream + events
+//   StereoConvolver's 2-4 way fan-out                  src/dsp/StereoConvolver.cpp:22-62 -> channels of one set
+//
+// Scheme. The reference computes y = x * ir with three overlap-add sub-convolvers: head
+// (IR[0,T), block h), tail0 (IR[T,2T), block h, result delivered T samples later) and tail
+// (IR[2T,..), block T, result delivered 2T later). Here the same sum is organised as two
+// overlap-save stages driven by ABSOLUTE sample time n (samples since clear()):
+//   stage A (zero latency): block h, partitions of IR[0,2T)  -- head and tail0 share their input
+//            spectra, so they are one delay line of up to 2T/h partitions, one FFT, one IFFT;
+//   stage T (tail):         block T, partitions of IR[2T,..), Y_m = sum_i H_i X_{m-2-i}: the
+//            contribution to output block m needs input blocks <= m-2 only, so it is computed one
+//            whole tail period ahead (exactly the slack the reference gives its background
+//            thread) into a time-indexed ring that stage A's epilogue adds.
+// Every buffer is a ring indexed by absolute sample / block number, so a process() call of ANY
+// length (one 512-sample block, a ragged 37 samples, or 40 s at once) is the same four steps:
+// ingest -> [tail: FFT new blocks, FIR, IFFT -> tail ring] -> stage A: FFT, FIR, IFFT(+tail) -> out.
+// A block that a call leaves partly filled is simply transformed again (zero-padded) by the
+// next call, like FFTConvolver.cpp:164-173. clear() just restarts the clock.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/reevr_amd/rvc.h"
+#include "rvc_internal.h"
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr int kNumKernelIds = 7;
+
+size_t next_pow2(size_t v) {   // Utilities.h:280-289
+  size_t p = 1;
+  while (p < v) p *= 2;
+  return p;
+}
+int ilog2(size_t v) {
+  int l = 0;
+  while (((size_t)1 << l) < v) ++l;
+  return l;
+}
+
+struct Stage {
+  int logB = 0;
+  size_t B = 0;
+  int P = 0;          // partitions (max over channels); 0 = stage absent
+  int delay = 0;      // block delay of the delay line (0 or 2)
+  size_t rows = 0;    // X ring rows (power of two)
+  size_t mcap = 0;    // Y rows (max output rows per call)
+  float2 *H = nullptr, *X = nullptr, *Y = nullptr;
+  float2 *tw = nullptr, *wsplit = nullptr;       // float twiddles
+  double2 *twd = nullptr, *wsplitd = nullptr;    // double twiddles (B <= 8192): IR spectra, f64 mode
+  bool f64 = false;                              // run this stage's transforms in double
+  const void *twp() const { return f64 ? (const void *)twd : (const void *)tw; }
+  const void *wsp() const { return f64 ? (const void *)wsplitd : (const void *)wsplit; }
+};
+
+struct TimedLaunch {
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct rvc_set {
+  int nch = 0;
+  int device = 0;
+  unsigned flags = 0;
+  int err = RVC_OK;
+  std::string errstr;
+
+  bool inited = false;   // init succeeded (possibly with an empty IR)
+  bool live = false;     // device state exists (non-empty IR)
+  size_t head = 0, tail = 0, max_len = 0;
+  Stage A, T;
+  float *xring = nullptr, *tailring = nullptr;
+  size_t ring_cap = 0;
+  float *d_in = nullptr, *d_out = nullptr;     // staging for the host-pointer API [nch][max_len]
+  float *h_in = nullptr, *h_out = nullptr;     // pinned
+  long long n = 0;               // absolute sample clock
+  long long tail_fft_done = 0;   // tail blocks [0, tail_fft_done) have spectra
+  long long tail_out_done = 2;   // tail contributions for output blocks [2, tail_out_done) are in the ring
+
+  hipStream_t st_main = nullptr, st_bg = nullptr;
+  bool streams_ok = false;
+  hipEvent_t ev_ingest = nullptr;
+  struct Job { long long m_hi; hipEvent_t ev; };
+  std::deque<Job> jobs;          // tail jobs enqueued on st_bg, oldest first
+  std::vector<hipEvent_t> ev_pool;
+
+  bool timing = false;
+  std::vector<TimedLaunch> timed[kNumKernelIds];
+};
+
+namespace {
+
+bool fail(rvc_set *s, int code, hipError_t e, const char *what) {
+  if (s->err == RVC_OK) {
+    s->err = code;
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s: %s", what, e == hipSuccess ? "invalid argument" : hipGetErrorString(e));
+    s->errstr = buf;
+  }
+  return false;
+}
+
+#define RVC_CK(expr)                                              \
+  do {                                                            \
+    hipError_t e__ = (expr);                                      \
+    if (e__ != hipSuccess) return fail(s, RVC_ERR_HIP, e__, #expr); \
+  } while (0)
+
+bool use_device(rvc_set *s) {
+  hipError_t e = hipSetDevice(s->device);
+  if (e != hipSuccess) return fail(s, RVC_ERR_NO_DEVICE, e, "hipSetDevice");
+  return true;
+}
+
+bool ensure_streams(rvc_set *s) {
+  if (s->streams_ok) return true;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= s->device)
+    return fail(s, RVC_ERR_NO_DEVICE, e, "no usable HIP device (this engine has no CPU fallback)");
+  if (!use_device(s)) return false;
+  RVC_CK(rvc::prepare_kernels());
+  RVC_CK(hipStreamCreateWithFlags(&s->st_main, hipStreamNonBlocking));
+  RVC_CK(hipStreamCreateWithFlags(&s->st_bg, hipStreamNonBlocking));
+  RVC_CK(hipEventCreateWithFlags(&s->ev_ingest, hipEventDisableTiming));
+  s->streams_ok = true;
+  return true;
+}
+
+void free_stage(Stage &g) {
+  hipFree(g.H); hipFree(g.X); hipFree(g.Y); hipFree(g.tw); hipFree(g.wsplit);
+  hipFree(g.twd); hipFree(g.wsplitd);
+  g = Stage();
+}
+
+void drop_timing(rvc_set *s) {
+  for (auto &v : s->timed) {
+    for (auto &t : v) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    v.clear();
+  }
+}
+
+void free_device_state(rvc_set *s) {
+  if (s->streams_ok) {
+    hipSetDevice(s->device);
+    hipStreamSynchronize(s->st_bg);
+    hipStreamSynchronize(s->st_main);
+  }
+  for (auto &j : s->jobs) s->ev_pool.push_back(j.ev);
+  s->jobs.clear();
+  drop_timing(s);
+  free_stage(s->A);
+  free_stage(s->T);
+  hipFree(s->xring); hipFree(s->tailring); hipFree(s->d_in); hipFree(s->d_out);
+  if (s->h_in) hipHostFree(s->h_in);
+  if (s->h_out) hipHostFree(s->h_out);
+  s->xring = s->tailring = s->d_in = s->d_out = s->h_in = s->h_out = nullptr;
+  s->ring_cap = 0;
+  s->live = false;
+  s->inited = false;
+  s->head = s->tail = s->max_len = 0;
+  s->n = 0;
+  s->tail_fft_done = 0;
+  s->tail_out_done = 2;
+}
+
+bool make_twiddles(rvc_set *s, Stage &g) {
+  const size_t B = g.B;
+  std::vector<float2> tw(B), ws(B / 2 + 1);
+  std::vector<double2> twd(B), wsd(B / 2 + 1);
+  for (size_t j = 0; j < B; ++j) {
+    const double ang = -2.0 * kPi * (double)j / (double)B;
+    twd[j] = make_double2(std::cos(ang), std::sin(ang));
+    tw[j] = make_float2((float)twd[j].x, (float)twd[j].y);
+  }
+  for (size_t k = 0; k <= B / 2; ++k) {
+    const double ang = -kPi * (double)k / (double)B;
+    wsd[k] = make_double2(std::cos(ang), std::sin(ang));
+    ws[k] = make_float2((float)wsd[k].x, (float)wsd[k].y);
+  }
+  RVC_CK(hipMalloc(&g.tw, sizeof(float2) * B));
+  RVC_CK(hipMalloc(&g.wsplit, sizeof(float2) * (B / 2 + 1)));
+  RVC_CK(hipMemcpy(g.tw, tw.data(), sizeof(float2) * B, hipMemcpyHostToDevice));
+  RVC_CK(hipMemcpy(g.wsplit, ws.data(), sizeof(float2) * (B / 2 + 1), hipMemcpyHostToDevice));
+  if (g.logB <= 13) {   // the double transform needs B * 16 bytes of LDS <= 128 KiB
+    RVC_CK(hipMalloc(&g.twd, sizeof(double2) * B));
+    RVC_CK(hipMalloc(&g.wsplitd, sizeof(double2) * (B / 2 + 1)));
+    RVC_CK(hipMemcpy(g.twd, twd.data(), sizeof(double2) * B, hipMemcpyHostToDevice));
+    RVC_CK(hipMemcpy(g.wsplitd, wsd.data(), sizeof(double2) * (B / 2 + 1), hipMemcpyHostToDevice));
+  }
+  return true;
+}
+
+// IR partitions -> spectra: one batched forward launch over all partitions of all channels
+// (replaces the per-partition loop FFTConvolver.cpp:129-137).
+bool upload_ir_stage(rvc_set *s, Stage &g, const std::vector<std::vector<float>> &parts) {
+  const size_t padded = (size_t)g.P * g.B;
+  std::vector<float> host((size_t)s->nch * padded, 0.f);
+  for (int c = 0; c < s->nch; ++c)
+    std::copy(parts[c].begin(), parts[c].end(), host.begin() + (size_t)c * padded);
+  float *d_ir = nullptr;
+  RVC_CK(hipMalloc(&d_ir, sizeof(float) * host.size()));
+  RVC_CK(hipMemcpy(d_ir, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
+  RVC_CK(hipMalloc(&g.H, sizeof(float2) * (size_t)s->nch * g.P * g.B));
+  rvc::FwdArgs a{};
+  a.src = d_ir; a.src_chan_stride = (long long)padded; a.src_mask = ~0ull;
+  a.seg0 = 0; a.valid_len = (int)g.B; a.lo = 0; a.hi = (long long)padded;
+  // One-off, so always in double where the LDS allows it (B <= 8192): the IR spectra then carry
+  // only the float rounding of the stored bins, like the reference's (AudioFFT.cpp:114-137).
+  const bool ir64 = g.twd != nullptr;
+  a.tw = ir64 ? (const void *)g.twd : (const void *)g.tw;
+  a.wsplit = ir64 ? (const void *)g.wsplitd : (const void *)g.wsplit;
+  a.dst = g.H; a.dst_chan_stride = (long long)g.P * (long long)g.B; a.row0 = 0; a.row_mask = ~0ull;
+  hipError_t e = rvc::launch_fft_fwd(g.logB, ir64, a, g.P, s->nch, s->st_main);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->st_main);
+  hipFree(d_ir);
+  if (e != hipSuccess) return fail(s, RVC_ERR_HIP, e, "IR spectra");
+  return true;
+}
+
+bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
+             const float *const *irs, const size_t *ir_lens, size_t max_len) {
+  if (s->streams_ok || s->live) free_device_state(s);
+  s->err = RVC_OK;
+  s->errstr.clear();
+  if (head_block == 0 || (two_stage && tail_block == 0)) {   // TwoStageFFTConvolver.cpp:94-97, FFTConvolver.cpp:97-100
+    s->err = RVC_ERR_BAD_ARG;
+    s->errstr = "block size 0";
+    return false;
+  }
+  if (!irs || !ir_lens) return fail(s, RVC_ERR_BAD_ARG, hipSuccess, "irs");
+  if (two_stage && head_block > tail_block) std::swap(head_block, tail_block);   // :100-104
+
+  // trailing |x| < 1e-6 is ignored (TwoStageFFTConvolver.cpp:107-110, FFTConvolver.cpp:102-106)
+  std::vector<size_t> len(s->nch);
+  size_t longest = 0;
+  for (int c = 0; c < s->nch; ++c) {
+    size_t l = irs[c] ? ir_lens[c] : 0;
+    while (l > 0 && std::fabs(irs[c][l - 1]) < 0.000001f) --l;
+    len[c] = l;
+    longest = std::max(longest, l);
+  }
+  const size_t hb = next_pow2(head_block);
+  const size_t tb = two_stage ? next_pow2(tail_block) : 0;
+  const bool want64 = (s->flags & RVC_FLAG_FFT_F64) != 0;
+  const size_t max_block = want64 ? RVC_MAX_BLOCK / 2 : RVC_MAX_BLOCK;
+  if (hb > max_block || tb > max_block) {
+    s->err = RVC_ERR_UNSUPPORTED;
+    s->errstr = want64 ? "block size above RVC_MAX_BLOCK/2 (f64 FFT mode)" : "block size above RVC_MAX_BLOCK";
+    return false;
+  }
+  if (longest == 0) {   // empty IR: success, process() gives zeros (:112-115)
+    s->inited = true;
+    s->head = hb; s->tail = tb; s->max_len = max_len ? max_len : hb;
+    return true;
+  }
+  if (!ensure_streams(s)) return false;
+  if (!use_device(s)) return false;
+
+  s->head = hb;
+  s->tail = tb;
+  s->max_len = max_len ? max_len : hb;
+  const size_t split = two_stage ? 2 * tb : (size_t)-1;
+
+  // partition counts (ceil(float/float) as FFTConvolver.cpp:115; exact below 2^24 samples)
+  std::vector<std::vector<float>> partsA(s->nch), partsT(s->nch);
+  size_t pa = 0, pt = 0;
+  for (int c = 0; c < s->nch; ++c) {
+    const size_t la = std::min(len[c], split);
+    partsA[c].assign(irs[c], irs[c] + la);
+    pa = std::max(pa, (la + hb - 1) / hb);
+    if (len[c] > split) {
+      partsT[c].assign(irs[c] + split, irs[c] + len[c]);
+      pt = std::max(pt, (len[c] - split + tb - 1) / tb);
+    }
+  }
+  Stage &A = s->A, &T = s->T;
+  A.B = hb; A.logB = ilog2(hb); A.P = (int)pa; A.delay = 0; A.f64 = want64;
+  A.mcap = s->max_len / hb + 2;
+  A.rows = next_pow2(pa + A.mcap + 1);
+  if (!make_twiddles(s, A)) return false;
+  if (!upload_ir_stage(s, A, partsA)) return false;
+  RVC_CK(hipMalloc(&A.X, sizeof(float2) * (size_t)s->nch * A.rows * A.B));
+  RVC_CK(hipMalloc(&A.Y, sizeof(float2) * (size_t)s->nch * A.mcap * A.B));
+  if (pt > 0) {
+    T.B = tb; T.logB = ilog2(tb); T.P = (int)pt; T.delay = 2; T.f64 = want64;
+    T.mcap = s->max_len / tb + 3;
+    T.rows = next_pow2(pt + 2 + T.mcap + 1);
+    if (!make_twiddles(s, T)) return false;
+    if (!upload_ir_stage(s, T, partsT)) return false;
+    RVC_CK(hipMalloc(&T.X, sizeof(float2) * (size_t)s->nch * T.rows * T.B));
+    RVC_CK(hipMalloc(&T.Y, sizeof(float2) * (size_t)s->nch * T.mcap * T.B));
+  }
+  const size_t span = std::max(hb, tb);
+  s->ring_cap = next_pow2(s->max_len + 4 * span);
+  RVC_CK(hipMalloc(&s->xring, sizeof(float) * (size_t)s->nch * s->ring_cap));
+  if (pt > 0) RVC_CK(hipMalloc(&s->tailring, sizeof(float) * (size_t)s->nch * s->ring_cap));
+  RVC_CK(hipMalloc(&s->d_in, sizeof(float) * (size_t)s->nch * s->max_len));
+  RVC_CK(hipMalloc(&s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
+  RVC_CK(hipHostMalloc(&s->h_in, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
+  RVC_CK(hipHostMalloc(&s->h_out, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
+  RVC_CK(hipDeviceSynchronize());
+  s->n = 0;
+  s->tail_fft_done = 0;
+  s->tail_out_done = 2;
+  s->live = true;
+  s->inited = true;
+  return true;
+}
+
+hipEvent_t get_event(rvc_set *s) {
+  if (!s->ev_pool.empty()) {
+    hipEvent_t e = s->ev_pool.back();
+    s->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  return e;
+}
+
+struct Timer {   // brackets one launch with events when timing is on
+  rvc_set *s; int id; hipStream_t st; TimedLaunch t{}; bool on;
+  Timer(rvc_set *s_, int id_, hipStream_t st_) : s(s_), id(id_), st(st_), on(s_->timing) {
+    if (on) { hipEventCreate(&t.a); hipEventCreate(&t.b); hipEventRecord(t.a, st); }
+  }
+  ~Timer() {
+    if (on) { hipEventRecord(t.b, st); s->timed[id].push_back(t); }
+  }
+};
+
+// one process() step of at most max_len samples, device buffers, asynchronous
+bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len) {
+  Stage &A = s->A, &T = s->T;
+  const long long n0 = s->n, n1 = n0 + (long long)len;
+  const bool has_tail = T.P > 0;
+  const bool bg = has_tail && (s->flags & RVC_FLAG_BG_STREAM);
+
+  {   // 1. ingest the call's input into the time ring
+    rvc::IngestArgs a{};
+    a.src = d_in; a.src_chan_stride = (long long)in_stride;
+    a.ring = s->xring; a.ring_chan_stride = (long long)s->ring_cap; a.ring_mask = s->ring_cap - 1;
+    a.n0 = n0; a.len = (long long)len;
+    Timer t(s, 0, s->st_main);
+    RVC_CK(rvc::launch_ingest(a, s->nch, s->st_main));
+  }
+
+  if (has_tail) {   // 2. tail stage, one tail period ahead (TwoStageFFTConvolver.cpp:213-222, :247-250)
+    const long long tb = (long long)T.B;
+    const long long mb0 = s->tail_fft_done, mb1 = n1 / tb;   // tail blocks [mb0, mb1) completed by this call
+    if (mb1 > mb0) {
+      hipStream_t st = bg ? s->st_bg : s->st_main;
+      if (bg) {   // startBackgroundProcessing: the job may start once its input is in the ring
+        RVC_CK(hipEventRecord(s->ev_ingest, s->st_main));
+        RVC_CK(hipStreamWaitEvent(st, s->ev_ingest, 0));
+      }
+      rvc::FwdArgs f{};
+      f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
+      f.seg0 = (mb0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
+      f.tw = T.twp(); f.wsplit = T.wsp();
+      f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = mb0; f.row_mask = T.rows - 1;
+      {
+        Timer t(s, 4, st);
+        RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(mb1 - mb0), s->nch, st));
+      }
+      const long long m_lo = s->tail_out_done, m_hi = mb1 + 2;   // output blocks whose inputs now exist
+      rvc::FirArgs r{};
+      r.H = T.H; r.h_chan_stride = (long long)T.P * tb;
+      r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
+      r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
+      r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = 2; r.B = (int)tb;
+      {
+        Timer t(s, 5, st);
+        RVC_CK(rvc::launch_fir(r, s->nch, st));
+      }
+      rvc::InvArgs v{};
+      v.Y = T.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp();
+      v.blk0 = m_lo;
+      v.dst = s->tailring; v.dst_chan_stride = (long long)s->ring_cap; v.dst_origin = 0; v.dst_mask = s->ring_cap - 1;
+      v.lo = 0; v.hi = (long long)1 << 62;
+      v.add = nullptr;
+      {
+        Timer t(s, 6, st);
+        RVC_CK(rvc::launch_fft_inv(T.logB, T.f64, v, r.M, s->nch, st));
+      }
+      s->tail_fft_done = mb1;
+      s->tail_out_done = m_hi;
+      if (bg) {
+        rvc_set::Job j{m_hi, get_event(s)};
+        RVC_CK(hipEventRecord(j.ev, st));
+        s->jobs.push_back(j);
+      }
+    }
+  }
+
+  // 3. zero-latency stage: blocks k0..k1 touched by this call
+  const long long hb = (long long)A.B;
+  const long long k0 = n0 / hb, k1 = (n1 - 1) / hb;
+  const int M = (int)(k1 - k0 + 1);
+  rvc::FwdArgs f{};
+  f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
+  f.seg0 = (k0 - 1) * hb; f.valid_len = (int)(2 * hb); f.lo = 0; f.hi = n1;
+  f.tw = A.twp(); f.wsplit = A.wsp();
+  f.dst = A.X; f.dst_chan_stride = (long long)A.rows * hb; f.row0 = k0; f.row_mask = A.rows - 1;
+  {
+    Timer t(s, 1, s->st_main);
+    RVC_CK(rvc::launch_fft_fwd(A.logB, A.f64, f, M, s->nch, s->st_main));
+  }
+  rvc::FirArgs r{};
+  r.H = A.H; r.h_chan_stride = (long long)A.P * hb;
+  r.X = A.X; r.x_chan_stride = (long long)A.rows * hb; r.x_row_mask = A.rows - 1;
+  r.Y = A.Y; r.y_chan_stride = (long long)A.mcap * hb;
+  r.k0 = k0; r.M = M; r.P = A.P; r.delay = 0; r.B = (int)hb;
+  {
+    Timer t(s, 2, s->st_main);
+    RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
+  }
+  if (bg) {   // waitForBackgroundProcessing: the job that produced the tail blocks this call reads
+    const long long m_need = (n1 - 1) / (long long)T.B;
+    while (!s->jobs.empty() && m_need >= 2) {
+      rvc_set::Job j = s->jobs.front();
+      // jobs are ordered; every job up to the first one covering m_need must have finished
+      RVC_CK(hipStreamWaitEvent(s->st_main, j.ev, 0));
+      s->jobs.pop_front();
+      s->ev_pool.push_back(j.ev);
+      if (j.m_hi > m_need) break;
+    }
+  }
+  rvc::InvArgs v{};
+  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(); v.wsplit = A.wsp();
+  v.blk0 = k0;
+  v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
+  v.lo = n0; v.hi = n1;
+  v.add = has_tail ? s->tailring : nullptr;
+  v.add_chan_stride = (long long)s->ring_cap; v.add_mask = s->ring_cap - 1;
+  v.add_from = has_tail ? 2 * (long long)T.B : 0;
+  {
+    Timer t(s, 3, s->st_main);
+    RVC_CK(rvc::launch_fft_inv(A.logB, A.f64, v, M, s->nch, s->st_main));
+  }
+  s->n = n1;
+  return true;
+}
+
+bool zero_device_out(rvc_set *s, float *d_out, size_t out_stride, size_t len) {
+  if (!s->streams_ok || len == 0) return true;
+  RVC_CK(hipMemset2DAsync(d_out, out_stride * sizeof(float), 0, len * sizeof(float), (size_t)s->nch, s->st_main));
+  return true;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+rvc_set *rvc_set_create(int n_channels, int device, unsigned flags) {
+  if (n_channels < 1) return nullptr;
+  rvc_set *s = new (std::nothrow) rvc_set();
+  if (!s) return nullptr;
+  s->nch = n_channels;
+  s->device = device;
+  s->flags = flags;
+  s->timing = (flags & RVC_FLAG_TIMING) != 0;
+  return s;
+}
+
+void rvc_set_destroy(rvc_set *s) {
+  if (!s) return;
+  free_device_state(s);
+  if (s->streams_ok) {
+    for (auto e : s->ev_pool) hipEventDestroy(e);
+    hipEventDestroy(s->ev_ingest);
+    hipStreamDestroy(s->st_bg);
+    hipStreamDestroy(s->st_main);
+  }
+  delete s;
+}
+
+int rvc_set_init(rvc_set *s, size_t head_block, size_t tail_block, const float *const *irs,
+                 const size_t *ir_lens, size_t max_len) {
+  if (!s) return 0;
+  const bool ok = do_init(s, head_block, tail_block, true, irs, ir_lens, max_len);
+  if (!ok && s->live) free_device_state(s);
+  return ok ? 1 : 0;
+}
+
+int rvc_set_init_uniform(rvc_set *s, size_t block, const float *const *irs, const size_t *ir_lens,
+                         size_t max_len) {
+  if (!s) return 0;
+  const bool ok = do_init(s, block, 0, false, irs, ir_lens, max_len);
+  if (!ok && s->live) free_device_state(s);
+  return ok ? 1 : 0;
+}
+
+void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out,
+                            size_t out_stride, size_t len) {
+  if (!s || len == 0) return;
+  if (!s->live || s->err != RVC_OK) {   // not initialised / empty IR / failed: zeros
+    zero_device_out(s, d_out, out_stride, len);
+    return;
+  }
+  if (!use_device(s)) return;
+  size_t done = 0;
+  while (done < len) {   // calls longer than max_len are split; results are call-pattern independent
+    const size_t chunk = std::min(len - done, s->max_len);
+    if (!step_device(s, d_in + done, in_stride, d_out + done, out_stride, chunk)) {
+      zero_device_out(s, d_out, out_stride, len);
+      return;
+    }
+    done += chunk;
+  }
+}
+
+void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size_t len) {
+  if (!s || len == 0 || !out) return;
+  auto zeros = [&]() {
+    for (int c = 0; c < s->nch; ++c)
+      if (out[c]) std::memset(out[c], 0, len * sizeof(float));
+  };
+  if (!s->live || s->err != RVC_OK || !in) { zeros(); return; }
+  if (!use_device(s)) { zeros(); return; }
+  size_t done = 0;
+  while (done < len) {
+    const size_t chunk = std::min(len - done, s->max_len);
+    for (int c = 0; c < s->nch; ++c) std::memcpy(s->h_in + (size_t)c * chunk, in[c] + done, chunk * sizeof(float));
+    bool ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * chunk * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
+    ok = ok && step_device(s, s->d_in, chunk, s->d_out, chunk, chunk);
+    ok = ok && hipMemcpyAsync(s->h_out, s->d_out, sizeof(float) * chunk * s->nch, hipMemcpyDeviceToHost, s->st_main) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s->st_main) == hipSuccess;
+    if (!ok) {
+      fail(s, RVC_ERR_HIP, hipGetLastError(), "process");
+      zeros();
+      return;
+    }
+    for (int c = 0; c < s->nch; ++c) std::memcpy(out[c] + done, s->h_out + (size_t)c * chunk, chunk * sizeof(float));
+    done += chunk;
+  }
+}
+
+void rvc_set_clear(rvc_set *s) {
+  if (!s || !s->live) return;
+  // Outstanding tail jobs still write into rings; let them finish, then restart the clock.
+  hipSetDevice(s->device);
+  hipStreamSynchronize(s->st_bg);
+  hipStreamSynchronize(s->st_main);
+  for (auto &j : s->jobs) s->ev_pool.push_back(j.ev);
+  s->jobs.clear();
+  s->n = 0;
+  s->tail_fft_done = 0;
+  s->tail_out_done = 2;
+}
+
+void rvc_set_reset(rvc_set *s) {
+  if (!s) return;
+  free_device_state(s);
+  s->err = RVC_OK;
+  s->errstr.clear();
+}
+
+int rvc_set_is_finished(rvc_set *s) {
+  if (!s || !s->live) return 1;
+  hipSetDevice(s->device);
+  return hipStreamQuery(s->st_bg) == hipSuccess ? 1 : 0;
+}
+
+void rvc_set_sync(rvc_set *s) {
+  if (!s || !s->streams_ok) return;
+  hipSetDevice(s->device);
+  hipStreamSynchronize(s->st_bg);
+  hipStreamSynchronize(s->st_main);
+}
+
+int rvc_set_channels(const rvc_set *s) { return s ? s->nch : 0; }
+size_t rvc_set_head_block(const rvc_set *s) { return s ? s->head : 0; }
+size_t rvc_set_tail_block(const rvc_set *s) { return s ? s->tail : 0; }
+size_t rvc_set_max_len(const rvc_set *s) { return s ? s->max_len : 0; }
+int rvc_set_partitions(const rvc_set *s, int stage) { return !s ? 0 : (stage == 0 ? s->A.P : s->T.P); }
+void *rvc_set_stream(rvc_set *s, int which) { return !s ? nullptr : (which == 0 ? (void *)s->st_main : (void *)s->st_bg); }
+int rvc_last_error(const rvc_set *s) { return s ? s->err : RVC_ERR_BAD_ARG; }
+const char *rvc_last_error_string(const rvc_set *s) { return s ? s->errstr.c_str() : "null handle"; }
+
+long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms) {
+  if (total_ms) *total_ms = 0.0;
+  if (!s || kernel < 0 || kernel >= kNumKernelIds) return 0;
+  rvc_set_sync(s);
+  double tot = 0.0;
+  for (auto &t : s->timed[kernel]) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  return (long)s->timed[kernel].size();
+}
+
+void rvc_set_kernel_time_reset(rvc_set *s) {
+  if (!s) return;
+  rvc_set_sync(s);
+  drop_timing(s);
+}
+
+void rvc_set_timing(rvc_set *s, int enable) {
+  if (s) s->timing = enable != 0;
+}
+
+rvc_set *rvc_create(int device) { return rvc_set_create(1, device, RVC_FLAG_BG_STREAM); }
+int rvc_init(rvc_set *h, size_t head_block, size_t tail_block, const float *ir, size_t ir_len) {
+  const float *irs[1] = {ir};
+  const size_t lens[1] = {ir_len};
+  return rvc_set_init(h, head_block, tail_block, irs, lens, 0);
+}
+void rvc_process(rvc_set *h, const float *in, float *out, size_t len) {
+  const float *ins[1] = {in};
+  float *outs[1] = {out};
+  rvc_set_process(h, ins, outs, len);
+}
+void rvc_clear(rvc_set *h) { rvc_set_clear(h); }
+void rvc_reset(rvc_set *h) { rvc_set_reset(h); }
+int rvc_is_finished(rvc_set *h) { return rvc_set_is_finished(h); }
+void rvc_destroy(rvc_set *h) { rvc_set_destroy(h); }
+
+int rvc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+const char *rvc_version(void) { return "reevr_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// rvc_internal.h -- launch interface between the engine (rvc_engine.cpp) and the gfx950
+// kernels (rvc_kernels.hip). Not part of the public ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rvc {
+
+// Everything time-domain is addressed by ABSOLUTE sample index n (samples since the last
+// clear()); rings are power-of-two sized and indexed with n & mask. Everything
+// frequency-domain is addressed by absolute block index (row) and bin.
+//
+// Spectrum rows hold B = block complex bins (float2, interleaved). Bin 0 is PACKED:
+// .x = DC, .y = Nyquist (both are real for real signals), so a row is exactly B complex
+// values (a power of two, 8*B bytes, always 16-byte aligned) instead of the reference's
+// B+1 split-complex values (Utilities.h:197-272).
+
+struct FwdArgs {            // real time-domain segment(s) -> spectrum row(s)
+  const float *src;         // [channel][ring] time-domain samples
+  long long src_chan_stride;
+  unsigned long long src_mask;   // index = n & src_mask
+  long long seg0;           // absolute start of row 0's 2B-sample segment
+  int valid_len;            // samples at the start of the segment that may be non-zero (2B: overlap-save
+                            // input segment, B: zero-padded IR partition)
+  long long lo, hi;         // global validity window: samples outside [lo, hi) read as zero
+  const void *tw;           // B twiddles      e^{-2 pi i j / B}     (float2 or double2, see f64)
+  const void *wsplit;       // B/2+1 twiddles  e^{-2 pi i k / 2B}
+  float2 *dst;              // [channel][row][B]
+  long long dst_chan_stride;
+  long long row0;           // absolute row index of row 0
+  unsigned long long row_mask;   // row slot = (row0 + r) & row_mask
+};
+
+struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency-domain delay line)
+  const float2 *H;          // [channel][P][B]
+  long long h_chan_stride;
+  const float2 *X;          // [channel][ring rows][B]
+  long long x_chan_stride;
+  unsigned long long x_row_mask;
+  float2 *Y;                // [channel][M rows][B]
+  long long y_chan_stride;
+  long long k0;             // absolute block index of output row 0
+  int M;                    // output rows
+  int P;                    // partitions
+  int delay;                // 0 for the zero-latency stage, 2 for the tail stage
+  int B;
+};
+
+struct InvArgs {            // spectrum row(s) -> last B samples of the inverse transform (overlap-save)
+  const float2 *Y;          // [channel][M rows][B]
+  long long y_chan_stride;
+  const void *tw;
+  const void *wsplit;
+  long long blk0;           // absolute block index of row 0; row r produces samples [(blk0+r)B, (blk0+r+1)B)
+  float *dst;               // [channel][...]
+  long long dst_chan_stride;
+  long long dst_origin;     // element index = (n - dst_origin) & dst_mask
+  unsigned long long dst_mask;
+  long long lo, hi;         // only samples with lo <= n < hi are written
+  const float *add;         // optional [channel][ring] stream added to the result (tail contribution)
+  long long add_chan_stride;
+  unsigned long long add_mask;
+  long long add_from;       // add applies for n >= add_from
+};
+
+struct IngestArgs {
+  const float *src;         // [channel][len] (device)
+  long long src_chan_stride;
+  float *ring;
+  long long ring_chan_stride;
+  unsigned long long ring_mask;
+  long long n0;
+  long long len;
+};
+
+// All launchers return hipGetLastError() of the launch. logB = log2(block).
+// f64: run the transform in double (LDS data + twiddles); tw/wsplit must then point to double2 tables.
+hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int channels, hipStream_t st);
+hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int channels, hipStream_t st);
+hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st);
+hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st);
+// one-off: raise the dynamic-LDS limit of the large FFT kernels
+hipError_t prepare_kernels();
+
+// time-tile (output rows per thread) the FIR launcher will pick for M rows
+int fir_time_tile(int M);
+
+}  // namespace rvc

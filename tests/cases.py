@@ -71,6 +71,20 @@ def kat_tolerance_ok(out: np.ndarray, exact: np.ndarray, ir_len: int) -> bool:
     return int(bad.sum()) == 0
 
 
+def kat_margin(out: np.ndarray, exact: np.ndarray, ir_len: int) -> float:
+    """How close the worst sample comes to failing the rule above: a sample fails when BOTH its
+    relative and absolute error exceed their tolerance, so its margin is the smaller of the two
+    ratios; < 1 passes. (The reference itself scores <= 0.07 on its 58 cases.)"""
+    a = out.astype(np.float64)
+    b = exact.astype(np.float64)
+    m = (np.abs(a) > 1.0) & (np.abs(b) > 1.0)
+    if not m.any():
+        return 0.0
+    abs_err = np.abs(a - b)[m]
+    rel_err = abs_err / b[m]
+    return float(np.minimum(abs_err / (1e-3 * float(ir_len)), rel_err / (1e-4 * np.log(float(ir_len)))).max())
+
+
 # ---- synthetic cases ---------------------------------------------------------------
 # kind: "fftconv" (block) or "twostage" (head, tail)
 # ir:   ("synth", irLen, nChannels, inst) | ("zeros", irLen) | ("synth_trailing_zeros", irLen, nzeros)

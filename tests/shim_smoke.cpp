@@ -1,0 +1,36 @@
+// Compiles the C++ drop-in classes against the C ABI with plain g++ and exercises the calls
+// that need no GPU (used by tests/test_abi.py). With a GPU present it also convolves a delta.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "reevr_amd/Convolver.h"
+#include "reevr_amd/StereoConvolver.h"
+
+int main() {
+  std::vector<float> ir(100, 0.0f);
+  ir[0] = 1.0f; ir[50] = 0.5f;
+  Convolver c;
+  if (c.init(0, 8192, ir.data(), ir.size())) { std::puts("init(0,..) must fail"); return 1; }
+  std::vector<float> zero(100, 0.0f);
+  if (!c.init(64, 256, zero.data(), zero.size())) { std::puts("empty IR must succeed"); return 1; }
+  std::vector<float> in(256, 0.0f), out(256, 1.0f);
+  in[3] = 2.0f;
+  c.process(in.data(), out.data(), in.size());
+  for (float v : out) if (v != 0.0f) { std::puts("empty IR must give zeros"); return 1; }
+  if (rvc_device_count() > 0) {
+    if (!c.init(64, 256, ir.data(), ir.size())) { std::puts("init failed on GPU"); return 1; }
+    c.process(in.data(), out.data(), in.size());
+    if (std::fabs(out[3] - 2.0f) > 1e-5f || std::fabs(out[53] - 1.0f) > 1e-5f) { std::puts("wrong output"); return 1; }
+    (void)c.isFinished();
+    StereoConvolver sc;
+    sc.prepare(128);
+    Impulse imp;
+    imp.bufferLL = ir; imp.bufferRR = ir;
+    sc.loadImpulse(imp);
+    sc.process(in.data(), in.data(), 128);
+    if (std::fabs(sc.bufferLL[3] - 2.0f) > 1e-5f) { std::puts("stereo wrong"); return 1; }
+  }
+  std::puts("ok");
+  return 0;
+}
