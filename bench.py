@@ -125,7 +125,7 @@ def main():
 
     import torch
     import reevr_amd
-    from reevr_amd import KERNEL_NAMES, synth
+    from reevr_amd import KERNEL_NAMES, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -155,14 +155,14 @@ def main():
     head, tail = conv.head_block, conv.tail_block
     d_in = torch.from_numpy(x).to(dev)
     d_out = torch.empty_like(d_in)
-    gathered = torch.empty((world,) + tuple(d_out.shape), device=dev) if (args.gather and world > 1) else None
+    do_gather = bool(args.gather and world > 1)
     torch.cuda.synchronize()
 
     def step():
         conv.process_device(d_in, d_out, sync=False)
-        if gathered is not None:
+        if do_gather:                      # one RCCL all_gather per batch of 3750 blocks
             conv.sync()
-            dist.all_gather_into_tensor(gathered, d_out)
+            shard.gather_batches(d_out, dist)
 
     def fence():
         conv.sync()
@@ -180,10 +180,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     conv.check()
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, dist, dev)    # slowest rank
     total_samples = world * nch * frames * args.steps
     value = total_samples / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
@@ -225,9 +222,24 @@ def main():
     roof = None
     if dominant:
         ach = alg[dominant] / (kern[dominant]["avg_ms"] * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters cannot be read from inside this process:
+        # they come from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/traffic.json, made by tools/pmc_summarize.py; valid for the default --frames only).
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and frames == 40 * SR:
+            tj = json.load(open(tpath))
+            if dominant in tj.get("kernels", {}):
+                traffic = tj["kernels"][dominant]["traffic_bytes"]
+                tsrc = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)"
         roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                "alg_bytes_per_launch": alg[dominant], "avg_launch_ms": round(kern[dominant]["avg_ms"], 5)}
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "alg_bytes_per_launch": alg[dominant], "avg_launch_ms": round(kern[dominant]["avg_ms"], 5),
+                "traffic_source": tsrc,
+                "note": "achieved = ALGORITHMIC bytes (16 B per partition x bin: one IR bin + one delay-line bin, "
+                        "SURVEY.md 8d) / measured launch time. The kernel tiles 16 blocks of time per thread, so "
+                        "each IR bin loaded is used 16 times: physical HBM traffic (`traffic`) is ~30x below the "
+                        "algorithmic figure and frac > 1 is expected; the kernel is fp32-FMA / latency bound."}
     bps = alg_bytes_per_sample(head, tail, IR_LEN)
     path_gbs = value / world * 1e6 * bps / 1e9
 
@@ -262,7 +274,8 @@ def main():
         "config": {"workload": "stereo, 10 s IR @ 48 kHz, block=512 (head 512 / tail 8192), TwoStage convolver",
                    "frames_per_step": frames, "channels_per_gpu": nch, "instances": world,
                    "partitions": {"head+tail0": PA, "tail": PT},
-                   "call": "one process() per step, device-resident I/O", "gather": bool(gathered is not None)},
+                   "call": "one process() per step, device-resident I/O", "gather": do_gather,
+                   "sharding": "one independent stereo instance per rank (unit mod world), no data-path collective"},
         "roofline": roof,
         "path_roofline": {"alg_bytes_per_sample": round(bps, 1), "achieved_GBs_per_gpu": round(path_gbs, 1),
                           "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4),

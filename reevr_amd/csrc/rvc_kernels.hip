@@ -230,7 +230,9 @@ __global__ void __launch_bounds__(fft_threads(LOGB)) k_fft_inv(const InvArgs a) 
 // frequency-domain delay line as a per-bin complex FIR over block time
 // grid (ceil(B/64), ceil(M / (TK*4)), channels), block 256 = 4 waves, wave = one time tile
 // ----------------------------------------------------------------------------------------
-template <int TK>
+// STAGE only names the instantiation (0 = zero-latency stage, 1 = tail stage) so that
+// profilers report the two delay lines separately.
+template <int TK, int STAGE>
 __global__ void __launch_bounds__(256) k_fir(const FirArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bin = blockIdx.x * 64 + lane;
@@ -360,13 +362,22 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   const int tk = fir_time_tile(a.M);
   const int tiles = (a.M + tk - 1) / tk;
   const dim3 grid((a.B + 63) / 64, (tiles + 3) / 4, channels), block(256);
+#define RVC_FIR_CASE(TKV)                                                             \
+  case TKV:                                                                           \
+    if (a.delay == 0) hipLaunchKernelGGL((k_fir<TKV, 0>), grid, block, 0, st, a);     \
+    else hipLaunchKernelGGL((k_fir<TKV, 1>), grid, block, 0, st, a);                  \
+    break;
   switch (tk) {
-    case 16: hipLaunchKernelGGL(k_fir<16>, grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL(k_fir<8>, grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL(k_fir<4>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(k_fir<2>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(k_fir<1>, grid, block, 0, st, a); break;
+    RVC_FIR_CASE(16)
+    RVC_FIR_CASE(8)
+    RVC_FIR_CASE(4)
+    RVC_FIR_CASE(2)
+    default:
+      if (a.delay == 0) hipLaunchKernelGGL((k_fir<1, 0>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((k_fir<1, 1>), grid, block, 0, st, a);
+      break;
   }
+#undef RVC_FIR_CASE
   return hipGetLastError();
 }
 

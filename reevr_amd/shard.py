@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of independent convolver units.
+
+The path has no cross-unit arithmetic: every `Convolver` (one IR channel x one input channel)
+is independent (reference src/dsp/StereoConvolver.cpp:33-42), so units are dealt to ranks
+statically, `rank = unit mod world`, at instance granularity (the 2-4 channels of one
+stereo/quad instance stay on one GPU). No collective is on the data path; the optional
+gather of output batches is one all_gather per *batch* of blocks, never per 512-frame block.
+One process per GPU; on ROCm torch.distributed's "nccl" backend is RCCL (xGMI), "gloo" on CPU.
+"""
+from __future__ import annotations
+
+from typing import List
+
+
+def units_for_rank(n_units: int, world: int, rank: int) -> List[int]:
+    """Static map rank = unit mod world."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return list(range(rank, n_units, world))
+
+
+def owner_of(unit: int, world: int) -> int:
+    return unit % world
+
+
+def max_over_ranks(value: float, dist=None, device=None) -> float:
+    """Slowest rank's time (bench contract: timing is the MAX over ranks)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_batches(local, dist=None):
+    """all_gather of equally-shaped per-rank output batches -> (world, *local.shape).
+    `local` is a torch tensor (CUDA with nccl/RCCL, CPU with gloo)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local.unsqueeze(0)
+    world = dist.get_world_size()
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if local.is_cuda:
+        dist.all_gather_into_tensor(out, local.contiguous())
+    else:
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local.contiguous())
+        out = torch.stack(parts)
+    return out
+
+
+def reassemble(gathered, n_units: int, world: int):
+    """gathered[r][j] holds unit units_for_rank(n_units, world, r)[j]; return them in unit order.
+    Requires n_units % world == 0 (equal shards)."""
+    import torch
+    assert n_units % world == 0
+    per = n_units // world
+    out = [None] * n_units
+    for r in range(world):
+        for j, u in enumerate(units_for_rank(n_units, world, r)):
+            assert j < per
+            out[u] = gathered[r][j]
+    return torch.stack(out)
