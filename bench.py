@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=40 * SR, help="frames per channel per step (one process() call)")
+    ap.add_argument("--bg-stream", type=int, default=1, help="1: tail stage on the second HIP stream (overlaps the head stage)")
     ap.add_argument("--gather", action="store_true", help="RCCL all_gather of the output batch each step")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--stream-calls", type=int, default=3000, help="512-frame calls of the streaming side measurement")
@@ -146,7 +147,7 @@ def main():
     nch = 2
     irs = synth.synth_ir(IR_LEN, nch, inst=rank)                 # this rank's stereo instance
     x = np.stack([synth.synth_input(frames, c + 2 * rank) for c in range(nch)])
-    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=False)
+    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream))
     t_init = time.perf_counter()
     if not conv.init(HOST_BLOCK, 8192, list(irs), max_len=frames):
         raise SystemExit(f"init failed: {conv.last_error_string}")

@@ -59,11 +59,12 @@ struct Stage {
   size_t rows = 0;    // X ring rows (power of two)
   size_t mcap = 0;    // Y rows (max output rows per call)
   float2 *H = nullptr, *X = nullptr, *Y = nullptr;
-  float2 *tw = nullptr, *wsplit = nullptr;       // float twiddles
-  double2 *twd = nullptr, *wsplitd = nullptr;    // double twiddles (B <= 8192): IR spectra, f64 mode
+  float2 *tw = nullptr, *wsplit = nullptr, *tw8 = nullptr;       // float twiddles
+  double2 *twd = nullptr, *wsplitd = nullptr, *tw8d = nullptr;   // double twiddles (B <= 8192): IR spectra, f64 mode
   bool f64 = false;                              // run this stage's transforms in double
   const void *twp() const { return f64 ? (const void *)twd : (const void *)tw; }
   const void *wsp() const { return f64 ? (const void *)wsplitd : (const void *)wsplit; }
+  const void *t8p() const { return f64 ? (const void *)tw8d : (const void *)tw8; }
 };
 
 struct TimedLaunch {
@@ -143,7 +144,7 @@ bool ensure_streams(rvc_set *s) {
 
 void free_stage(Stage &g) {
   hipFree(g.H); hipFree(g.X); hipFree(g.Y); hipFree(g.tw); hipFree(g.wsplit);
-  hipFree(g.twd); hipFree(g.wsplitd);
+  hipFree(g.twd); hipFree(g.wsplitd); hipFree(g.tw8); hipFree(g.tw8d);
   g = Stage();
 }
 
@@ -180,27 +181,60 @@ void free_device_state(rvc_set *s) {
 
 bool make_twiddles(rvc_set *s, Stage &g) {
   const size_t B = g.B;
-  std::vector<float2> tw(B), ws(B / 2 + 1);
-  std::vector<double2> twd(B), wsd(B / 2 + 1);
+  const size_t nws = B;   // e^{-i pi k / B}, k < B (the generic kernels use the first B/2+1)
+  std::vector<float2> tw(B), ws(nws + 1);
+  std::vector<double2> twd(B), wsd(nws + 1);
   for (size_t j = 0; j < B; ++j) {
     const double ang = -2.0 * kPi * (double)j / (double)B;
     twd[j] = make_double2(std::cos(ang), std::sin(ang));
     tw[j] = make_float2((float)twd[j].x, (float)twd[j].y);
   }
-  for (size_t k = 0; k <= B / 2; ++k) {
+  for (size_t k = 0; k <= nws; ++k) {
     const double ang = -kPi * (double)k / (double)B;
     wsd[k] = make_double2(std::cos(ang), std::sin(ang));
     ws[k] = make_float2((float)wsd[k].x, (float)wsd[k].y);
   }
   RVC_CK(hipMalloc(&g.tw, sizeof(float2) * B));
-  RVC_CK(hipMalloc(&g.wsplit, sizeof(float2) * (B / 2 + 1)));
+  RVC_CK(hipMalloc(&g.wsplit, sizeof(float2) * (nws + 1)));
   RVC_CK(hipMemcpy(g.tw, tw.data(), sizeof(float2) * B, hipMemcpyHostToDevice));
-  RVC_CK(hipMemcpy(g.wsplit, ws.data(), sizeof(float2) * (B / 2 + 1), hipMemcpyHostToDevice));
-  if (g.logB <= 13) {   // the double transform needs B * 16 bytes of LDS <= 128 KiB
+  RVC_CK(hipMemcpy(g.wsplit, ws.data(), sizeof(float2) * (nws + 1), hipMemcpyHostToDevice));
+  const bool dbl = g.logB <= 13;   // the double transform needs B * 16 bytes of LDS (+pad) <= 136 KiB
+  if (dbl) {
     RVC_CK(hipMalloc(&g.twd, sizeof(double2) * B));
-    RVC_CK(hipMalloc(&g.wsplitd, sizeof(double2) * (B / 2 + 1)));
+    RVC_CK(hipMalloc(&g.wsplitd, sizeof(double2) * (nws + 1)));
     RVC_CK(hipMemcpy(g.twd, twd.data(), sizeof(double2) * B, hipMemcpyHostToDevice));
-    RVC_CK(hipMemcpy(g.wsplitd, wsd.data(), sizeof(double2) * (B / 2 + 1), hipMemcpyHostToDevice));
+    RVC_CK(hipMemcpy(g.wsplitd, wsd.data(), sizeof(double2) * (nws + 1), hipMemcpyHostToDevice));
+  }
+  // per-pass tables of the radix-8 kernels (layout documented in rvc_internal.h)
+  const int n8e = rvc::fft8_table_entries(g.logB);
+  if (n8e > 0) {
+    std::vector<double2> t8d((size_t)n8e);
+    std::vector<float2> t8((size_t)n8e);
+    size_t o = 0;
+    const int N8 = g.logB / 3;
+    for (int j = 1; j < N8; ++j) {
+      const size_t p = (size_t)1 << (3 * j);
+      for (size_t k = 0; k < p; ++k)
+        for (int r = 0; r < 8; ++r) {
+          const double ang = -2.0 * kPi * (double)r * (double)k / (double)(8 * p);
+          t8d[o++] = make_double2(std::cos(ang), std::sin(ang));
+        }
+    }
+    if (g.logB % 3 == 2) {
+      for (size_t k = 0; k < B / 4; ++k)
+        for (int r = 0; r < 4; ++r) {
+          const double ang = -2.0 * kPi * (double)r * (double)k / (double)B;
+          t8d[o++] = make_double2(std::cos(ang), std::sin(ang));
+        }
+    }
+    if (o != (size_t)n8e) return fail(s, RVC_ERR_HIP, hipSuccess, "twiddle table layout");
+    for (size_t i = 0; i < o; ++i) t8[i] = make_float2((float)t8d[i].x, (float)t8d[i].y);
+    RVC_CK(hipMalloc(&g.tw8, sizeof(float2) * o));
+    RVC_CK(hipMemcpy(g.tw8, t8.data(), sizeof(float2) * o, hipMemcpyHostToDevice));
+    if (dbl) {
+      RVC_CK(hipMalloc(&g.tw8d, sizeof(double2) * o));
+      RVC_CK(hipMemcpy(g.tw8d, t8d.data(), sizeof(double2) * o, hipMemcpyHostToDevice));
+    }
   }
   return true;
 }
@@ -224,6 +258,7 @@ bool upload_ir_stage(rvc_set *s, Stage &g, const std::vector<std::vector<float>>
   const bool ir64 = g.twd != nullptr;
   a.tw = ir64 ? (const void *)g.twd : (const void *)g.tw;
   a.wsplit = ir64 ? (const void *)g.wsplitd : (const void *)g.wsplit;
+  a.tw8 = ir64 ? (const void *)g.tw8d : (const void *)g.tw8;
   a.dst = g.H; a.dst_chan_stride = (long long)g.P * (long long)g.B; a.row0 = 0; a.row_mask = ~0ull;
   hipError_t e = rvc::launch_fft_fwd(g.logB, ir64, a, g.P, s->nch, s->st_main);
   if (e == hipSuccess) e = hipStreamSynchronize(s->st_main);
@@ -371,7 +406,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       rvc::FwdArgs f{};
       f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
       f.seg0 = (mb0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
-      f.tw = T.twp(); f.wsplit = T.wsp();
+      f.tw = T.twp(); f.wsplit = T.wsp(); f.tw8 = T.t8p();
       f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = mb0; f.row_mask = T.rows - 1;
       {
         Timer t(s, 4, st);
@@ -388,7 +423,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
         RVC_CK(rvc::launch_fir(r, s->nch, st));
       }
       rvc::InvArgs v{};
-      v.Y = T.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp();
+      v.Y = T.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp(); v.tw8 = T.t8p();
       v.blk0 = m_lo;
       v.dst = s->tailring; v.dst_chan_stride = (long long)s->ring_cap; v.dst_origin = 0; v.dst_mask = s->ring_cap - 1;
       v.lo = 0; v.hi = (long long)1 << 62;
@@ -414,7 +449,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   rvc::FwdArgs f{};
   f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
   f.seg0 = (k0 - 1) * hb; f.valid_len = (int)(2 * hb); f.lo = 0; f.hi = n1;
-  f.tw = A.twp(); f.wsplit = A.wsp();
+  f.tw = A.twp(); f.wsplit = A.wsp(); f.tw8 = A.t8p();
   f.dst = A.X; f.dst_chan_stride = (long long)A.rows * hb; f.row0 = k0; f.row_mask = A.rows - 1;
   {
     Timer t(s, 1, s->st_main);
@@ -441,7 +476,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     }
   }
   rvc::InvArgs v{};
-  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(); v.wsplit = A.wsp();
+  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(); v.wsplit = A.wsp(); v.tw8 = A.t8p();
   v.blk0 = k0;
   v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
   v.lo = n0; v.hi = n1;

@@ -25,7 +25,8 @@ struct FwdArgs {            // real time-domain segment(s) -> spectrum row(s)
                             // input segment, B: zero-padded IR partition)
   long long lo, hi;         // global validity window: samples outside [lo, hi) read as zero
   const void *tw;           // B twiddles      e^{-2 pi i j / B}     (float2 or double2, see f64)
-  const void *wsplit;       // B/2+1 twiddles  e^{-2 pi i k / 2B}
+  const void *wsplit;       // B twiddles      e^{-2 pi i k / 2B}
+  const void *tw8;          // per-pass tables of the radix-8 kernels (B >= 512), see Plan8
   float2 *dst;              // [channel][row][B]
   long long dst_chan_stride;
   long long row0;           // absolute row index of row 0
@@ -52,6 +53,7 @@ struct InvArgs {            // spectrum row(s) -> last B samples of the inverse 
   long long y_chan_stride;
   const void *tw;
   const void *wsplit;
+  const void *tw8;
   long long blk0;           // absolute block index of row 0; row r produces samples [(blk0+r)B, (blk0+r+1)B)
   float *dst;               // [channel][...]
   long long dst_chan_stride;
@@ -82,6 +84,11 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st);
 hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st);
 // one-off: raise the dynamic-LDS limit of the large FFT kernels
 hipError_t prepare_kernels();
+
+// radix-8 kernels (logB >= 9): number of entries of their per-pass twiddle table, laid out as
+//   for j = 1 .. N8-1 (N8 = logB / 3):  p = 8^j entries [k < p][r < 8] = e^{-2 pi i r k / (8 p)}
+//   then, if logB % 3 == 2:             [k < B/4][r < 4]               = e^{-2 pi i r k / B}
+int fft8_table_entries(int logB);
 
 // time-tile (output rows per thread) the FIR launcher will pick for M rows
 int fir_time_tile(int M);

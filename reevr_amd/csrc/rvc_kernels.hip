@@ -20,6 +20,8 @@
 //    is loaded is used TK times (time tiling; TK = 1 is the streaming case).
 #include "rvc_internal.h"
 
+#include <type_traits>
+
 namespace rvc {
 
 // ----------------------------------------------------------------------------------------
@@ -226,61 +228,518 @@ __global__ void __launch_bounds__(fft_threads(LOGB)) k_fft_inv(const InvArgs a) 
   }
 }
 
+// ========================================================================================
+// Radix-8 register-resident transforms for B >= 512 (the sizes the plugin uses: head 512..,
+// tail 8192/16384). One thread owns 8*S complex values; a radix-8 butterfly never leaves
+// registers; between passes the values are exchanged through a padded LDS buffer. The first
+// pass is fed straight from global memory and the last pass leaves natural-order results in
+// registers for the epilogue, so a 512-point complex transform (1024 real samples) makes 2 LDS
+// round trips for the FFT + 1 for the real split instead of 6. Twiddles come from small
+// per-pass tables [k][r] (contiguous per thread, L1/L2 resident), computed in double on the host.
+// ========================================================================================
+template <int LOGB> struct Plan8 {
+  static constexpr int B = 1 << LOGB;
+  static constexpr int N8 = LOGB / 3;             // radix-8 passes
+  static constexpr int Q = 1 << (LOGB % 3);       // final pass radix: 1 (none), 2 or 4
+  static constexpr int S = (LOGB >= 14) ? 2 : 1;  // radix-8 butterflies per thread
+  static constexpr int NT = B / (8 * S);          // threads per transform
+  static constexpr int E = 8 * S;                 // complex values per thread
+  static constexpr int T = B / 8;                 // stride between the legs of a radix-8 butterfly
+  static constexpr int LDS_ELEMS = B + B / 16;    // padded
+  // offset (in entries) of the [k][8] table of radix-8 pass j >= 1 (p = 8^j) inside tw8
+  static constexpr int off8(int j) { int o = 0; for (int i = 1; i < j; ++i) o += (1 << (3 * i)) * 8; return o; }
+  static constexpr int offq = off8(N8);           // the final radix-4 table [k][4] (Q == 4 only)
+  static constexpr int tw8_entries = offq + (Q == 4 ? B : 0);
+  // natural-order index of held value e after the whole transform / before the first pass
+  __device__ static __forceinline__ int in_idx(int tid, int e) { return tid + (e >> 3) * NT + (e & 7) * T; }
+  __device__ static __forceinline__ int out_idx(int tid, int e) {
+    if constexpr (Q == 1) return in_idx(tid, e);
+    else return tid + (e / Q) * NT + (e % Q) * (B / Q);
+  }
+};
+
+__device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
+
+template <typename R, bool INV>
+__device__ __forceinline__ void dft4(cx<R> &u0, cx<R> &u1, cx<R> &u2, cx<R> &u3) {
+  const cx<R> a = cadd(u0, u2), b = csub(u0, u2), c = cadd(u1, u3), d = csub(u1, u3);
+  const cx<R> jd = INV ? mk<R>(-d.y, d.x) : mk<R>(d.y, -d.x);   // -i*d (forward) / +i*d (inverse)
+  u0 = cadd(a, c); u1 = cadd(b, jd); u2 = csub(a, c); u3 = csub(b, jd);
+}
+
+// 8-point DFT, natural order in and out.
+template <typename R, bool INV>
+__device__ __forceinline__ void dft8(cx<R> *a) {
+  const R h = (R)0.70710678118654752440;
+  cx<R> s0 = cadd(a[0], a[4]), d0 = csub(a[0], a[4]);
+  cx<R> s1 = cadd(a[1], a[5]), d1 = csub(a[1], a[5]);
+  cx<R> s2 = cadd(a[2], a[6]), d2 = csub(a[2], a[6]);
+  cx<R> s3 = cadd(a[3], a[7]), d3 = csub(a[3], a[7]);
+  // odd branch twiddles W8^1, W8^2, W8^3 (conjugated for the inverse)
+  if (!INV) {
+    d1 = mk<R>(h * (d1.x + d1.y), h * (d1.y - d1.x));
+    d2 = mk<R>(d2.y, -d2.x);
+    d3 = mk<R>(h * (d3.y - d3.x), -h * (d3.x + d3.y));
+  } else {
+    d1 = mk<R>(h * (d1.x - d1.y), h * (d1.y + d1.x));
+    d2 = mk<R>(-d2.y, d2.x);
+    d3 = mk<R>(-h * (d3.x + d3.y), h * (d3.x - d3.y));
+  }
+  dft4<R, INV>(s0, s1, s2, s3);
+  dft4<R, INV>(d0, d1, d2, d3);
+  a[0] = s0; a[2] = s1; a[4] = s2; a[6] = s3;
+  a[1] = d0; a[3] = d1; a[5] = d2; a[7] = d3;
+}
+
+// v[e] = x[in_idx(e)] on entry, X[out_idx(e)] on exit (unscaled). `lds` holds LDS_ELEMS values.
+// Ends with all LDS reads done but NO trailing barrier.
+template <int LOGB, bool INV, typename R>
+__device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const cx<R> *__restrict__ tw8,
+                                          const cx<R> *__restrict__ tw, const int tid) {
+  typedef Plan8<LOGB> P;
+  typedef cx<R> C;
+#pragma unroll
+  for (int j = 0; j < P::N8; ++j) {
+    const int p = 1 << (3 * j);
+#pragma unroll
+    for (int s = 0; s < P::S; ++s) {
+      const int i = tid + s * P::NT;
+      C *a = v + 8 * s;
+      if (j > 0) {
+        const int k = i & (p - 1);
+        const C *t = tw8 + P::off8(j) + k * 8;
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+          C w = t[r];
+          if (INV) w.y = -w.y;
+          a[r] = cmul(a[r], w);
+        }
+      }
+      dft8<R, INV>(a);
+    }
+    const bool last8 = (j == P::N8 - 1);
+    if (!(last8 && P::Q == 1)) {
+      if (j > 0) __syncthreads();               // previous exchange fully read before overwriting
+#pragma unroll
+      for (int s = 0; s < P::S; ++s) {
+        const int i = tid + s * P::NT;
+        const int k = i & (p - 1);
+        const int base = ((i - k) << 3) + k;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) lds[lpad(base + r * p)] = v[8 * s + r];
+      }
+      __syncthreads();
+      if (!last8) {
+#pragma unroll
+        for (int s = 0; s < P::S; ++s) {
+          const int i = tid + s * P::NT;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[8 * s + r] = lds[lpad(i + r * P::T)];
+        }
+      }
+    }
+  }
+  if constexpr (P::Q > 1) {                      // final radix-2 / radix-4 pass, p = B/Q, k = i
+    constexpr int NBF = P::E / P::Q;
+    constexpr int ST = P::B / P::Q;
+#pragma unroll
+    for (int jb = 0; jb < NBF; ++jb) {
+      const int i = tid + jb * P::NT;
+      C *b = v + jb * P::Q;
+#pragma unroll
+      for (int r = 0; r < P::Q; ++r) b[r] = lds[lpad(i + r * ST)];
+      if constexpr (P::Q == 2) {
+        C w = tw[i];                             // e^{-2 pi i k / B}
+        if (INV) w.y = -w.y;
+        const C x1 = cmul(b[1], w);
+        const C x0 = b[0];
+        b[0] = cadd(x0, x1); b[1] = csub(x0, x1);
+      } else {
+        const C *t = tw8 + P::offq + i * 4;
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+          C w = t[r];
+          if (INV) w.y = -w.y;
+          b[r] = cmul(b[r], w);
+        }
+        dft4<R, INV>(b[0], b[1], b[2], b[3]);
+      }
+    }
+  }
+}
+
+template <int LOGB, typename R>
+__global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
+  typedef Plan8<LOGB> P;
+  typedef cx<R> C;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  C *lds = reinterpret_cast<C *>(smem_raw);
+  constexpr int B = P::B;
+  const int tid = threadIdx.x;
+  const int r_ = blockIdx.x, c = blockIdx.y;
+  const float *src = a.src + (long long)c * a.src_chan_stride;
+  const long long seg = a.seg0 + (long long)r_ * B;
+  const C *tw = reinterpret_cast<const C *>(a.tw);
+  const C *tw8 = reinterpret_cast<const C *>(a.tw8);
+  const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
+
+  C v[P::E];
+  // z[m] = x[2m] + i x[2m+1], m = in_idx(e). Fast path: the whole 2B segment is valid input
+  // (wave-uniform test) -> one aligned 8-byte load per value, no per-sample checks.
+  const bool whole = (a.valid_len == 2 * B) && seg >= a.lo && seg + 2 * B <= a.hi;
+  if (whole) {
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      const long long n = seg + 2 * P::in_idx(tid, e);
+      const float2 x = *reinterpret_cast<const float2 *>(src + ((unsigned long long)n & a.src_mask));
+      v[e] = mk<R>((R)x.x, (R)x.y);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      const int q = 2 * P::in_idx(tid, e);
+      const long long n0 = seg + q, n1 = n0 + 1;
+      float v0 = 0.f, v1 = 0.f;
+      if (q < a.valid_len && n0 >= a.lo && n0 < a.hi) v0 = src[(unsigned long long)n0 & a.src_mask];
+      if (q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi) v1 = src[(unsigned long long)n1 & a.src_mask];
+      v[e] = mk<R>((R)v0, (R)v1);
+    }
+  }
+  fft8_core<LOGB, false, R>(v, lds, tw8, tw, tid);
+
+  // real split through LDS: X[k] = E + w^k O with the partner Z[B-k] held by another thread
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = v[e];
+  __syncthreads();
+  float2 *dst = a.dst + (long long)c * a.dst_chan_stride +
+                (long long)(((unsigned long long)(a.row0 + r_)) & a.row_mask) * B;
+  const R half = (R)0.5;
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int k = P::out_idx(tid, e);
+    const C A = v[e];
+    if (k == 0) {
+      dst[0] = make_float2((float)(A.x + A.y), (float)(A.x - A.y));   // packed (DC, Nyquist)
+    } else {
+      const C Bc = cconj(lds[lpad(B - k)]);
+      const C Ev = mk<R>(half * (A.x + Bc.x), half * (A.y + Bc.y));
+      const C D = mk<R>(half * (A.x - Bc.x), half * (A.y - Bc.y));
+      const C O = mk<R>(D.y, -D.x);                  // -i * D
+      const C X = cadd(Ev, cmul(wsplit[k], O));      // wsplit has B entries: e^{-i pi k / B}
+      dst[k] = make_float2((float)X.x, (float)X.y);
+    }
+  }
+}
+
+template <int LOGB, typename R>
+__global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_inv(const InvArgs a) {
+  typedef Plan8<LOGB> P;
+  typedef cx<R> C;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  C *lds = reinterpret_cast<C *>(smem_raw);
+  constexpr int B = P::B;
+  const int tid = threadIdx.x;
+  const int r_ = blockIdx.x, c = blockIdx.y;
+  const long long nblk = (a.blk0 + r_) * (long long)B;
+  if (nblk >= a.hi || nblk + B <= a.lo) return;            // uniform
+  const float2 *Y = a.Y + (long long)c * a.y_chan_stride + (long long)r_ * B;
+  const C *tw = reinterpret_cast<const C *>(a.tw);
+  const C *tw8 = reinterpret_cast<const C *>(a.tw8);
+  const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
+
+  // Z[k] = E + iO straight from global: Y[k] ascending and Y[B-k] descending are both coalesced
+  C v[P::E];
+  const R sc = (R)0.5 / (R)B;
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int k = P::in_idx(tid, e);
+    const float2 yk = Y[k];
+    if (k == 0) {
+      v[e] = mk<R>(sc * ((R)yk.x + (R)yk.y), sc * ((R)yk.x - (R)yk.y));
+    } else {
+      const float2 yc = Y[B - k];
+      const C Yk = mk<R>((R)yk.x, (R)yk.y), Yc = mk<R>((R)yc.x, -(R)yc.y);
+      const C Ev = mk<R>(sc * (Yk.x + Yc.x), sc * (Yk.y + Yc.y));
+      const C D = mk<R>(sc * (Yk.x - Yc.x), sc * (Yk.y - Yc.y));
+      const C O = cmul(cconj(wsplit[k]), D);
+      v[e] = mk<R>(Ev.x - O.y, Ev.y + O.x);
+    }
+  }
+  fft8_core<LOGB, true, R>(v, lds, tw8, tw, tid);
+
+  // z[m] = (s[2m], s[2m+1]); the overlap-save output is s[B..2B) = z[B/2..B): 8-byte stores
+  float *dst = a.dst + (long long)c * a.dst_chan_stride;
+  const float *add = a.add ? a.add + (long long)c * a.add_chan_stride : nullptr;
+  const bool whole = nblk >= a.lo && nblk + B <= a.hi;      // uniform: every sample of the block is wanted
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int m = P::out_idx(tid, e);
+    if (m >= B / 2) {
+      const int p0 = 2 * m - B;
+      const long long n = nblk + p0;
+      float2 o = make_float2((float)v[e].x, (float)v[e].y);
+      if (whole) {
+        if (add && n >= a.add_from) {     // add_from is a multiple of the (even) block sizes: both samples or none
+          const float2 t = *reinterpret_cast<const float2 *>(add + ((unsigned long long)n & a.add_mask));
+          o.x += t.x; o.y += t.y;
+        }
+        float *q = dst + ((unsigned long long)(n - a.dst_origin) & a.dst_mask);
+        if ((((unsigned long long)(n - a.dst_origin)) & 1ull) == 0ull && ((reinterpret_cast<uintptr_t>(q) & 7u) == 0u)) {
+          *reinterpret_cast<float2 *>(q) = o;
+        } else {
+          q[0] = o.x;
+          dst[(unsigned long long)(n + 1 - a.dst_origin) & a.dst_mask] = o.y;
+        }
+      } else {
+        if (n >= a.lo && n < a.hi) {
+          float t = o.x;
+          if (add && n >= a.add_from) t += add[(unsigned long long)n & a.add_mask];
+          dst[(unsigned long long)(n - a.dst_origin) & a.dst_mask] = t;
+        }
+        if (n + 1 >= a.lo && n + 1 < a.hi) {
+          float t = o.y;
+          if (add && n + 1 >= a.add_from) t += add[(unsigned long long)(n + 1) & a.add_mask];
+          dst[(unsigned long long)(n + 1 - a.dst_origin) & a.dst_mask] = t;
+        }
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------
 // frequency-domain delay line as a per-bin complex FIR over block time
 // grid (ceil(B/64), ceil(M / (TK*4)), channels), block 256 = 4 waves, wave = one time tile
 // ----------------------------------------------------------------------------------------
 // STAGE only names the instantiation (0 = zero-latency stage, 1 = tail stage) so that
 // profilers report the two delay lines separately.
+//
+// Inner loop = explicit software pipeline: the IR row and the input-spectrum row of step i+D are
+// requested while step i's 4*TK FMAs run (D = 4 loads of each in flight per wave), loads are
+// branch-free (rows before time 0 are fetched from a clamped address and zeroed by a scalar
+// select) so the compiler emits counted s_waitcnt vmcnt(N) instead of load -> wait(0) -> use.
 template <int TK, int STAGE>
-__global__ void __launch_bounds__(256) k_fir(const FirArgs a) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// __launch_bounds__(256, 4): 4 waves/SIMD (<= 128 VGPRs; TK = 16 spills 6 dwords, two scratch
+// round trips per 16 steps) so that the 3840-wave tail launch of the benchmark is resident in
+// ONE round; at 132 VGPRs / 3 waves per SIMD it needed a second, quarter-full round.
+__global__ void __launch_bounds__(256, 4) k_fir(const FirArgs a) {
+  // prefetch distance (steps); must divide TK (queue slot = step mod D).
+  constexpr int D = TK < 4 ? TK : 4;
+  // readfirstlane makes the wave id provably uniform, so every row address below is scalar
+  // (SGPR base + per-lane 32-bit offset) instead of 64-bit VGPR arithmetic per load
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bin = blockIdx.x * 64 + lane;
   const int c = blockIdx.z;
   const long long t0 = ((long long)blockIdx.y * 4 + wave) * TK;   // first output row of this wave
   if (t0 >= a.M) return;                                           // wave-uniform
   const bool active = bin < a.B;
   const int b = active ? bin : 0;
-  const float2 *__restrict__ H = a.H + (long long)c * a.h_chan_stride + b;
-  const float2 *__restrict__ X = a.X + (long long)c * a.x_chan_stride + b;
+  const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride;
+  const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride;
   const long long B = a.B;
+  const int P = a.P;
   const long long cbase = a.k0 + t0 - a.delay;   // input row that meets partition 0 for output row t0
   const bool packed = (bin == 0);                 // bin 0 carries (DC, Nyquist): two real products
+  const float2 zero = make_float2(0.f, 0.f);
 
+  // unconditional load of input row `row` (clamped to >= 0); rowsel() zeroes rows before time 0
+  // address = wave-uniform row pointer (SGPR pair) + zero-extended 32-bit lane byte offset: the
+  // saddr form of global_load, no 64-bit VGPR address per load in flight
+  const unsigned boff = (unsigned)b * (unsigned)sizeof(float2);
   auto loadX = [&](long long row) -> float2 {
-    // rows before time 0 are zero (wave-uniform test); ring slot = row & mask
-    return row >= 0 ? X[(long long)((unsigned long long)row & a.x_row_mask) * B] : make_float2(0.f, 0.f);
+    const long long rr = row < 0 ? 0 : row;
+    const char *rp = reinterpret_cast<const char *>(Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B);
+    return *reinterpret_cast<const float2 *>(rp + boff);
+  };
+  auto loadH = [&](int i) -> float2 {
+    const int ii = i < P ? i : P - 1;             // clamped: the value is never used when i >= P
+    const char *rp = reinterpret_cast<const char *>(Hc + (long long)ii * B);
+    return *reinterpret_cast<const float2 *>(rp + boff);
   };
 
   float2 acc[TK], w[TK];
 #pragma unroll
   for (int t = 0; t < TK; ++t) {
-    acc[t] = make_float2(0.f, 0.f);
-    w[t] = loadX(cbase + t);                      // window slot = (row - cbase) mod TK
+    acc[t] = zero;
+    const float2 x = loadX(cbase + t);            // window slot = (row - cbase) mod TK
+    w[t] = (cbase + t >= 0) ? x : zero;
   }
-  const int P = a.P;
-  for (int i0 = 0; i0 < P; i0 += TK) {
+  float2 hq[D], xq[D];                            // hq[d]: H of step d ; xq[d]: row entering after step d
 #pragma unroll
-    for (int u = 0; u < TK; ++u) {
-      const int i = i0 + u;
-      if (i < P) {                                // uniform
-        const float2 h = H[(long long)i * B];
-        const float hz = packed ? 0.f : h.y;     // general bin: hz = h.im ; packed bin: 0
-        const float h3 = packed ? h.y : h.x;     // general bin: h.re     ; packed bin: Nyquist gain
+  for (int d = 0; d < D; ++d) {
+    hq[d] = loadH(d);
+    xq[d] = loadX(cbase - d - 1);
+  }
+
+  auto step = [&](const int i, const int u) {     // u = i mod TK, compile-time after unrolling
+    const float2 h = hq[u % D];
+    const float2 xin = xq[u % D];
+    hq[u % D] = loadH(i + D);                     // request step i+D's operands now
+    xq[u % D] = loadX(cbase - (i + D) - 1);
+    __builtin_amdgcn_sched_barrier(0);            // keep the two requests above this step's FMAs
+    const float hz = packed ? 0.f : h.y;          // general bin: hz = h.im ; packed bin: 0
+    const float h3 = packed ? h.y : h.x;          // general bin: h.re     ; packed bin: Nyquist gain
 #pragma unroll
-        for (int t = 0; t < TK; ++t) {
-          const float2 x = w[(t - u) & (TK - 1)];
-          acc[t].x = fmaf(h.x, x.x, acc[t].x);
-          acc[t].x = fmaf(-hz, x.y, acc[t].x);
-          acc[t].y = fmaf(h3, x.y, acc[t].y);
-          acc[t].y = fmaf(hz, x.x, acc[t].y);
-        }
-        // slide the window one row into the past: row cbase-i-1 replaces row cbase-i-1+TK
-        w[(TK - 1 - u) & (TK - 1)] = loadX(cbase - i - 1);
-      }
+    for (int t = 0; t < TK; ++t) {
+      const float2 x = w[(t - u) & (TK - 1)];
+      acc[t].x = fmaf(h.x, x.x, acc[t].x);
+      acc[t].x = fmaf(-hz, x.y, acc[t].x);
+      acc[t].y = fmaf(h3, x.y, acc[t].y);
+      acc[t].y = fmaf(hz, x.x, acc[t].y);
     }
+    // slide the window one row into the past: row cbase-i-1 replaces row cbase-i-1+TK
+    w[(TK - 1 - u) & (TK - 1)] = (cbase - i - 1 >= 0) ? xin : zero;
+  };
+
+  const int Pfull = P - (P % TK);
+  int i0 = 0;
+  for (; i0 < Pfull; i0 += TK) {
+#pragma unroll
+    for (int u = 0; u < TK; ++u) step(i0 + u, u);
   }
+#pragma unroll
+  for (int u = 0; u < TK; ++u)                    // remainder (uniform branches)
+    if (i0 + u < P) step(i0 + u, u);
+
   if (active) {
+    float2 *Y = a.Y + (long long)c * a.y_chan_stride + t0 * B + bin;
+#pragma unroll
+    for (int t = 0; t < TK; ++t)
+      if (t0 + t < a.M) Y[(long long)t * B] = acc[t];
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// LDS-staged delay line for long calls (M >= 16 rows, B a multiple of 64).
+// A workgroup = 4 waves = 64 consecutive output rows x 64 bins. At step i wave w needs the IR
+// row i (the same for all four waves) and ONE new input row, R0 + 16w - i - 1; the row wave w
+// needs now is the row wave w-1 needed 16 steps ago. So the workgroup as a whole consumes one
+// new IR row and one new input row per step: both are fetched ONCE per workgroup with 16-byte
+// cooperative loads, eight steps (a chunk) ahead, into a 64-row LDS ring / a double-buffered
+// IR chunk, and every wave picks its operands up with ds_read_b64. Versus k_fir (every wave
+// loads its own 8-byte operands) this is 8x fewer L1 requests, the limiter measured there
+// (TCP_TOTAL_CACHE_ACCESSES: 32 B per access for dwordx2 loads).
+// grid (B/64, ceil(M/64), channels), block 256, static LDS 40 KiB -> 4 workgroups per CU.
+// ----------------------------------------------------------------------------------------
+template <int STAGE>
+__global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
+  constexpr int TK = 16, CH = 8, RING = 64;
+  __shared__ __attribute__((aligned(16))) float2 sX[RING][64];   // 32 KiB: input rows, slot = row & 63
+  __shared__ __attribute__((aligned(16))) float2 sH[2][CH][64];  //  8 KiB: IR rows of the current / next chunk
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bin0 = blockIdx.x * 64, bin = bin0 + lane;
+  const int c = blockIdx.z;
+  const long long T0 = (long long)blockIdx.y * 64;      // first output row of the workgroup
+  const long long t0 = T0 + 16 * wave;                  // ... of this wave
+  const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride + bin0;
+  const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride + bin0;
+  const long long B = a.B;
+  const int P = a.P;
+  const long long R0 = a.k0 + T0 - a.delay;              // input row meeting partition 0 for output row T0
+  const long long cbase = R0 + 16 * wave;
+  const bool packed = (bin == 0);
+  const float2 zero = make_float2(0.f, 0.f);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // cooperative loader: thread -> (row lr of a group of 8, bins lc, lc+1), 16 bytes
+  const int lr = tid >> 5, lc = (tid & 31) * 2;
+  auto gX = [&](long long row) -> float4 {               // rows before time 0 are zero
+#ifdef RVC_ABLATE_NOLOAD
+    return make_float4((float)row, 1.f, 2.f, 3.f);
+#endif
+    const long long rr = row < 0 ? 0 : row;
+    const float4 v = *reinterpret_cast<const float4 *>(Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B + lc);
+    return row >= 0 ? v : zero4;
+  };
+  auto gH = [&](int i) -> float4 {                        // clamped: rows >= P are never used
+#ifdef RVC_ABLATE_NOLOAD
+    return make_float4((float)i, 1.f, 2.f, 3.f);
+#endif
+    const int ii = i < P ? i : P - 1;
+    return *reinterpret_cast<const float4 *>(Hc + (long long)ii * B + lc);
+  };
+  auto sXrow = [&](long long row) -> float2 * { return &sX[(int)((unsigned long long)row & (RING - 1))][0]; };
+
+  // prologue. Register window of wave w = rows cbase .. cbase+15 (from global, one 8-byte load
+  // each); waves 0..2 also publish theirs into the ring (rows R0 .. R0+47 are what the other
+  // waves will pick up during their first 16w steps), rows R0-8 .. R0-1 and IR chunk 0 come from
+  // one cooperative 16-byte load each, and the operands of chunk 1 are already requested.
+  float2 acc[TK], w[TK];
+#pragma unroll
+  for (int t = 0; t < TK; ++t) {
+    acc[t] = zero;
+    const long long row = cbase + t, rr = row < 0 ? 0 : row;
+    const float2 x = (Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B)[lane];
+    w[t] = row >= 0 ? x : zero;
+  }
+  const int nchunks = (P + CH - 1) / CH;
+  float4 px[2], phv[2];                                   // in-flight operands of chunks j+1 (set (j+1)&1) and j+2
+  px[0] = gX(R0 - 1 - lr);                                // chunk 0 (goes to LDS right away)
+  phv[0] = gH(lr);
+  px[1] = zero4; phv[1] = zero4;
+  if (nchunks > 1) { px[1] = gX(R0 - CH - 1 - lr); phv[1] = gH(CH + lr); }
+  if (wave < 3) {
+#pragma unroll
+    for (int t = 0; t < TK; ++t) sXrow(cbase + t)[lane] = w[t];
+  }
+  *reinterpret_cast<float4 *>(sXrow(R0 - 1 - lr) + lc) = px[0];
+  *reinterpret_cast<float4 *>(&sH[0][lr][lc]) = phv[0];
+  __syncthreads();
+
+  // one chunk = 8 steps; PH = chunk parity: selects which half of the 16-slot register window
+  // rotates and which in-flight register set is which. Operands are requested TWO chunks
+  // (16 steps) ahead: chunk j requests chunk j+2 into set PH and, at its end, stages chunk j+1
+  // (requested one chunk earlier, set PH^1) into LDS.
+  auto chunk = [&](const int j, auto ph_tag) {
+    constexpr int PH = decltype(ph_tag)::value;
+    const int buf = j & 1;
+    if (j + 2 < nchunks) {                                // uniform
+      px[PH] = gX(R0 - (long long)(j + 2) * CH - 1 - lr);
+      phv[PH] = gH((j + 2) * CH + lr);
+    }
+    auto step = [&](const int i, const int u, const int u16) {
+#ifdef RVC_ABLATE_NOLDSREAD
+      const float2 h = make_float2(1.f + i, 0.5f), xin = make_float2(0.25f * u, 1.f);
+#else
+      const float2 h = sH[buf][u][lane];
+      const float2 xin = sXrow(cbase - i - 1)[lane];
+#endif
+      const float hz = packed ? 0.f : h.y;
+      const float h3 = packed ? h.y : h.x;
+#pragma unroll
+      for (int t = 0; t < TK; ++t) {
+        const float2 x = w[(t - u16) & (TK - 1)];
+        acc[t].x = fmaf(h.x, x.x, acc[t].x);
+        acc[t].x = fmaf(-hz, x.y, acc[t].x);
+        acc[t].y = fmaf(h3, x.y, acc[t].y);
+        acc[t].y = fmaf(hz, x.x, acc[t].y);
+      }
+      w[(TK - 1 - u16) & (TK - 1)] = xin;                 // zero for rows < 0 was applied when staged
+    };
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (j * CH + u < P) step(j * CH + u, u, PH * CH + u);   // uniform (only the last chunk can be partial)
+    if (j + 1 < nchunks) {
+      // ONE barrier per chunk. The slots written here are free without a barrier in front:
+      //  * ring: rows of chunk j+1 land on the slots of rows R0+48-8j .. R0+55-8j, above every
+      //    row any wave reads in chunk j (<= R0+47-8j);
+      //  * sH[buf^1] was last read in chunk j-1, which every wave left before the previous barrier.
+      *reinterpret_cast<float4 *>(sXrow(R0 - (long long)(j + 1) * CH - 1 - lr) + lc) = px[PH ^ 1];
+      *reinterpret_cast<float4 *>(&sH[buf ^ 1][lr][lc]) = phv[PH ^ 1];
+      __syncthreads();
+    }
+  };
+  for (int j = 0; j < nchunks; j += 2) {
+    chunk(j, std::integral_constant<int, 0>{});
+    if (j + 1 < nchunks) chunk(j + 1, std::integral_constant<int, 1>{});
+  }
+
+#ifdef RVC_ABLATE_NOSTORE
+  if (t0 < a.M && acc[0].x == 123.456f) {
+#else
+  if (t0 < a.M) {
+#endif
     float2 *Y = a.Y + (long long)c * a.y_chan_stride + t0 * B + bin;
 #pragma unroll
     for (int t = 0; t < TK; ++t)
@@ -304,15 +763,37 @@ __global__ void __launch_bounds__(256) k_ingest(const IngestArgs a) {
 // ----------------------------------------------------------------------------------------
 template <int LOGB, typename R>
 static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStream_t st) {
-  const size_t lds = sizeof(cx<R>) << LOGB;
-  hipLaunchKernelGGL((k_fft_fwd<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
+  if constexpr (LOGB >= 9) {
+    const size_t lds = sizeof(cx<R>) * Plan8<LOGB>::LDS_ELEMS;
+    hipLaunchKernelGGL((k_fft8_fwd<LOGB, R>), dim3(rows, channels), dim3(Plan8<LOGB>::NT), lds, st, a);
+  } else {
+    const size_t lds = sizeof(cx<R>) << LOGB;
+    hipLaunchKernelGGL((k_fft_fwd<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
+  }
   return hipGetLastError();
 }
 template <int LOGB, typename R>
 static hipError_t launch_inv_t(const InvArgs &a, int rows, int channels, hipStream_t st) {
-  const size_t lds = sizeof(cx<R>) << LOGB;
-  hipLaunchKernelGGL((k_fft_inv<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
+  if constexpr (LOGB >= 9) {
+    const size_t lds = sizeof(cx<R>) * Plan8<LOGB>::LDS_ELEMS;
+    hipLaunchKernelGGL((k_fft8_inv<LOGB, R>), dim3(rows, channels), dim3(Plan8<LOGB>::NT), lds, st, a);
+  } else {
+    const size_t lds = sizeof(cx<R>) << LOGB;
+    hipLaunchKernelGGL((k_fft_inv<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
+  }
   return hipGetLastError();
+}
+
+int fft8_table_entries(int logB) {   // entries of the tw8 table the radix-8 kernels expect (0: not used)
+  switch (logB) {
+    case 9: return Plan8<9>::tw8_entries;
+    case 10: return Plan8<10>::tw8_entries;
+    case 11: return Plan8<11>::tw8_entries;
+    case 12: return Plan8<12>::tw8_entries;
+    case 13: return Plan8<13>::tw8_entries;
+    case 14: return Plan8<14>::tw8_entries;
+    default: return 0;
+  }
 }
 
 // float: B up to 2^14 (128 KiB of LDS); double: B up to 2^13 (also 128 KiB)
@@ -359,6 +840,12 @@ int fir_time_tile(int M) { return M >= 16 ? 16 : (M >= 8 ? 8 : (M >= 4 ? 4 : (M 
 
 hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   if (a.M <= 0 || channels <= 0 || a.P <= 0) return hipSuccess;
+  if (a.M >= 16 && (a.B % 64) == 0) {     // long call: LDS-staged, 64 rows x 64 bins per workgroup
+    const dim3 grid(a.B / 64, (a.M + 63) / 64, channels), block(256);
+    if (a.delay == 0) hipLaunchKernelGGL((k_fir_lds<0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_fir_lds<1>), grid, block, 0, st, a);
+    return hipGetLastError();
+  }
   const int tk = fir_time_tile(a.M);
   const int tiles = (a.M + tk - 1) / tk;
   const dim3 grid((a.B + 63) / 64, (tiles + 3) / 4, channels), block(256);
@@ -391,10 +878,13 @@ hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st) {
 
 hipError_t prepare_kernels() {
   // B = 16384 needs 128 KiB of dynamic LDS, above the 64 KiB default limit.
-  const void *big[] = {reinterpret_cast<const void *>(k_fft_fwd<14, float>), reinterpret_cast<const void *>(k_fft_inv<14, float>),
-                       reinterpret_cast<const void *>(k_fft_fwd<13, double>), reinterpret_cast<const void *>(k_fft_inv<13, double>)};
+  // padded LDS: B + B/16 values. float B=8192: 68 KiB, B=16384: 136 KiB; double B=4096: 68 KiB, B=8192: 136 KiB
+  const void *big[] = {reinterpret_cast<const void *>(k_fft8_fwd<13, float>), reinterpret_cast<const void *>(k_fft8_inv<13, float>),
+                       reinterpret_cast<const void *>(k_fft8_fwd<14, float>), reinterpret_cast<const void *>(k_fft8_inv<14, float>),
+                       reinterpret_cast<const void *>(k_fft8_fwd<12, double>), reinterpret_cast<const void *>(k_fft8_inv<12, double>),
+                       reinterpret_cast<const void *>(k_fft8_fwd<13, double>), reinterpret_cast<const void *>(k_fft8_inv<13, double>)};
   for (const void *f : big) {
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 139264);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
