@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=40 * SR, help="frames per channel per step (one process() call)")
-    ap.add_argument("--bg-stream", type=int, default=1, help="1: tail stage on the second HIP stream (overlaps the head stage)")
+    ap.add_argument("--bg-stream", type=int, default=0, help="1: tail stage on the second HIP stream (overlaps the head stage)")
     ap.add_argument("--gather", action="store_true", help="RCCL all_gather of the output batch each step")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--stream-calls", type=int, default=3000, help="512-frame calls of the streaming side measurement")
@@ -249,20 +249,17 @@ def main():
     if args.stream_calls > 0:
         sconv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=True)
         assert sconv.init(HOST_BLOCK, 8192, list(irs), max_len=HOST_BLOCK)
-        blk_in = d_in[:, :HOST_BLOCK * 64].contiguous().view(nch, 64, HOST_BLOCK)
-        blk_out = torch.empty(nch, HOST_BLOCK, device=dev)
-        ins = [blk_in[:, i, :] for i in range(64)]
-        for i in range(200):
-            sconv.process_device(ins[i % 64], blk_out, sync=False)
-        sconv.sync()
+        nblk = args.stream_calls
+        s_in = d_in[:, :HOST_BLOCK * nblk].contiguous()
+        s_out = torch.empty_like(s_in)
+        sconv.process_device_blocks(s_in[:, :HOST_BLOCK * 200].contiguous(), HOST_BLOCK)   # warm-up
         ts = time.perf_counter()
-        for i in range(args.stream_calls):
-            sconv.process_device(ins[i % 64], blk_out, sync=False)
-        sconv.sync()
+        sconv.process_device_blocks(s_in, HOST_BLOCK, s_out)      # the per-block host loop, in C
         te = time.perf_counter() - ts
         streaming = {"value": round(nch * HOST_BLOCK * args.stream_calls / te / 1e6, 3), "unit": "Msamples/s",
                      "us_per_block": round(te / args.stream_calls * 1e6, 2),
-                     "note": "one process_device() call per 512-frame block, tail on the second stream"}
+                     "note": "one process_device() call per 512-frame block (host loop in C, "
+                             "rvc_set_process_device_blocks), fused latency-path kernel, tail on the second stream"}
         sconv.close()
 
     cpu = cpu_baseline(irs, x[:, :20 * SR], args.cpu_seconds) if (world == 1 and args.cpu_seconds > 0) else None

@@ -101,6 +101,13 @@ void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size
 void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride,
                             float *d_out, size_t out_stride, size_t len);
 
+/* The host's per-block loop in C: feeds `len` device-resident frames through
+ * rvc_set_process_device in consecutive calls of `block` frames (the last one shorter), i.e.
+ * exactly what PluginProcessor::processBlock does call by call (src/PluginProcessor.cpp:1793-1797)
+ * without per-call host-language overhead. Used to measure the block-synchronous (latency) path. */
+void rvc_set_process_device_blocks(rvc_set *s, const float *d_in, size_t in_stride, float *d_out,
+                                   size_t out_stride, size_t len, size_t block);
+
 /* ---- state ------------------------------------------------------------------------- */
 
 /* Replaces TwoStageFFTConvolver::clear / FFTConvolver::clear (TwoStageFFTConvolver.cpp:69-84,
@@ -131,7 +138,8 @@ const char *rvc_last_error_string(const rvc_set *s);
 
 /* With RVC_FLAG_TIMING: accumulated HIP-event time of one kernel family since the last
  * rvc_set_kernel_time_reset. kernel: 0 ingest, 1 fft_fwd(head) 2 fir(head) 3 fft_inv(head),
- * 4 fft_fwd(tail) 5 fir(tail) 6 fft_inv(tail). Synchronises the set. Returns launches. */
+ * 4 fft_fwd(tail) 5 fir(tail) 6 fft_inv(tail), 7 fused single-block step, 8 pre-multiply.
+ * Synchronises the set. Returns launches. */
 long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms);
 void rvc_set_kernel_time_reset(rvc_set *s);
 /* Switch per-launch event timing on/off at run time (same as creating with RVC_FLAG_TIMING). */

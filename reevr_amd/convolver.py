@@ -107,6 +107,20 @@ class ConvolverSet:
             self.check()
         return d_out
 
+    def process_device_blocks(self, d_in, block: int, d_out=None, sync: bool = True):
+        """The host's per-block loop in C: d_in (n_channels, len) is fed in consecutive calls of
+        `block` frames (strict streaming; every call takes the latency path)."""
+        import torch
+        assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
+        if d_out is None:
+            d_out = torch.empty_like(d_in)
+        self._lib.rvc_set_process_device_blocks(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(),
+                                                d_out.stride(0), d_in.shape[1], block)
+        if sync:
+            self.sync()
+            self.check()
+        return d_out
+
     # -- state --------------------------------------------------------------------------
     def clear(self):
         self._lib.rvc_set_clear(self._h)
@@ -164,7 +178,8 @@ class ConvolverSet:
         self._lib.rvc_set_kernel_time_reset(self._h)
 
 
-KERNEL_NAMES = ["ingest", "fft_fwd_head", "fir_head", "fft_inv_head", "fft_fwd_tail", "fir_tail", "fft_inv_tail"]
+KERNEL_NAMES = ["ingest", "fft_fwd_head", "fir_head", "fft_inv_head", "fft_fwd_tail", "fir_tail", "fft_inv_tail",
+                "fused_block", "premultiply"]
 
 
 class _Mono:

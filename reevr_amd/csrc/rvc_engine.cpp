@@ -38,7 +38,7 @@
 namespace {
 
 constexpr double kPi = 3.14159265358979323846264338327950288;
-constexpr int kNumKernelIds = 7;
+constexpr int kNumKernelIds = 9;
 
 size_t next_pow2(size_t v) {   // Utilities.h:280-289
   size_t p = 1;
@@ -86,6 +86,8 @@ struct rvc_set {
   Stage A, T;
   float *xring = nullptr, *tailring = nullptr;
   size_t ring_cap = 0;
+  float2 *ypre = nullptr;        // [nch][head block]: pre-multiplied accumulator of block ypre_block
+  long long ypre_block = -1;     // (fused single-block path); -1 = not valid
   float *d_in = nullptr, *d_out = nullptr;     // staging for the host-pointer API [nch][max_len]
   float *h_in = nullptr, *h_out = nullptr;     // pinned
   long long n = 0;               // absolute sample clock
@@ -166,7 +168,9 @@ void free_device_state(rvc_set *s) {
   drop_timing(s);
   free_stage(s->A);
   free_stage(s->T);
-  hipFree(s->xring); hipFree(s->tailring); hipFree(s->d_in); hipFree(s->d_out);
+  hipFree(s->xring); hipFree(s->tailring); hipFree(s->d_in); hipFree(s->d_out); hipFree(s->ypre);
+  s->ypre = nullptr;
+  s->ypre_block = -1;
   if (s->h_in) hipHostFree(s->h_in);
   if (s->h_out) hipHostFree(s->h_out);
   s->xring = s->tailring = s->d_in = s->d_out = s->h_in = s->h_out = nullptr;
@@ -344,6 +348,9 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   s->ring_cap = next_pow2(s->max_len + 4 * span);
   RVC_CK(hipMalloc(&s->xring, sizeof(float) * (size_t)s->nch * s->ring_cap));
   if (pt > 0) RVC_CK(hipMalloc(&s->tailring, sizeof(float) * (size_t)s->nch * s->ring_cap));
+  RVC_CK(hipMalloc(&s->ypre, sizeof(float2) * (size_t)s->nch * A.B));
+  RVC_CK(hipMemset(s->ypre, 0, sizeof(float2) * (size_t)s->nch * A.B));
+  s->ypre_block = -1;
   RVC_CK(hipMalloc(&s->d_in, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipMalloc(&s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipHostMalloc(&s->h_in, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
@@ -378,76 +385,153 @@ struct Timer {   // brackets one launch with events when timing is on
   }
 };
 
+// Tail stage, one tail period ahead (TwoStageFFTConvolver.cpp:213-222, :247-250): transform the
+// tail blocks this call completed, run the tail delay line for every output block whose inputs
+// now exist, and put the result into the time-indexed tail ring. `src2` = the call's own input
+// when the ring does not hold it yet (long single-stream calls), else nullptr.
+bool run_tail_job(rvc_set *s, long long n0, long long n1, const float *src2, size_t in_stride, bool bg) {
+  Stage &T = s->T;
+  const long long tb = (long long)T.B;
+  const long long mb0 = s->tail_fft_done, mb1 = n1 / tb;   // tail blocks [mb0, mb1) completed by this call
+  if (mb1 <= mb0) return true;
+  hipStream_t st = bg ? s->st_bg : s->st_main;
+  if (bg) {   // startBackgroundProcessing: the job may start once its input is in the ring
+    RVC_CK(hipEventRecord(s->ev_ingest, s->st_main));
+    RVC_CK(hipStreamWaitEvent(st, s->ev_ingest, 0));
+  }
+  rvc::FwdArgs f{};
+  f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
+  f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
+  f.seg0 = (mb0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
+  f.tw = T.twp(); f.wsplit = T.wsp(); f.tw8 = T.t8p();
+  f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = mb0; f.row_mask = T.rows - 1;
+  {
+    Timer t(s, 4, st);
+    RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(mb1 - mb0), s->nch, st));
+  }
+  const long long m_lo = s->tail_out_done, m_hi = mb1 + 2;   // output blocks whose inputs now exist
+  rvc::FirArgs r{};
+  r.H = T.H; r.h_chan_stride = (long long)T.P * tb;
+  r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
+  r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
+  r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = 2; r.B = (int)tb;
+  {
+    Timer t(s, 5, st);
+    RVC_CK(rvc::launch_fir(r, s->nch, st));
+  }
+  rvc::InvArgs v{};
+  v.Y = T.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp(); v.tw8 = T.t8p();
+  v.blk0 = m_lo;
+  v.dst = s->tailring; v.dst_chan_stride = (long long)s->ring_cap; v.dst_origin = 0; v.dst_mask = s->ring_cap - 1;
+  v.lo = 0; v.hi = (long long)1 << 62;
+  v.add = nullptr;
+  {
+    Timer t(s, 6, st);
+    RVC_CK(rvc::launch_fft_inv(T.logB, T.f64, v, r.M, s->nch, st));
+  }
+  s->tail_fft_done = mb1;
+  s->tail_out_done = m_hi;
+  if (bg) {
+    rvc_set::Job j{m_hi, get_event(s)};
+    RVC_CK(hipEventRecord(j.ev, st));
+    s->jobs.push_back(j);
+  }
+  return true;
+}
+
+// waitForBackgroundProcessing: make the foreground stream wait for the job(s) that produced the
+// tail blocks a call ending at n1 reads
+bool wait_tail_jobs(rvc_set *s, long long n1) {
+  const long long m_need = (n1 - 1) / (long long)s->T.B;
+  while (!s->jobs.empty() && m_need >= 2) {
+    rvc_set::Job j = s->jobs.front();
+    RVC_CK(hipStreamWaitEvent(s->st_main, j.ev, 0));   // jobs are ordered: all up to the first one covering m_need
+    s->jobs.pop_front();
+    s->ev_pool.push_back(j.ev);
+    if (j.m_hi > m_need) break;
+  }
+  return true;
+}
+
+// Ypre_kb = sum_{i>=1} H_i X_{kb-i}: everything of block kb's spectrum that does not depend on
+// block kb's own input (FFTConvolver.cpp:176-185)
+bool run_premultiply(rvc_set *s, long long kb) {
+  Stage &A = s->A;
+  if (A.P > 1) {
+    rvc::FirArgs r{};
+    r.H = A.H + A.B; r.h_chan_stride = (long long)A.P * (long long)A.B;
+    r.X = A.X; r.x_chan_stride = (long long)A.rows * (long long)A.B; r.x_row_mask = A.rows - 1;
+    r.Y = s->ypre; r.y_chan_stride = (long long)A.B;
+    r.k0 = kb; r.M = 1; r.P = A.P - 1; r.delay = 1; r.B = (int)A.B;
+    Timer t(s, 8, s->st_main);
+    RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
+  }
+  s->ypre_block = kb;
+  return true;
+}
+
 // one process() step of at most max_len samples, device buffers, asynchronous
 bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len) {
   Stage &A = s->A, &T = s->T;
   const long long n0 = s->n, n1 = n0 + (long long)len;
   const bool has_tail = T.P > 0;
   const bool bg = has_tail && (s->flags & RVC_FLAG_BG_STREAM);
+  const long long hb = (long long)A.B;
+  const long long k0 = n0 / hb, k1 = (n1 - 1) / hb;
 
-  {   // 1. ingest the call's input into the time ring
+  // ---- latency path: the call stays inside one head block (the plugin's per-block call) ----
+  if (k0 == k1 && rvc::fused_supported(A.logB, A.f64)) {
+    if (bg && !wait_tail_jobs(s, n1)) return false;
+    if (s->ypre_block != k0 && !run_premultiply(s, k0)) return false;
+    rvc::FusedArgs g{};
+    g.in = d_in; g.in_chan_stride = (long long)in_stride;
+    g.ring = s->xring; g.ring_chan_stride = (long long)s->ring_cap; g.ring_mask = s->ring_cap - 1;
+    g.n0 = n0; g.n1 = n1; g.k = k0;
+    g.tw = A.tw; g.wsplit = A.wsplit; g.tw8 = A.tw8;
+    g.H0 = A.H; g.h_chan_stride = (long long)A.P * hb;
+    g.Ypre = s->ypre; g.ypre_chan_stride = hb;
+    g.Xrow = A.X; g.x_chan_stride = (long long)A.rows * hb; g.x_row_mask = A.rows - 1;
+    g.out = d_out; g.out_chan_stride = (long long)out_stride;
+    g.add = has_tail ? s->tailring : nullptr;
+    g.add_chan_stride = (long long)s->ring_cap; g.add_mask = s->ring_cap - 1;
+    g.add_from = has_tail ? 2 * (long long)T.B : 0;
+    {
+      Timer t(s, 7, s->st_main);
+      RVC_CK(rvc::launch_fused(A.logB, g, s->nch, s->st_main));
+    }
+    // off the latency path: the tail job if a tail block just completed, and the pre-multiplied
+    // accumulator of the next block if this one is complete
+    if (has_tail && !run_tail_job(s, n0, n1, nullptr, in_stride, bg)) return false;
+    if (n1 % hb == 0 && !run_premultiply(s, k0 + 1)) return false;
+    s->n = n1;
+    return true;
+  }
+
+  // ---- general path: any length ----
+  // 1. ingest the call's input into the time ring. For a long call on a single stream the
+  // transforms read the call's buffer directly (FwdArgs::src2) and only the history later calls
+  // can still need -- the last 2*max(h,T) samples -- is copied. (With the tail on the second
+  // stream the job may outlive the caller's buffer, so everything is copied; those calls are short.)
+  const long long keep = 2 * (long long)std::max(A.B, T.B);
+  const bool fuse_in = !bg && (long long)len > keep;
+  {
     rvc::IngestArgs a{};
-    a.src = d_in; a.src_chan_stride = (long long)in_stride;
+    const long long skip = fuse_in ? (long long)len - keep : 0;
+    a.src = d_in + skip; a.src_chan_stride = (long long)in_stride;
     a.ring = s->xring; a.ring_chan_stride = (long long)s->ring_cap; a.ring_mask = s->ring_cap - 1;
-    a.n0 = n0; a.len = (long long)len;
+    a.n0 = n0 + skip; a.len = (long long)len - skip;
     Timer t(s, 0, s->st_main);
     RVC_CK(rvc::launch_ingest(a, s->nch, s->st_main));
   }
+  const float *src2 = fuse_in ? d_in : nullptr;
 
-  if (has_tail) {   // 2. tail stage, one tail period ahead (TwoStageFFTConvolver.cpp:213-222, :247-250)
-    const long long tb = (long long)T.B;
-    const long long mb0 = s->tail_fft_done, mb1 = n1 / tb;   // tail blocks [mb0, mb1) completed by this call
-    if (mb1 > mb0) {
-      hipStream_t st = bg ? s->st_bg : s->st_main;
-      if (bg) {   // startBackgroundProcessing: the job may start once its input is in the ring
-        RVC_CK(hipEventRecord(s->ev_ingest, s->st_main));
-        RVC_CK(hipStreamWaitEvent(st, s->ev_ingest, 0));
-      }
-      rvc::FwdArgs f{};
-      f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
-      f.seg0 = (mb0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
-      f.tw = T.twp(); f.wsplit = T.wsp(); f.tw8 = T.t8p();
-      f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = mb0; f.row_mask = T.rows - 1;
-      {
-        Timer t(s, 4, st);
-        RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(mb1 - mb0), s->nch, st));
-      }
-      const long long m_lo = s->tail_out_done, m_hi = mb1 + 2;   // output blocks whose inputs now exist
-      rvc::FirArgs r{};
-      r.H = T.H; r.h_chan_stride = (long long)T.P * tb;
-      r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
-      r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
-      r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = 2; r.B = (int)tb;
-      {
-        Timer t(s, 5, st);
-        RVC_CK(rvc::launch_fir(r, s->nch, st));
-      }
-      rvc::InvArgs v{};
-      v.Y = T.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp(); v.tw8 = T.t8p();
-      v.blk0 = m_lo;
-      v.dst = s->tailring; v.dst_chan_stride = (long long)s->ring_cap; v.dst_origin = 0; v.dst_mask = s->ring_cap - 1;
-      v.lo = 0; v.hi = (long long)1 << 62;
-      v.add = nullptr;
-      {
-        Timer t(s, 6, st);
-        RVC_CK(rvc::launch_fft_inv(T.logB, T.f64, v, r.M, s->nch, st));
-      }
-      s->tail_fft_done = mb1;
-      s->tail_out_done = m_hi;
-      if (bg) {
-        rvc_set::Job j{m_hi, get_event(s)};
-        RVC_CK(hipEventRecord(j.ev, st));
-        s->jobs.push_back(j);
-      }
-    }
-  }
+  if (has_tail && !run_tail_job(s, n0, n1, src2, in_stride, bg)) return false;   // 2. tail stage
 
   // 3. zero-latency stage: blocks k0..k1 touched by this call
-  const long long hb = (long long)A.B;
-  const long long k0 = n0 / hb, k1 = (n1 - 1) / hb;
   const int M = (int)(k1 - k0 + 1);
   rvc::FwdArgs f{};
   f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
+  f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
   f.seg0 = (k0 - 1) * hb; f.valid_len = (int)(2 * hb); f.lo = 0; f.hi = n1;
   f.tw = A.twp(); f.wsplit = A.wsp(); f.tw8 = A.t8p();
   f.dst = A.X; f.dst_chan_stride = (long long)A.rows * hb; f.row0 = k0; f.row_mask = A.rows - 1;
@@ -464,17 +548,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     Timer t(s, 2, s->st_main);
     RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
   }
-  if (bg) {   // waitForBackgroundProcessing: the job that produced the tail blocks this call reads
-    const long long m_need = (n1 - 1) / (long long)T.B;
-    while (!s->jobs.empty() && m_need >= 2) {
-      rvc_set::Job j = s->jobs.front();
-      // jobs are ordered; every job up to the first one covering m_need must have finished
-      RVC_CK(hipStreamWaitEvent(s->st_main, j.ev, 0));
-      s->jobs.pop_front();
-      s->ev_pool.push_back(j.ev);
-      if (j.m_hi > m_need) break;
-    }
-  }
+  if (bg && !wait_tail_jobs(s, n1)) return false;
   rvc::InvArgs v{};
   v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(); v.wsplit = A.wsp(); v.tw8 = A.t8p();
   v.blk0 = k0;
@@ -562,6 +636,13 @@ void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride, flo
   }
 }
 
+void rvc_set_process_device_blocks(rvc_set *s, const float *d_in, size_t in_stride, float *d_out,
+                                   size_t out_stride, size_t len, size_t block) {
+  if (!s || block == 0) return;
+  for (size_t done = 0; done < len; done += block)
+    rvc_set_process_device(s, d_in + done, in_stride, d_out + done, out_stride, std::min(block, len - done));
+}
+
 void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size_t len) {
   if (!s || len == 0 || !out) return;
   auto zeros = [&]() {
@@ -599,6 +680,7 @@ void rvc_set_clear(rvc_set *s) {
   s->n = 0;
   s->tail_fft_done = 0;
   s->tail_out_done = 2;
+  s->ypre_block = -1;
 }
 
 void rvc_set_reset(rvc_set *s) {

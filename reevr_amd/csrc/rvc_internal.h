@@ -20,6 +20,9 @@ struct FwdArgs {            // real time-domain segment(s) -> spectrum row(s)
   const float *src;         // [channel][ring] time-domain samples
   long long src_chan_stride;
   unsigned long long src_mask;   // index = n & src_mask
+  const float *src2;        // optional second source: the current call's input, [channel][len]; samples
+  long long src2_chan_stride;   // n >= src2_from are read from src2[n - src2_from] instead of the ring
+  long long src2_from;      // (saves the ingest copy of long calls); nullptr = ring only
   long long seg0;           // absolute start of row 0's 2B-sample segment
   int valid_len;            // samples at the start of the segment that may be non-zero (2B: overlap-save
                             // input segment, B: zero-padded IR partition)
@@ -66,6 +69,34 @@ struct InvArgs {            // spectrum row(s) -> last B samples of the inverse 
   long long add_from;       // add applies for n >= add_from
 };
 
+// One head block per call (the plugin's per-block process()): ingest + forward transform +
+// Y = Ypre + H0 * X + inverse transform + tail add, one launch, one workgroup per channel.
+// Ypre = sum_{i>=1} H_i X_{k-i} is prepared off the critical path when block k-1 completes
+// (the reference's _preMultiplied, FFTConvolver.cpp:176-185).
+struct FusedArgs {
+  const float *in;          // [channel][len] the call's input (device)
+  long long in_chan_stride;
+  float *ring;              // time ring (read history, append the call's input)
+  long long ring_chan_stride;
+  unsigned long long ring_mask;
+  long long n0, n1;         // the call covers absolute samples [n0, n1), all inside block k
+  long long k;              // block index
+  const void *tw, *wsplit, *tw8;
+  const float2 *H0;         // [channel][B] partition 0 of the IR spectra
+  long long h_chan_stride;
+  const float2 *Ypre;       // [channel][B]
+  long long ypre_chan_stride;
+  float2 *Xrow;             // [channel][rows][B]: where X_k is stored for later blocks
+  long long x_chan_stride;
+  unsigned long long x_row_mask;
+  float *out;               // [channel][len]
+  long long out_chan_stride;
+  const float *add;         // tail ring or nullptr
+  long long add_chan_stride;
+  unsigned long long add_mask;
+  long long add_from;
+};
+
 struct IngestArgs {
   const float *src;         // [channel][len] (device)
   long long src_chan_stride;
@@ -81,6 +112,9 @@ struct IngestArgs {
 hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int channels, hipStream_t st);
 hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int channels, hipStream_t st);
 hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st);
+// fused single-block step; supported for 9 <= logB <= 13 (float transforms only)
+bool fused_supported(int logB, bool f64);
+hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t st);
 hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st);
 // one-off: raise the dynamic-LDS limit of the large FFT kernels
 hipError_t prepare_kernels();

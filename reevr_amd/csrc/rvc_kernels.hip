@@ -122,6 +122,11 @@ __device__ __forceinline__ void cfft_lds(cx<R> *s, const cx<R> *__restrict__ tw,
   }
 }
 
+// sample n of the input timeline: the call's own input buffer for n >= src2_from, else the ring
+__device__ __forceinline__ float load_sample(const FwdArgs &a, const float *ring, const float *src2, long long n) {
+  return (src2 && n >= a.src2_from) ? src2[n - a.src2_from] : ring[(unsigned long long)n & a.src_mask];
+}
+
 // ----------------------------------------------------------------------------------------
 // forward: 2B real samples -> B packed complex bins (stored as float2 whatever R is: like the
 // reference, spectra live in float and only the transform itself may run in double)
@@ -137,6 +142,7 @@ __global__ void __launch_bounds__(fft_threads(LOGB)) k_fft_fwd(const FwdArgs a) 
   const int tid = threadIdx.x;
   const int r = blockIdx.x, c = blockIdx.y;
   const float *src = a.src + (long long)c * a.src_chan_stride;
+  const float *src2 = a.src2 ? a.src2 + (long long)c * a.src2_chan_stride : nullptr;
   const long long seg = a.seg0 + (long long)r * B;
   const C *tw = reinterpret_cast<const C *>(a.tw);
   const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
@@ -147,8 +153,8 @@ __global__ void __launch_bounds__(fft_threads(LOGB)) k_fft_fwd(const FwdArgs a) 
     const int q = 2 * m;
     const long long n0 = seg + q, n1 = n0 + 1;
     float v0 = 0.f, v1 = 0.f;
-    if (q < a.valid_len && n0 >= a.lo && n0 < a.hi) v0 = src[(unsigned long long)n0 & a.src_mask];
-    if (q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi) v1 = src[(unsigned long long)n1 & a.src_mask];
+    if (q < a.valid_len && n0 >= a.lo && n0 < a.hi) v0 = load_sample(a, src, src2, n0);
+    if (q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi) v1 = load_sample(a, src, src2, n1);
     s[m] = mk<R>((R)v0, (R)v1);
   }
   __syncthreads();
@@ -291,11 +297,62 @@ __device__ __forceinline__ void dft8(cx<R> *a) {
   a[1] = d0; a[3] = d1; a[5] = d2; a[7] = d3;
 }
 
+// Twiddles of one transform, per thread, in registers: they depend on the thread index only, so
+// they are requested at the top of the kernel -- before the input data has even arrived -- and the
+// passes never wait on a twiddle load. Forward and inverse share them (conjugated on use).
+template <int LOGB, typename R> struct Tw8 {
+  typedef Plan8<LOGB> P;
+  // eager (register) prefetch only where it fits the 128-VGPR budget of a 1024-thread workgroup
+  static constexpr bool EAGER = sizeof(R) == 4 ? (LOGB <= 12) : (LOGB <= 11);
+  static constexpr int NP = (EAGER && P::N8 > 1) ? P::N8 - 1 : 1;
+  static constexpr int NQ = !EAGER ? 1 : (P::Q == 2 ? P::E / 2 : (P::Q == 4 ? (P::E / 4) * 3 : 1));
+  cx<R> t8[NP][P::S][7];     // radix-8 passes j = 1 .. N8-1: w^{r k}, r = 1..7
+  cx<R> tq[NQ];              // final radix-2 / radix-4 pass
+  const cx<R> *p8, *p1;
+  int tid_;
+  __device__ __forceinline__ void load(const cx<R> *__restrict__ tw8, const cx<R> *__restrict__ tw, const int tid) {
+    p8 = tw8; p1 = tw; tid_ = tid;
+    if constexpr (EAGER) {
+#pragma unroll
+      for (int j = 1; j < P::N8; ++j) {
+        const int p = 1 << (3 * j);
+#pragma unroll
+        for (int s = 0; s < P::S; ++s) {
+          const int k = (tid + s * P::NT) & (p - 1);
+          const cx<R> *t = tw8 + P::off8(j) + k * 8;
+#pragma unroll
+          for (int r = 1; r < 8; ++r) t8[j - 1][s][r - 1] = t[r];
+        }
+      }
+      if constexpr (P::Q == 2) {
+#pragma unroll
+        for (int jb = 0; jb < P::E / 2; ++jb) tq[jb] = tw[tid + jb * P::NT];
+      } else if constexpr (P::Q == 4) {
+#pragma unroll
+        for (int jb = 0; jb < P::E / 4; ++jb) {
+          const cx<R> *t = tw8 + P::offq + (tid + jb * P::NT) * 4;
+#pragma unroll
+          for (int r = 1; r < 4; ++r) tq[jb * 3 + r - 1] = t[r];
+        }
+      }
+    }
+  }
+  // twiddle of radix-8 pass j >= 1, butterfly slot s, leg r = 1..7
+  __device__ __forceinline__ cx<R> w8(const int j, const int s, const int r) const {
+    if constexpr (EAGER) return t8[j - 1][s][r - 1];
+    else return p8[P::off8(j) + ((tid_ + s * P::NT) & ((1 << (3 * j)) - 1)) * 8 + r];
+  }
+  // twiddle of the final pass: butterfly jb, leg r (radix-2: r = 1; radix-4: r = 1..3)
+  __device__ __forceinline__ cx<R> wq(const int jb, const int r) const {
+    if constexpr (EAGER) return P::Q == 2 ? tq[jb] : tq[jb * 3 + r - 1];
+    else return P::Q == 2 ? p1[tid_ + jb * P::NT] : p8[P::offq + (tid_ + jb * P::NT) * 4 + r];
+  }
+};
+
 // v[e] = x[in_idx(e)] on entry, X[out_idx(e)] on exit (unscaled). `lds` holds LDS_ELEMS values.
 // Ends with all LDS reads done but NO trailing barrier.
 template <int LOGB, bool INV, typename R>
-__device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const cx<R> *__restrict__ tw8,
-                                          const cx<R> *__restrict__ tw, const int tid) {
+__device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, R> &T, const int tid) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
 #pragma unroll
@@ -303,14 +360,11 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const cx<R> *__r
     const int p = 1 << (3 * j);
 #pragma unroll
     for (int s = 0; s < P::S; ++s) {
-      const int i = tid + s * P::NT;
       C *a = v + 8 * s;
       if (j > 0) {
-        const int k = i & (p - 1);
-        const C *t = tw8 + P::off8(j) + k * 8;
 #pragma unroll
         for (int r = 1; r < 8; ++r) {
-          C w = t[r];
+          C w = T.w8(j > 0 ? j : 1, s, r);
           if (INV) w.y = -w.y;
           a[r] = cmul(a[r], w);
         }
@@ -349,16 +403,15 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const cx<R> *__r
 #pragma unroll
       for (int r = 0; r < P::Q; ++r) b[r] = lds[lpad(i + r * ST)];
       if constexpr (P::Q == 2) {
-        C w = tw[i];                             // e^{-2 pi i k / B}
+        C w = T.wq(jb, 1);                       // e^{-2 pi i k / B}
         if (INV) w.y = -w.y;
         const C x1 = cmul(b[1], w);
         const C x0 = b[0];
         b[0] = cadd(x0, x1); b[1] = csub(x0, x1);
       } else {
-        const C *t = tw8 + P::offq + i * 4;
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
-          C w = t[r];
+          C w = T.wq(jb, r);
           if (INV) w.y = -w.y;
           b[r] = cmul(b[r], w);
         }
@@ -378,20 +431,26 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
   const int tid = threadIdx.x;
   const int r_ = blockIdx.x, c = blockIdx.y;
   const float *src = a.src + (long long)c * a.src_chan_stride;
+  const float *src2 = a.src2 ? a.src2 + (long long)c * a.src2_chan_stride : nullptr;
   const long long seg = a.seg0 + (long long)r_ * B;
   const C *tw = reinterpret_cast<const C *>(a.tw);
   const C *tw8 = reinterpret_cast<const C *>(a.tw8);
   const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
 
+  Tw8<LOGB, R> T;
+  T.load(tw8, tw, tid);
   C v[P::E];
   // z[m] = x[2m] + i x[2m+1], m = in_idx(e). Fast path: the whole 2B segment is valid input
   // (wave-uniform test) -> one aligned 8-byte load per value, no per-sample checks.
   const bool whole = (a.valid_len == 2 * B) && seg >= a.lo && seg + 2 * B <= a.hi;
-  if (whole) {
+  // with a second source the 8-byte loads need it even-aligned relative to the sample clock
+  const bool s2ok = !src2 || (((a.src2_from & 1) == 0) && ((reinterpret_cast<uintptr_t>(src2) & 7u) == 0));
+  if (whole && s2ok) {
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       const long long n = seg + 2 * P::in_idx(tid, e);
-      const float2 x = *reinterpret_cast<const float2 *>(src + ((unsigned long long)n & a.src_mask));
+      const float *p = (src2 && n >= a.src2_from) ? src2 + (n - a.src2_from) : src + ((unsigned long long)n & a.src_mask);
+      const float2 x = *reinterpret_cast<const float2 *>(p);
       v[e] = mk<R>((R)x.x, (R)x.y);
     }
   } else {
@@ -400,12 +459,22 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
       const int q = 2 * P::in_idx(tid, e);
       const long long n0 = seg + q, n1 = n0 + 1;
       float v0 = 0.f, v1 = 0.f;
-      if (q < a.valid_len && n0 >= a.lo && n0 < a.hi) v0 = src[(unsigned long long)n0 & a.src_mask];
-      if (q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi) v1 = src[(unsigned long long)n1 & a.src_mask];
+      if (q < a.valid_len && n0 >= a.lo && n0 < a.hi) v0 = load_sample(a, src, src2, n0);
+      if (q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi) v1 = load_sample(a, src, src2, n1);
       v[e] = mk<R>((R)v0, (R)v1);
     }
   }
-  fft8_core<LOGB, false, R>(v, lds, tw8, tw, tid);
+  C ws[P::E];                                   // split twiddles: requested before the transform when
+  constexpr bool kEager = Tw8<LOGB, R>::EAGER;  // the register budget allows, else after it
+  if constexpr (kEager) {
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) ws[e] = wsplit[P::out_idx(tid, e)];
+  }
+  fft8_core<LOGB, false, R>(v, lds, T, tid);
+  if constexpr (!kEager) {
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) ws[e] = wsplit[P::out_idx(tid, e)];
+  }
 
   // real split through LDS: X[k] = E + w^k O with the partner Z[B-k] held by another thread
   __syncthreads();
@@ -426,7 +495,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
       const C Ev = mk<R>(half * (A.x + Bc.x), half * (A.y + Bc.y));
       const C D = mk<R>(half * (A.x - Bc.x), half * (A.y - Bc.y));
       const C O = mk<R>(D.y, -D.x);                  // -i * D
-      const C X = cadd(Ev, cmul(wsplit[k], O));      // wsplit has B entries: e^{-i pi k / B}
+      const C X = cadd(Ev, cmul(ws[e], O));          // wsplit has B entries: e^{-i pi k / B}
       dst[k] = make_float2((float)X.x, (float)X.y);
     }
   }
@@ -449,6 +518,8 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_inv(const InvArgs a) {
   const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
 
   // Z[k] = E + iO straight from global: Y[k] ascending and Y[B-k] descending are both coalesced
+  Tw8<LOGB, R> T;
+  T.load(tw8, tw, tid);
   C v[P::E];
   const R sc = (R)0.5 / (R)B;
 #pragma unroll
@@ -466,7 +537,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_inv(const InvArgs a) {
       v[e] = mk<R>(Ev.x - O.y, Ev.y + O.x);
     }
   }
-  fft8_core<LOGB, true, R>(v, lds, tw8, tw, tid);
+  fft8_core<LOGB, true, R>(v, lds, T, tid);
 
   // z[m] = (s[2m], s[2m+1]); the overlap-save output is s[B..2B) = z[B/2..B): 8-byte stores
   float *dst = a.dst + (long long)c * a.dst_chan_stride;
@@ -502,6 +573,130 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_inv(const InvArgs a) {
           if (add && n + 1 >= a.add_from) t += add[(unsigned long long)(n + 1) & a.add_mask];
           dst[(unsigned long long)(n + 1 - a.dst_origin) & a.dst_mask] = t;
         }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// fused streaming step: everything the plugin's per-block process() needs in ONE launch
+// (TwoStageFFTConvolver.cpp:151-233 for len <= head block). One workgroup per channel.
+// ----------------------------------------------------------------------------------------
+template <int LOGB>
+__global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fused_block(const FusedArgs a) {
+  typedef Plan8<LOGB> P;
+  typedef cx<float> C;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  C *lds = reinterpret_cast<C *>(smem_raw);
+  constexpr int B = P::B;
+  const int tid = threadIdx.x;
+  const int c = blockIdx.x;
+  const float *in = a.in + (long long)c * a.in_chan_stride;
+  float *ring = a.ring + (long long)c * a.ring_chan_stride;
+  const C *tw = reinterpret_cast<const C *>(a.tw);
+  const C *tw8 = reinterpret_cast<const C *>(a.tw8);
+  const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
+  const long long seg = (a.k - 1) * (long long)B;     // overlap-save segment [x_{k-1}; x_k]
+
+  // 0. everything that does not depend on the audio is requested first: twiddles, split
+  //    twiddles, partition 0 of the IR and the pre-multiplied accumulator
+  Tw8<LOGB, float> T;
+  T.load(tw8, tw, tid);
+  const float2 *H0 = a.H0 + (long long)c * a.h_chan_stride;
+  const float2 *Ypre = a.Ypre + (long long)c * a.ypre_chan_stride;
+  C wso[P::E], wsi[P::E];
+  float2 h0[P::E], ypre[P::E];
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    wso[e] = wsplit[P::out_idx(tid, e)];
+    wsi[e] = wsplit[P::in_idx(tid, e)];
+    h0[e] = H0[P::out_idx(tid, e)];
+    ypre[e] = Ypre[P::out_idx(tid, e)];
+  }
+  // 1. load the segment: history from the ring, this call's samples from `in` (and append them
+  //    to the ring), zero for the not-yet-played rest of block k and for time < 0
+  C v[P::E];
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const long long n = seg + 2 * P::in_idx(tid, e);
+    float s0 = 0.f, s1 = 0.f;
+    if (n >= a.n0) {
+      if (n < a.n1) { s0 = in[n - a.n0]; ring[(unsigned long long)n & a.ring_mask] = s0; }
+    } else if (n >= 0) s0 = ring[(unsigned long long)n & a.ring_mask];
+    const long long m = n + 1;
+    if (m >= a.n0) {
+      if (m < a.n1) { s1 = in[m - a.n0]; ring[(unsigned long long)m & a.ring_mask] = s1; }
+    } else if (m >= 0) s1 = ring[(unsigned long long)m & a.ring_mask];
+    v[e] = mk<float>(s0, s1);
+  }
+  // 2. forward transform, real split; X_k goes to the delay line and, times H0 plus the
+  //    pre-multiplied accumulator, becomes Y_k
+  fft8_core<LOGB, false, float>(v, lds, T, tid);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = v[e];
+  __syncthreads();
+  float2 *Xrow = a.Xrow + (long long)c * a.x_chan_stride + (long long)((unsigned long long)a.k & a.x_row_mask) * B;
+  C y[P::E];
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int k = P::out_idx(tid, e);
+    const C A = v[e];
+    const float2 h = h0[e], yp = ypre[e];
+    if (k == 0) {
+      const float2 X = make_float2(A.x + A.y, A.x - A.y);             // packed (DC, Nyquist)
+      Xrow[0] = X;
+      y[e] = mk<float>(fmaf(h.x, X.x, yp.x), fmaf(h.y, X.y, yp.y));  // two real products
+    } else {
+      const C Bc = cconj(lds[lpad(B - k)]);
+      const C Ev = mk<float>(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
+      const C D = mk<float>(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
+      const C O = mk<float>(D.y, -D.x);
+      const C X = cadd(Ev, cmul(wso[e], O));
+      Xrow[k] = make_float2(X.x, X.y);
+      y[e] = mk<float>(fmaf(h.x, X.x, fmaf(-h.y, X.y, yp.x)), fmaf(h.x, X.y, fmaf(h.y, X.x, yp.y)));
+    }
+  }
+  // 3. inverse split needs Y[k] and Y[B-k] in the in_idx mapping: exchange through LDS
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = y[e];
+  __syncthreads();
+  const float sc = 0.5f / (float)B;
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int k = P::in_idx(tid, e);
+    const C Yk = lds[lpad(k)];
+    if (k == 0) {
+      v[e] = mk<float>(sc * (Yk.x + Yk.y), sc * (Yk.x - Yk.y));
+    } else {
+      const C Yc = cconj(lds[lpad(B - k)]);
+      const C Ev = mk<float>(sc * (Yk.x + Yc.x), sc * (Yk.y + Yc.y));
+      const C D = mk<float>(sc * (Yk.x - Yc.x), sc * (Yk.y - Yc.y));
+      const C O = cmul(cconj(wsi[e]), D);
+      v[e] = mk<float>(Ev.x - O.y, Ev.y + O.x);
+    }
+  }
+  __syncthreads();
+  fft8_core<LOGB, true, float>(v, lds, T, tid);
+  // 4. the block's samples are z[B/2 .. B); only [n0, n1) is wanted; add the tail contribution
+  float *out = a.out + (long long)c * a.out_chan_stride;
+  const float *add = a.add ? a.add + (long long)c * a.add_chan_stride : nullptr;
+  const long long nblk = a.k * (long long)B;
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const int m = P::out_idx(tid, e);
+    if (m >= B / 2) {
+      const long long n = nblk + 2 * m - B;
+      if (n >= a.n0 && n < a.n1) {
+        float t = v[e].x;
+        if (add && n >= a.add_from) t += add[(unsigned long long)n & a.add_mask];
+        out[n - a.n0] = t;
+      }
+      if (n + 1 >= a.n0 && n + 1 < a.n1) {
+        float t = v[e].y;
+        if (add && n + 1 >= a.add_from) t += add[(unsigned long long)(n + 1) & a.add_mask];
+        out[n + 1 - a.n0] = t;
       }
     }
   }
@@ -748,6 +943,59 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------
+// single output row (the streaming case, M = 1): Y = sum_i H[i] * X[k0-d-i]. Latency matters,
+// not bandwidth: the four waves of a workgroup split the partitions (i = wave, wave+4, ...),
+// each keeps 8 independent row pairs in flight, and the partial sums meet in LDS.
+// grid (ceil(B/64), channels), block 256.
+// ----------------------------------------------------------------------------------------
+template <int STAGE>
+__global__ void __launch_bounds__(256) k_fir_row(const FirArgs a) {
+  __shared__ float2 part[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int bin = blockIdx.x * 64 + lane;
+  const int c = blockIdx.y;
+  const bool active = bin < a.B;
+  const int b = active ? bin : 0;
+  const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride + b;
+  const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride + b;
+  const long long B = a.B;
+  const long long cbase = a.k0 - a.delay;
+  const bool packed = (bin == 0);
+  float2 acc = make_float2(0.f, 0.f);
+  constexpr int U = 8;
+  for (int i0 = wave; i0 < a.P; i0 += 4 * U) {
+    float2 h[U], x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                       // all 16 loads first (clamped addresses)
+      const int i = i0 + 4 * u;
+      const int ii = i < a.P ? i : a.P - 1;
+      const long long row = cbase - ii, rr = row < 0 ? 0 : row;
+      h[u] = Hc[(long long)ii * B];
+      x[u] = Xc[(long long)((unsigned long long)rr & a.x_row_mask) * B];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 4 * u;
+      if (i < a.P && cbase - i >= 0) {                   // uniform
+        const float hz = packed ? 0.f : h[u].y;
+        const float h3 = packed ? h[u].y : h[u].x;
+        acc.x = fmaf(h[u].x, x[u].x, acc.x);
+        acc.x = fmaf(-hz, x[u].y, acc.x);
+        acc.y = fmaf(h3, x[u].y, acc.y);
+        acc.y = fmaf(hz, x[u].x, acc.y);
+      }
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && active) {
+    const float2 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+    a.Y[(long long)c * a.y_chan_stride + bin] = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // ingest: append the call's input to the per-channel time ring
 // ----------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_ingest(const IngestArgs a) {
@@ -836,6 +1084,26 @@ hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int ch
   }
 }
 
+bool fused_supported(int logB, bool f64) { return !f64 && logB >= 9 && logB <= 13; }
+
+template <int LOGB>
+static hipError_t launch_fused_t(const FusedArgs &a, int channels, hipStream_t st) {
+  const size_t lds = sizeof(cx<float>) * Plan8<LOGB>::LDS_ELEMS;
+  hipLaunchKernelGGL((k_fused_block<LOGB>), dim3(channels), dim3(Plan8<LOGB>::NT), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t st) {
+  switch (logB) {
+    case 9: return launch_fused_t<9>(a, channels, st);
+    case 10: return launch_fused_t<10>(a, channels, st);
+    case 11: return launch_fused_t<11>(a, channels, st);
+    case 12: return launch_fused_t<12>(a, channels, st);
+    case 13: return launch_fused_t<13>(a, channels, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 int fir_time_tile(int M) { return M >= 16 ? 16 : (M >= 8 ? 8 : (M >= 4 ? 4 : (M >= 2 ? 2 : 1))); }
 
 hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
@@ -844,6 +1112,12 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
     const dim3 grid(a.B / 64, (a.M + 63) / 64, channels), block(256);
     if (a.delay == 0) hipLaunchKernelGGL((k_fir_lds<0>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_fir_lds<1>), grid, block, 0, st, a);
+    return hipGetLastError();
+  }
+  if (a.M == 1) {                         // one block: the latency-oriented row kernel
+    const dim3 grid((a.B + 63) / 64, channels), block(256);
+    if (a.delay == 0) hipLaunchKernelGGL((k_fir_row<0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_fir_row<1>), grid, block, 0, st, a);
     return hipGetLastError();
   }
   const int tk = fir_time_tile(a.M);
@@ -879,6 +1153,11 @@ hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st) {
 hipError_t prepare_kernels() {
   // B = 16384 needs 128 KiB of dynamic LDS, above the 64 KiB default limit.
   // padded LDS: B + B/16 values. float B=8192: 68 KiB, B=16384: 136 KiB; double B=4096: 68 KiB, B=8192: 136 KiB
+  {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_block<13>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 139264);
+    if (e != hipSuccess) return e;
+  }
   const void *big[] = {reinterpret_cast<const void *>(k_fft8_fwd<13, float>), reinterpret_cast<const void *>(k_fft8_inv<13, float>),
                        reinterpret_cast<const void *>(k_fft8_fwd<14, float>), reinterpret_cast<const void *>(k_fft8_inv<14, float>),
                        reinterpret_cast<const void *>(k_fft8_fwd<12, double>), reinterpret_cast<const void *>(k_fft8_inv<12, double>),
