@@ -17,10 +17,10 @@ import re
 
 
 def family(name: str, head_log: int, tail_log: int):
-    m = re.search(r"k_fir<(\d+), (\d)>", name)
+    m = re.search(r"k_fir(?:_lds|_row)?<(?:\d+, )?(\d)>", name)
     if m:
-        return "fir_head" if m.group(2) == "0" else "fir_tail"
-    m = re.search(r"k_fft_(fwd|inv)<(\d+), float>", name)
+        return "fir_head" if m.group(1) == "0" else "fir_tail"
+    m = re.search(r"k_fft8?_(fwd|inv)<(\d+), float>", name)
     if m:
         lg = int(m.group(2))
         st = "head" if lg == head_log else ("tail" if lg == tail_log else None)
