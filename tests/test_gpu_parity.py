@@ -236,3 +236,77 @@ def test_stereo_convolver_quad_and_force2():
     sc.process(L[:480], R[:480], 480, True)              # force2Chans leaves LR/RL untouched
     assert np.array_equal(before, sc.bufferLR)
     assert isinstance(sc.finishedLoading(), bool)
+
+
+def test_many_channels_one_set_vs_oracle():
+    """BASELINE configs[3]/[4] shape: many independent channels in ONE set (one launch per stage),
+    each with its own IR (different lengths: the set pads the partition count) and input."""
+    nch, frames = 16, 40000
+    irs = [synth.synth_ir(9000 + 1500 * c, 1, 30 + c)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(frames, c) for c in range(nch)])
+    s = reevr_amd.ConvolverSet(nch)
+    assert s.init(512, 8192, irs, max_len=frames)
+    big = s.process(x)
+    s.clear()
+    blk = np.concatenate([s.process(x[:, i:i + 512]) for i in range(0, 512 * 40, 512)], axis=1)
+    for c in range(nch):
+        o = O.TwoStageFFTConvolver("orc"); assert o.init(512, 8192, irs[c])
+        want = o.process(x[c])
+        assert rel_rms(big[c], want) <= TOL
+        assert rel_rms(blk[c], want[:512 * 40]) <= TOL
+
+
+def test_f64_mode_big_call_and_streaming():
+    case = cases.SYNTH_CASES["cfg4_inst3_10s_b512"]
+    irs = cases.make_ir(case["ir"])
+    x = cases.make_input(case, 2)
+    want = cases.run_synth_case(orc_factory, case)
+    s = reevr_amd.ConvolverSet(2, fft_f64=True)
+    assert s.init(512, 8192, list(irs), max_len=case["frames"])
+    big = s.process(x)
+    s.clear()
+    n = 512 * 100
+    blk = np.concatenate([s.process(x[:, i:i + 512]) for i in range(0, n, 512)], axis=1)
+    for c in range(2):
+        assert rel_rms(big[c], want[c]) <= 1e-6        # double transforms: reference-grade
+        assert rel_rms(blk[c], want[c, :n]) <= 1e-6
+
+
+def test_handles_are_independent_across_threads():
+    """The reference's threading contract: init() on one instance runs concurrently
+    with process() on another (IR hot-swap, src/PluginProcessor.cpp:1680-1691)."""
+    import threading
+    ir_a = synth.synth_ir(60000, 2, 40)
+    ir_b = synth.synth_ir(90000, 2, 41)
+    x = np.stack([synth.synth_input(512 * 300, c) for c in range(2)])
+    want = []
+    for c in range(2):
+        o = O.TwoStageFFTConvolver("orc"); assert o.init(512, 8192, ir_a[c])
+        want.append(o.process(x[c]))
+    want = np.stack(want)
+    a = reevr_amd.ConvolverSet(2, bg_stream=True)
+    assert a.init(512, 8192, list(ir_a))
+    stop = threading.Event()
+    errors = []
+
+    def loader():          # keeps re-initialising and exercising a second set
+        b = reevr_amd.ConvolverSet(2, bg_stream=True)
+        try:
+            while not stop.is_set():
+                if not b.init(512, 8192, list(ir_b)):
+                    errors.append(b.last_error_string)
+                    return
+                b.process(x[:, :512 * 4])
+        except Exception as e:   # pragma: no cover
+            errors.append(repr(e))
+
+    t = threading.Thread(target=loader)
+    t.start()
+    try:
+        got = np.concatenate([a.process(x[:, i:i + 512]) for i in range(0, x.shape[1], 512)], axis=1)
+    finally:
+        stop.set()
+        t.join()
+    assert not errors, errors
+    for c in range(2):
+        assert rel_rms(got[c], want[c]) <= TOL
