@@ -10,8 +10,13 @@ A "step" is one pass of the hot path over one batch of input: ONE process() call
 input and output resident in HBM. process() takes any length, and its result does not
 depend on how the stream is cut into calls (tests/test_gpu_parity.py), so this is the same
 function the plugin calls per 512-sample block -- batched in time because a single
-512-frame block (2 KB per channel) cannot fill a 256-CU GPU. The strictly block-by-block
-rate (one call per 512 frames) is reported beside it as "streaming".
+512-frame block (2 KB per channel) cannot fill a 256-CU GPU. Two more numbers are reported
+beside `value` so nothing hides behind the batching:
+  * "two_stage": the same call with RVC_FLAG_FIXED_PARTITIONS, i.e. forced through the
+    reference's head-512 / tail-8192 partition structure (the engine's default instead gives a
+    call that spans >= 4 tail blocks to one uniform delay line at the tail block size -- same
+    output, no 512-sample work where no 512-sample latency is asked for);
+  * "streaming": strictly one call per 512-frame block (the plugin's real-time pattern).
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
@@ -119,8 +124,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=40 * SR, help="frames per channel per step (one process() call)")
     ap.add_argument("--bg-stream", type=int, default=0, help="1: tail stage on the second HIP stream (overlaps the head stage)")
+    ap.add_argument("--fixed-partitions", type=int, default=0,
+                    help="1: force the reference's head/tail partition sizes even for long calls")
     ap.add_argument("--gather", action="store_true", help="RCCL all_gather of the output batch each step")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--side", type=int, default=1, help="0: skip the two_stage side measurement")
     ap.add_argument("--stream-calls", type=int, default=3000, help="512-frame calls of the streaming side measurement")
     args = ap.parse_args()
 
@@ -147,7 +155,8 @@ def main():
     nch = 2
     irs = synth.synth_ir(IR_LEN, nch, inst=rank)                 # this rank's stereo instance
     x = np.stack([synth.synth_input(frames, c + 2 * rank) for c in range(nch)])
-    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream))
+    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream),
+                                  fixed_partitions=bool(args.fixed_partitions))
     t_init = time.perf_counter()
     if not conv.init(HOST_BLOCK, 8192, list(irs), max_len=frames):
         raise SystemExit(f"init failed: {conv.last_error_string}")
@@ -219,6 +228,14 @@ def main():
         "fft_inv_tail": (8.0 * (tail + 1) + 12.0 * tail) * blocksT * nch,
         "ingest": 8.0 * frames * nch,
     }
+    adaptive = not args.fixed_partitions and not args.bg_stream and "fir_head" not in kern
+    if adaptive:
+        # the long-call path runs ONE delay line (P_T + 2 partitions at the tail block size) that does
+        # the work of the reference's head, tail0 and tail delay lines: it inherits all their
+        # algorithmic bytes; likewise the transforms
+        alg["fir_tail"] += alg["fir_head"]
+        alg["fft_fwd_tail"] += alg["fft_fwd_head"]
+        alg["fft_inv_tail"] += alg["fft_inv_head"]
     dominant = max(kern, key=lambda k: kern[k]["avg_ms"]) if kern else None
     roof = None
     if dominant:
@@ -237,12 +254,31 @@ def main():
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": alg[dominant], "avg_launch_ms": round(kern[dominant]["avg_ms"], 5),
                 "traffic_source": tsrc,
-                "note": "achieved = ALGORITHMIC bytes (16 B per partition x bin: one IR bin + one delay-line bin, "
-                        "SURVEY.md 8d) / measured launch time. The kernel tiles 16 blocks of time per thread, so "
-                        "each IR bin loaded is used 16 times: physical HBM traffic (`traffic`) is ~30x below the "
-                        "algorithmic figure and frac > 1 is expected; the kernel is fp32-FMA / latency bound."}
+                "note": "achieved = ALGORITHMIC bytes of the reference structure this launch replaces (16 B per "
+                        "partition x bin of the head, tail0 and tail delay lines, SURVEY.md 8d) / measured launch "
+                        "time. The kernel tiles 64 blocks of time per workgroup and, for long calls, uses 8192-sample "
+                        "partitions for the whole IR, so physical HBM traffic (`traffic`) is ~50x below the "
+                        "algorithmic figure: frac > 1 is expected, the kernel is fp32-FMA bound (DESIGN.md 7)."}
     bps = alg_bytes_per_sample(head, tail, IR_LEN)
     path_gbs = value / world * 1e6 * bps / 1e9
+
+    # ---- side measurement: the same call forced through the reference's partition sizes ----
+    two_stage = None
+    if adaptive and args.side:
+        fconv = reevr_amd.ConvolverSet(nch, device=local_rank, fixed_partitions=True)
+        assert fconv.init(HOST_BLOCK, 8192, list(irs), max_len=frames)
+        for _ in range(max(args.warmup, 2)):
+            fconv.process_device(d_in, d_out, sync=False)
+        fconv.sync()
+        tf = time.perf_counter()
+        for _ in range(args.steps):
+            fconv.process_device(d_in, d_out, sync=False)
+        fconv.sync()
+        tf = time.perf_counter() - tf
+        two_stage = {"value": round(nch * frames * args.steps / tf / 1e6, 3), "unit": "Msamples/s",
+                     "ms_per_step": round(tf / args.steps * 1e3, 4),
+                     "note": "RVC_FLAG_FIXED_PARTITIONS: head 512 (32 partitions) + tail 8192 (57 partitions) for the whole call"}
+        fconv.close()
 
     # ---- streaming side measurement: one process() call per 512-frame host block --------
     streaming = None
@@ -273,12 +309,15 @@ def main():
                    "frames_per_step": frames, "channels_per_gpu": nch, "instances": world,
                    "partitions": {"head+tail0": PA, "tail": PT},
                    "call": "one process() per step, device-resident I/O", "gather": do_gather,
+                   "partitioning": "fixed head/tail" if not adaptive else
+                                   "adaptive: long call -> one uniform delay line at the tail block size (P = %d)" % (PT + 2),
                    "sharding": "one independent stereo instance per rank (unit mod world), no data-path collective"},
         "roofline": roof,
         "path_roofline": {"alg_bytes_per_sample": round(bps, 1), "achieved_GBs_per_gpu": round(path_gbs, 1),
                           "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4),
                           "x_realtime_per_gpu": round(value / world * 1e6 / (SR * nch), 1)},
         "kernels_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()},
+        "two_stage": two_stage,
         "streaming": streaming,
         "cpu_baseline": cpu,
         "init_ms": round(init_ms, 2),

@@ -55,6 +55,12 @@ enum {
                                    faster). Limits the block size to RVC_MAX_BLOCK/2. IR spectra are computed
                                    in double at init in either mode. */
 
+#define RVC_FLAG_FIXED_PARTITIONS 8u /* always use the reference's head/tail partition sizes. Default: a long
+                                   call (>= 5 tail blocks) computes the tail blocks that lie entirely
+                                   inside it with ONE uniform delay line at the tail block size over the
+                                   whole IR -- same result (it does not depend on partition sizes), no
+                                   512-sample work where no 512-sample latency is needed. */
+
 /* ---- lifetime ---------------------------------------------------------------------- */
 
 /* Replaces `new Convolver()` x n (StereoConvolver.h:12-17). `device` is the HIP ordinal.

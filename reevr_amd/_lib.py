@@ -16,6 +16,7 @@ RVC_OK, RVC_ERR_NO_DEVICE, RVC_ERR_HIP, RVC_ERR_BAD_ARG, RVC_ERR_UNSUPPORTED, RV
 RVC_FLAG_BG_STREAM = 1
 RVC_FLAG_TIMING = 2
 RVC_FLAG_FFT_F64 = 4
+RVC_FLAG_FIXED_PARTITIONS = 8
 RVC_MAX_BLOCK = 16384
 
 # name -> (restype, argtypes); must list every symbol declared in include/reevr_amd/rvc.h

@@ -54,7 +54,10 @@ int ilog2(size_t v) {
 struct Stage {
   int logB = 0;
   size_t B = 0;
-  int P = 0;          // partitions (max over channels); 0 = stage absent
+  int P = 0;          // partitions of this delay line (max over channels); 0 = stage absent
+  int PF = 0;         // tail stage only: rows of H = 2 + P, the WHOLE IR at block T (rows 0,1 = IR[0,2T) are
+                      // used by the adaptive long-call path, rows 2.. are the delay-2 tail partitions)
+  int hrows() const { return PF ? PF : P; }
   int delay = 0;      // block delay of the delay line (0 or 2)
   size_t rows = 0;    // X ring rows (power of two)
   size_t mcap = 0;    // Y rows (max output rows per call)
@@ -93,6 +96,9 @@ struct rvc_set {
   long long n = 0;               // absolute sample clock
   long long tail_fft_done = 0;   // tail blocks [0, tail_fft_done) have spectra
   long long tail_out_done = 2;   // tail contributions for output blocks [2, tail_out_done) are in the ring
+                                 // (or were delivered directly by the adaptive long-call path)
+  long long xa_next = 0;         // head delay line: rows [xa_next-P+1, xa_next) are valid; a stage-A run that
+                                 // starts beyond xa_next (the long-call path skipped blocks) rebuilds its history
 
   hipStream_t st_main = nullptr, st_bg = nullptr;
   bool streams_ok = false;
@@ -181,6 +187,7 @@ void free_device_state(rvc_set *s) {
   s->n = 0;
   s->tail_fft_done = 0;
   s->tail_out_done = 2;
+  s->xa_next = 0;
 }
 
 bool make_twiddles(rvc_set *s, Stage &g) {
@@ -246,14 +253,14 @@ bool make_twiddles(rvc_set *s, Stage &g) {
 // IR partitions -> spectra: one batched forward launch over all partitions of all channels
 // (replaces the per-partition loop FFTConvolver.cpp:129-137).
 bool upload_ir_stage(rvc_set *s, Stage &g, const std::vector<std::vector<float>> &parts) {
-  const size_t padded = (size_t)g.P * g.B;
+  const size_t padded = (size_t)g.hrows() * g.B;
   std::vector<float> host((size_t)s->nch * padded, 0.f);
   for (int c = 0; c < s->nch; ++c)
     std::copy(parts[c].begin(), parts[c].end(), host.begin() + (size_t)c * padded);
   float *d_ir = nullptr;
   RVC_CK(hipMalloc(&d_ir, sizeof(float) * host.size()));
   RVC_CK(hipMemcpy(d_ir, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
-  RVC_CK(hipMalloc(&g.H, sizeof(float2) * (size_t)s->nch * g.P * g.B));
+  RVC_CK(hipMalloc(&g.H, sizeof(float2) * (size_t)s->nch * g.hrows() * g.B));
   rvc::FwdArgs a{};
   a.src = d_ir; a.src_chan_stride = (long long)padded; a.src_mask = ~0ull;
   a.seg0 = 0; a.valid_len = (int)g.B; a.lo = 0; a.hi = (long long)padded;
@@ -263,8 +270,8 @@ bool upload_ir_stage(rvc_set *s, Stage &g, const std::vector<std::vector<float>>
   a.tw = ir64 ? (const void *)g.twd : (const void *)g.tw;
   a.wsplit = ir64 ? (const void *)g.wsplitd : (const void *)g.wsplit;
   a.tw8 = ir64 ? (const void *)g.tw8d : (const void *)g.tw8;
-  a.dst = g.H; a.dst_chan_stride = (long long)g.P * (long long)g.B; a.row0 = 0; a.row_mask = ~0ull;
-  hipError_t e = rvc::launch_fft_fwd(g.logB, ir64, a, g.P, s->nch, s->st_main);
+  a.dst = g.H; a.dst_chan_stride = (long long)g.hrows() * (long long)g.B; a.row0 = 0; a.row_mask = ~0ull;
+  hipError_t e = rvc::launch_fft_fwd(g.logB, ir64, a, g.hrows(), s->nch, s->st_main);
   if (e == hipSuccess) e = hipStreamSynchronize(s->st_main);
   hipFree(d_ir);
   if (e != hipSuccess) return fail(s, RVC_ERR_HIP, e, "IR spectra");
@@ -322,11 +329,10 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     const size_t la = std::min(len[c], split);
     partsA[c].assign(irs[c], irs[c] + la);
     pa = std::max(pa, (la + hb - 1) / hb);
-    if (len[c] > split) {
-      partsT[c].assign(irs[c] + split, irs[c] + len[c]);
-      pt = std::max(pt, (len[c] - split + tb - 1) / tb);
-    }
+    if (len[c] > split) pt = std::max(pt, (len[c] - split + tb - 1) / tb);
   }
+  if (pt > 0)   // the tail stage keeps the WHOLE IR at block T (see Stage::PF)
+    for (int c = 0; c < s->nch; ++c) partsT[c].assign(irs[c], irs[c] + len[c]);
   Stage &A = s->A, &T = s->T;
   A.B = hb; A.logB = ilog2(hb); A.P = (int)pa; A.delay = 0; A.f64 = want64;
   A.mcap = s->max_len / hb + 2;
@@ -336,16 +342,16 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   RVC_CK(hipMalloc(&A.X, sizeof(float2) * (size_t)s->nch * A.rows * A.B));
   RVC_CK(hipMalloc(&A.Y, sizeof(float2) * (size_t)s->nch * A.mcap * A.B));
   if (pt > 0) {
-    T.B = tb; T.logB = ilog2(tb); T.P = (int)pt; T.delay = 2; T.f64 = want64;
+    T.B = tb; T.logB = ilog2(tb); T.P = (int)pt; T.PF = (int)pt + 2; T.delay = 2; T.f64 = want64;
     T.mcap = s->max_len / tb + 3;
-    T.rows = next_pow2(pt + 2 + T.mcap + 1);
+    T.rows = next_pow2(pt + 2 + T.mcap + 2);
     if (!make_twiddles(s, T)) return false;
     if (!upload_ir_stage(s, T, partsT)) return false;
     RVC_CK(hipMalloc(&T.X, sizeof(float2) * (size_t)s->nch * T.rows * T.B));
     RVC_CK(hipMalloc(&T.Y, sizeof(float2) * (size_t)s->nch * T.mcap * T.B));
   }
   const size_t span = std::max(hb, tb);
-  s->ring_cap = next_pow2(s->max_len + 4 * span);
+  s->ring_cap = next_pow2(s->max_len + 6 * span + 4 * hb);
   RVC_CK(hipMalloc(&s->xring, sizeof(float) * (size_t)s->nch * s->ring_cap));
   if (pt > 0) RVC_CK(hipMalloc(&s->tailring, sizeof(float) * (size_t)s->nch * s->ring_cap));
   RVC_CK(hipMalloc(&s->ypre, sizeof(float2) * (size_t)s->nch * A.B));
@@ -359,6 +365,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   s->n = 0;
   s->tail_fft_done = 0;
   s->tail_out_done = 2;
+  s->xa_next = 0;
   s->live = true;
   s->inited = true;
   return true;
@@ -385,33 +392,39 @@ struct Timer {   // brackets one launch with events when timing is on
   }
 };
 
-// Tail stage, one tail period ahead (TwoStageFFTConvolver.cpp:213-222, :247-250): transform the
-// tail blocks this call completed, run the tail delay line for every output block whose inputs
-// now exist, and put the result into the time-indexed tail ring. `src2` = the call's own input
-// when the ring does not hold it yet (long single-stream calls), else nullptr.
-bool run_tail_job(rvc_set *s, long long n0, long long n1, const float *src2, size_t in_stride, bool bg) {
+// ---- tail stage pieces -------------------------------------------------------------------
+// Spectra of the tail blocks a call ending at n1 completed. `src2` = the call's own input when
+// the ring does not hold it yet (long single-stream calls), else nullptr.
+// with_partial: also transform the block the call ends in (zero-padded beyond n1); it is transformed
+// again when it completes, exactly like a partly filled head block.
+bool tail_spectra(rvc_set *s, long long n0, long long n1, const float *src2, size_t in_stride, hipStream_t st,
+                  bool with_partial = false) {
   Stage &T = s->T;
   const long long tb = (long long)T.B;
   const long long mb0 = s->tail_fft_done, mb1 = n1 / tb;   // tail blocks [mb0, mb1) completed by this call
-  if (mb1 <= mb0) return true;
-  hipStream_t st = bg ? s->st_bg : s->st_main;
-  if (bg) {   // startBackgroundProcessing: the job may start once its input is in the ring
-    RVC_CK(hipEventRecord(s->ev_ingest, s->st_main));
-    RVC_CK(hipStreamWaitEvent(st, s->ev_ingest, 0));
-  }
+  const int extra = (with_partial && n1 % tb != 0) ? 1 : 0;
+  if (mb1 + extra <= mb0) return true;
   rvc::FwdArgs f{};
   f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
   f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
   f.seg0 = (mb0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
   f.tw = T.twp(); f.wsplit = T.wsp(); f.tw8 = T.t8p();
   f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = mb0; f.row_mask = T.rows - 1;
-  {
-    Timer t(s, 4, st);
-    RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(mb1 - mb0), s->nch, st));
-  }
-  const long long m_lo = s->tail_out_done, m_hi = mb1 + 2;   // output blocks whose inputs now exist
+  Timer t(s, 4, st);
+  RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(mb1 - mb0) + extra, s->nch, st));
+  if (mb1 > mb0) s->tail_fft_done = mb1;
+  return true;
+}
+
+// Tail contributions (IR[2T,..), delivered two tail blocks late) for output blocks
+// [tail_out_done, m_hi) into the time-indexed tail ring. Needs spectra of blocks < m_hi - 2.
+bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
+  Stage &T = s->T;
+  const long long tb = (long long)T.B;
+  const long long m_lo = s->tail_out_done;
+  if (m_hi <= m_lo) return true;
   rvc::FirArgs r{};
-  r.H = T.H; r.h_chan_stride = (long long)T.P * tb;
+  r.H = T.H + 2 * tb; r.h_chan_stride = (long long)T.PF * tb;       // partitions 2.. of the whole-IR table
   r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
   r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
   r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = 2; r.B = (int)tb;
@@ -429,10 +442,26 @@ bool run_tail_job(rvc_set *s, long long n0, long long n1, const float *src2, siz
     Timer t(s, 6, st);
     RVC_CK(rvc::launch_fft_inv(T.logB, T.f64, v, r.M, s->nch, st));
   }
-  s->tail_fft_done = mb1;
   s->tail_out_done = m_hi;
+  return true;
+}
+
+// The reference's background job (TwoStageFFTConvolver.cpp:213-222, :247-250), one tail period
+// ahead: when a call completes tail block(s), transform them and compute every tail contribution
+// whose inputs now exist. On the second stream when RVC_FLAG_BG_STREAM is set.
+bool run_tail_job(rvc_set *s, long long n0, long long n1, const float *src2, size_t in_stride, bool bg) {
+  const long long tb = (long long)s->T.B;
+  const long long mb1 = n1 / tb;
+  if (mb1 <= s->tail_fft_done) return true;
+  hipStream_t st = bg ? s->st_bg : s->st_main;
+  if (bg) {   // startBackgroundProcessing: the job may start once its input is in the ring
+    RVC_CK(hipEventRecord(s->ev_ingest, s->st_main));
+    RVC_CK(hipStreamWaitEvent(st, s->ev_ingest, 0));
+  }
+  if (!tail_spectra(s, n0, n1, src2, in_stride, st)) return false;
+  if (!tail_rows(s, mb1 + 2, st)) return false;
   if (bg) {
-    rvc_set::Job j{m_hi, get_event(s)};
+    rvc_set::Job j{mb1 + 2, get_event(s)};
     RVC_CK(hipEventRecord(j.ev, st));
     s->jobs.push_back(j);
   }
@@ -450,6 +479,69 @@ bool wait_tail_jobs(rvc_set *s, long long n1) {
     s->ev_pool.push_back(j.ev);
     if (j.m_hi > m_need) break;
   }
+  return true;
+}
+
+// ---- head stage pieces -------------------------------------------------------------------
+// Forward transforms of head blocks [k_lo, k_hi] (samples at or beyond n_hi read as zero: the
+// unplayed rest of a partly filled block).
+bool head_spectra(rvc_set *s, long long k_lo, long long k_hi, long long n_hi, const float *src2,
+                  size_t in_stride, long long src2_from) {
+  Stage &A = s->A;
+  const long long hb = (long long)A.B;
+  rvc::FwdArgs f{};
+  f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
+  f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = src2_from;
+  f.seg0 = (k_lo - 1) * hb; f.valid_len = (int)(2 * hb); f.lo = 0; f.hi = n_hi;
+  f.tw = A.twp(); f.wsplit = A.wsp(); f.tw8 = A.t8p();
+  f.dst = A.X; f.dst_chan_stride = (long long)A.rows * hb; f.row0 = k_lo; f.row_mask = A.rows - 1;
+  Timer t(s, 1, s->st_main);
+  RVC_CK(rvc::launch_fft_fwd(A.logB, A.f64, f, (int)(k_hi - k_lo + 1), s->nch, s->st_main));
+  return true;
+}
+
+// First head block a stage-A run starting at block ka must transform: ka itself when the delay
+// line is contiguous, else (the adaptive long-call path skipped blocks) P-1 blocks of history too.
+long long head_fft_from(const rvc_set *s, long long ka) {
+  if (ka <= s->xa_next) return ka;
+  const long long lo = ka - (long long)s->A.P + 1;
+  return lo < 0 ? 0 : lo;
+}
+
+// Zero-latency stage over samples [na, nb) of the current call (which starts at n0): FFT, delay
+// line, inverse FFT + tail ring -> d_out[na - n0 ..).
+bool head_stage(rvc_set *s, long long n0, long long na, long long nb, const float *src2, size_t in_stride,
+                float *d_out, size_t out_stride, bool bg) {
+  Stage &A = s->A, &T = s->T;
+  const bool has_tail = T.P > 0;
+  const long long hb = (long long)A.B;
+  const long long ka = na / hb, kb = (nb - 1) / hb;
+  const int M = (int)(kb - ka + 1);
+  if (!head_spectra(s, head_fft_from(s, ka), kb, nb, src2, in_stride, n0)) return false;
+  s->xa_next = (nb % hb == 0) ? kb + 1 : kb;
+  rvc::FirArgs r{};
+  r.H = A.H; r.h_chan_stride = (long long)A.P * hb;
+  r.X = A.X; r.x_chan_stride = (long long)A.rows * hb; r.x_row_mask = A.rows - 1;
+  r.Y = A.Y; r.y_chan_stride = (long long)A.mcap * hb;
+  r.k0 = ka; r.M = M; r.P = A.P; r.delay = 0; r.B = (int)hb;
+  {
+    Timer t(s, 2, s->st_main);
+    RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
+  }
+  if (has_tail) {
+    if (bg) { if (!wait_tail_jobs(s, nb)) return false; }
+    else if (!tail_rows(s, (nb - 1) / (long long)T.B + 1, s->st_main)) return false;   // lazily, if skipped
+  }
+  rvc::InvArgs v{};
+  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(); v.wsplit = A.wsp(); v.tw8 = A.t8p();
+  v.blk0 = ka;
+  v.dst = d_out + (na - n0); v.dst_chan_stride = (long long)out_stride; v.dst_origin = na; v.dst_mask = ~0ull;
+  v.lo = na; v.hi = nb;
+  v.add = has_tail ? s->tailring : nullptr;
+  v.add_chan_stride = (long long)s->ring_cap; v.add_mask = s->ring_cap - 1;
+  v.add_from = has_tail ? 2 * (long long)T.B : 0;
+  Timer t(s, 3, s->st_main);
+  RVC_CK(rvc::launch_fft_inv(A.logB, A.f64, v, M, s->nch, s->st_main));
   return true;
 }
 
@@ -481,7 +573,15 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
 
   // ---- latency path: the call stays inside one head block (the plugin's per-block call) ----
   if (k0 == k1 && rvc::fused_supported(A.logB, A.f64)) {
-    if (bg && !wait_tail_jobs(s, n1)) return false;
+    if (has_tail) {
+      if (bg) { if (!wait_tail_jobs(s, n1)) return false; }
+      else if (!tail_rows(s, (n1 - 1) / (long long)T.B + 1, s->st_main)) return false;
+    }
+    if (k0 > s->xa_next) {   // the long-call path skipped head blocks: rebuild the delay line's history
+      if (!head_spectra(s, head_fft_from(s, k0), k0 - 1, n0, nullptr, 0, 0)) return false;
+      s->xa_next = k0;
+      s->ypre_block = -1;
+    }
     if (s->ypre_block != k0 && !run_premultiply(s, k0)) return false;
     rvc::FusedArgs g{};
     g.in = d_in; g.in_chan_stride = (long long)in_stride;
@@ -499,6 +599,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       Timer t(s, 7, s->st_main);
       RVC_CK(rvc::launch_fused(A.logB, g, s->nch, s->st_main));
     }
+    s->xa_next = (n1 % hb == 0) ? k0 + 1 : k0;
     // off the latency path: the tail job if a tail block just completed, and the pre-multiplied
     // accumulator of the next block if this one is complete
     if (has_tail && !run_tail_job(s, n0, n1, nullptr, in_stride, bg)) return false;
@@ -510,9 +611,10 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   // ---- general path: any length ----
   // 1. ingest the call's input into the time ring. For a long call on a single stream the
   // transforms read the call's buffer directly (FwdArgs::src2) and only the history later calls
-  // can still need -- the last 2*max(h,T) samples -- is copied. (With the tail on the second
-  // stream the job may outlive the caller's buffer, so everything is copied; those calls are short.)
-  const long long keep = 2 * (long long)std::max(A.B, T.B);
+  // can still need is copied: 2 tail blocks for the tail transforms, P+2 head blocks for a
+  // rebuild of the head delay line. (With the tail on the second stream the job may outlive the
+  // caller's buffer, so everything is copied; those calls are short.)
+  const long long keep = 2 * (long long)std::max(A.B, T.B) + ((long long)A.P + 2) * hb;
   const bool fuse_in = !bg && (long long)len > keep;
   {
     rvc::IngestArgs a{};
@@ -525,42 +627,49 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   }
   const float *src2 = fuse_in ? d_in : nullptr;
 
-  if (has_tail && !run_tail_job(s, n0, n1, src2, in_stride, bg)) return false;   // 2. tail stage
+  // 2. adaptive partitioning for long calls. The result does not depend on the partition sizes,
+  // only the latency does -- and a call that hands over many tail blocks at once has no use for
+  // 512-sample latency inside them. A call touching >= 4 tail blocks is therefore produced
+  // entirely by ONE uniform delay line at block T over the whole IR (partitions 0..P_T+1,
+  // delay 0): transform the tail blocks it completes (plus the partly filled one it ends in),
+  // one FIR, one inverse transform windowed to [n0, n1). The head stage is not run at all; its
+  // state (delay-line history, tail-ring rows) is rebuilt lazily by the next short call.
+  if (has_tail && !bg && (s->flags & RVC_FLAG_FIXED_PARTITIONS) == 0) {
+    const long long tb = (long long)T.B;
+    const long long m_first = n0 / tb, m_last = (n1 - 1) / tb;
+    if (m_last - m_first >= 3) {
+      if (!tail_spectra(s, n0, n1, src2, in_stride, s->st_main, true)) return false;
+      rvc::FirArgs r{};
+      r.H = T.H; r.h_chan_stride = (long long)T.PF * tb;
+      r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
+      r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
+      r.k0 = m_first; r.M = (int)(m_last - m_first + 1); r.P = T.PF; r.delay = 0; r.B = (int)tb;
+      {
+        Timer t(s, 5, s->st_main);
+        RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
+      }
+      rvc::InvArgs v{};
+      v.Y = T.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp(); v.tw8 = T.t8p();
+      v.blk0 = m_first;
+      v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
+      v.lo = n0; v.hi = n1;
+      v.add = nullptr;
+      {
+        Timer t(s, 6, s->st_main);
+        RVC_CK(rvc::launch_fft_inv(T.logB, T.f64, v, r.M, s->nch, s->st_main));
+      }
+      // tail-ring rows of blocks delivered directly are never needed; the one the call ends in is
+      // computed lazily if a later short call continues inside it
+      const long long done = (n1 % tb == 0) ? m_last + 1 : m_last;
+      if (s->tail_out_done < done) s->tail_out_done = done;
+      s->n = n1;
+      return true;
+    }
+  }
 
-  // 3. zero-latency stage: blocks k0..k1 touched by this call
-  const int M = (int)(k1 - k0 + 1);
-  rvc::FwdArgs f{};
-  f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
-  f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
-  f.seg0 = (k0 - 1) * hb; f.valid_len = (int)(2 * hb); f.lo = 0; f.hi = n1;
-  f.tw = A.twp(); f.wsplit = A.wsp(); f.tw8 = A.t8p();
-  f.dst = A.X; f.dst_chan_stride = (long long)A.rows * hb; f.row0 = k0; f.row_mask = A.rows - 1;
-  {
-    Timer t(s, 1, s->st_main);
-    RVC_CK(rvc::launch_fft_fwd(A.logB, A.f64, f, M, s->nch, s->st_main));
-  }
-  rvc::FirArgs r{};
-  r.H = A.H; r.h_chan_stride = (long long)A.P * hb;
-  r.X = A.X; r.x_chan_stride = (long long)A.rows * hb; r.x_row_mask = A.rows - 1;
-  r.Y = A.Y; r.y_chan_stride = (long long)A.mcap * hb;
-  r.k0 = k0; r.M = M; r.P = A.P; r.delay = 0; r.B = (int)hb;
-  {
-    Timer t(s, 2, s->st_main);
-    RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
-  }
-  if (bg && !wait_tail_jobs(s, n1)) return false;
-  rvc::InvArgs v{};
-  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(); v.wsplit = A.wsp(); v.tw8 = A.t8p();
-  v.blk0 = k0;
-  v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
-  v.lo = n0; v.hi = n1;
-  v.add = has_tail ? s->tailring : nullptr;
-  v.add_chan_stride = (long long)s->ring_cap; v.add_mask = s->ring_cap - 1;
-  v.add_from = has_tail ? 2 * (long long)T.B : 0;
-  {
-    Timer t(s, 3, s->st_main);
-    RVC_CK(rvc::launch_fft_inv(A.logB, A.f64, v, M, s->nch, s->st_main));
-  }
+  // 3. two-stage path: tail job one period ahead, then the zero-latency stage over the whole call
+  if (has_tail && !run_tail_job(s, n0, n1, src2, in_stride, bg)) return false;
+  if (!head_stage(s, n0, n0, n1, src2, in_stride, d_out, out_stride, bg)) return false;
   s->n = n1;
   return true;
 }
@@ -681,6 +790,7 @@ void rvc_set_clear(rvc_set *s) {
   s->tail_fft_done = 0;
   s->tail_out_done = 2;
   s->ypre_block = -1;
+  s->xa_next = 0;
 }
 
 void rvc_set_reset(rvc_set *s) {

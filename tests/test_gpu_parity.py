@@ -310,3 +310,33 @@ def test_handles_are_independent_across_threads():
     assert not errors, errors
     for c in range(2):
         assert rel_rms(got[c], want[c]) <= TOL
+
+
+@pytest.mark.parametrize("fixed", [False, True])
+def test_mixed_long_and_short_calls_hand_state_over(fixed):
+    """Adaptive partitioning: a long call is served by one uniform delay line at the tail block
+    size and leaves the head stage's state (delay-line history, tail-ring rows, pre-multiplied
+    accumulator) stale; the next short call must rebuild it lazily. Any interleaving of long,
+    block-sized and ragged calls has to give the reference's stream."""
+    ir = synth.synth_ir(60000, 2, 50)
+    sched = [512] * 3 + [70000] + [512] * 40 + [37, 475, 512, 300] + [8192 * 5] + [100] + [512] * 20 + \
+            [8192 * 4 + 5] + [8187] + [512] * 33 + [90001] + [511, 1] + [512] * 17
+    total = sum(sched)
+    x = np.stack([synth.synth_input(total, c) for c in range(2)])
+    s = reevr_amd.ConvolverSet(2, fixed_partitions=fixed)
+    assert s.init(512, 8192, list(ir), max_len=max(sched))
+    got = []
+    pos = 0
+    for n in sched:
+        got.append(s.process(x[:, pos:pos + n]))
+        pos += n
+    got = np.concatenate(got, axis=1)
+    assert s.last_error == 0, s.last_error_string
+    for c in range(2):
+        o = O.TwoStageFFTConvolver("orc"); assert o.init(512, 8192, ir[c])
+        want = o.process(x[c])
+        assert rel_rms(got[c], want) <= TOL
+        # and no region is worse than the rest (a stale-state bug would be local)
+        for a in range(0, total - 4096, 4096):
+            seg = slice(a, a + 4096)
+            assert np.sqrt(np.mean((got[c, seg].astype(np.float64) - want[seg]) ** 2)) <= 5e-6
