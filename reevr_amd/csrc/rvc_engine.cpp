@@ -398,7 +398,7 @@ struct Timer {   // brackets one launch with events when timing is on
 // with_partial: also transform the block the call ends in (zero-padded beyond n1); it is transformed
 // again when it completes, exactly like a partly filled head block.
 bool tail_spectra(rvc_set *s, long long n0, long long n1, const float *src2, size_t in_stride, hipStream_t st,
-                  bool with_partial = false) {
+                  bool with_partial = false, long long ring_from = -1) {
   Stage &T = s->T;
   const long long tb = (long long)T.B;
   const long long mb0 = s->tail_fft_done, mb1 = n1 / tb;   // tail blocks [mb0, mb1) completed by this call
@@ -410,6 +410,10 @@ bool tail_spectra(rvc_set *s, long long n0, long long n1, const float *src2, siz
   f.seg0 = (mb0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
   f.tw = T.twp(); f.wsplit = T.wsp(); f.tw8 = T.t8p();
   f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = mb0; f.row_mask = T.rows - 1;
+  if (ring_from >= 0) {   // the transform kernel also appends the call's recent samples to the time ring
+    f.ring_out = s->xring; f.ring_out_chan_stride = (long long)s->ring_cap; f.ring_out_mask = s->ring_cap - 1;
+    f.ring_out_from = ring_from;
+  }
   Timer t(s, 4, st);
   RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(mb1 - mb0) + extra, s->nch, st));
   if (mb1 > mb0) s->tail_fft_done = mb1;
@@ -427,7 +431,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
   r.H = T.H + 2 * tb; r.h_chan_stride = (long long)T.PF * tb;       // partitions 2.. of the whole-IR table
   r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
   r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
-  r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = 2; r.B = (int)tb;
+  r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = 2; r.B = (int)tb; r.tag = 1;
   {
     Timer t(s, 5, st);
     RVC_CK(rvc::launch_fir(r, s->nch, st));
@@ -616,7 +620,12 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   // caller's buffer, so everything is copied; those calls are short.)
   const long long keep = 2 * (long long)std::max(A.B, T.B) + ((long long)A.P + 2) * hb;
   const bool fuse_in = !bg && (long long)len > keep;
-  {
+  // (the adaptive long-call path below lets its forward transform append the history: no ingest launch)
+  const long long tbq = has_tail ? (long long)T.B : 1;
+  const bool adaptive = has_tail && !bg && (s->flags & RVC_FLAG_FIXED_PARTITIONS) == 0 &&
+                        ((n1 - 1) / tbq - n0 / tbq) >= 3;
+  const bool fft_ingests = adaptive && fuse_in && rvc::fwd_appends_ring(T.logB) && (n0 / tbq) >= s->tail_fft_done;
+  if (!fft_ingests) {
     rvc::IngestArgs a{};
     const long long skip = fuse_in ? (long long)len - keep : 0;
     a.src = d_in + skip; a.src_chan_stride = (long long)in_stride;
@@ -634,16 +643,16 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   // delay 0): transform the tail blocks it completes (plus the partly filled one it ends in),
   // one FIR, one inverse transform windowed to [n0, n1). The head stage is not run at all; its
   // state (delay-line history, tail-ring rows) is rebuilt lazily by the next short call.
-  if (has_tail && !bg && (s->flags & RVC_FLAG_FIXED_PARTITIONS) == 0) {
+  if (adaptive) {
     const long long tb = (long long)T.B;
     const long long m_first = n0 / tb, m_last = (n1 - 1) / tb;
-    if (m_last - m_first >= 3) {
-      if (!tail_spectra(s, n0, n1, src2, in_stride, s->st_main, true)) return false;
+    {
+      if (!tail_spectra(s, n0, n1, src2, in_stride, s->st_main, true, fft_ingests ? n1 - keep : -1)) return false;
       rvc::FirArgs r{};
       r.H = T.H; r.h_chan_stride = (long long)T.PF * tb;
       r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
       r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
-      r.k0 = m_first; r.M = (int)(m_last - m_first + 1); r.P = T.PF; r.delay = 0; r.B = (int)tb;
+      r.k0 = m_first; r.M = (int)(m_last - m_first + 1); r.P = T.PF; r.delay = 0; r.B = (int)tb; r.tag = 2;
       {
         Timer t(s, 5, s->st_main);
         RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));

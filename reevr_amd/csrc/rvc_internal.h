@@ -23,6 +23,10 @@ struct FwdArgs {            // real time-domain segment(s) -> spectrum row(s)
   const float *src2;        // optional second source: the current call's input, [channel][len]; samples
   long long src2_chan_stride;   // n >= src2_from are read from src2[n - src2_from] instead of the ring
   long long src2_from;      // (saves the ingest copy of long calls); nullptr = ring only
+  float *ring_out;          // optional (radix-8 kernels only): every block's own B samples with index
+  long long ring_out_chan_stride;   // >= ring_out_from (and < hi) are also appended to this time ring
+  unsigned long long ring_out_mask; // -- the history later calls need -- so that a long call needs no
+  long long ring_out_from;  // separate ingest launch
   long long seg0;           // absolute start of row 0's 2B-sample segment
   int valid_len;            // samples at the start of the segment that may be non-zero (2B: overlap-save
                             // input segment, B: zero-padded IR partition)
@@ -49,6 +53,8 @@ struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency
   int P;                    // partitions
   int delay;                // 0 for the zero-latency stage, 2 for the tail stage
   int B;
+  int tag;                  // names the kernel instantiation for profilers: 0 head stage, 1 tail stage
+                            // (delay 2), 2 whole-IR delay line of the adaptive long-call path
 };
 
 struct InvArgs {            // spectrum row(s) -> last B samples of the inverse transform (overlap-save)
@@ -112,6 +118,8 @@ struct IngestArgs {
 hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int channels, hipStream_t st);
 hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int channels, hipStream_t st);
 hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st);
+// whether launch_fft_fwd honours FwdArgs::ring_out for this block size / precision
+bool fwd_appends_ring(int logB);
 // fused single-block step; supported for 9 <= logB <= 13 (float transforms only)
 bool fused_supported(int logB, bool f64);
 hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t st);

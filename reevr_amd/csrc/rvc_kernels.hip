@@ -445,13 +445,18 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
   const bool whole = (a.valid_len == 2 * B) && seg >= a.lo && seg + 2 * B <= a.hi;
   // with a second source the 8-byte loads need it even-aligned relative to the sample clock
   const bool s2ok = !src2 || (((a.src2_from & 1) == 0) && ((reinterpret_cast<uintptr_t>(src2) & 7u) == 0));
+  float *ring_out = a.ring_out ? a.ring_out + (long long)c * a.ring_out_chan_stride : nullptr;
   if (whole && s2ok) {
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
-      const long long n = seg + 2 * P::in_idx(tid, e);
+      const int m = P::in_idx(tid, e);
+      const long long n = seg + 2 * m;
       const float *p = (src2 && n >= a.src2_from) ? src2 + (n - a.src2_from) : src + ((unsigned long long)n & a.src_mask);
       const float2 x = *reinterpret_cast<const float2 *>(p);
       v[e] = mk<R>((R)x.x, (R)x.y);
+      // second half of the segment = this block's own samples: keep the recent ones as history
+      if (ring_out && m >= B / 2 && n >= a.ring_out_from)
+        *reinterpret_cast<float2 *>(ring_out + ((unsigned long long)n & a.ring_out_mask)) = x;
     }
   } else {
 #pragma unroll
@@ -462,6 +467,10 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
       if (q < a.valid_len && n0 >= a.lo && n0 < a.hi) v0 = load_sample(a, src, src2, n0);
       if (q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi) v1 = load_sample(a, src, src2, n1);
       v[e] = mk<R>((R)v0, (R)v1);
+      if (ring_out && q >= B) {
+        if (n0 >= a.ring_out_from && n0 >= a.lo && n0 < a.hi) ring_out[(unsigned long long)n0 & a.ring_out_mask] = v0;
+        if (n1 >= a.ring_out_from && n1 >= a.lo && n1 < a.hi) ring_out[(unsigned long long)n1 & a.ring_out_mask] = v1;
+      }
     }
   }
   C ws[P::E];                                   // split twiddles: requested before the transform when
@@ -1084,6 +1093,8 @@ hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int ch
   }
 }
 
+bool fwd_appends_ring(int logB) { return logB >= 9; }
+
 bool fused_supported(int logB, bool f64) { return !f64 && logB >= 9 && logB <= 13; }
 
 template <int LOGB>
@@ -1110,13 +1121,14 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   if (a.M <= 0 || channels <= 0 || a.P <= 0) return hipSuccess;
   if (a.M >= 16 && (a.B % 64) == 0) {     // long call: LDS-staged, 64 rows x 64 bins per workgroup
     const dim3 grid(a.B / 64, (a.M + 63) / 64, channels), block(256);
-    if (a.delay == 0) hipLaunchKernelGGL((k_fir_lds<0>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_fir_lds<1>), grid, block, 0, st, a);
+    if (a.tag == 0) hipLaunchKernelGGL((k_fir_lds<0>), grid, block, 0, st, a);
+    else if (a.tag == 1) hipLaunchKernelGGL((k_fir_lds<1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_fir_lds<2>), grid, block, 0, st, a);
     return hipGetLastError();
   }
   if (a.M == 1) {                         // one block: the latency-oriented row kernel
     const dim3 grid((a.B + 63) / 64, channels), block(256);
-    if (a.delay == 0) hipLaunchKernelGGL((k_fir_row<0>), grid, block, 0, st, a);
+    if (a.tag == 0) hipLaunchKernelGGL((k_fir_row<0>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_fir_row<1>), grid, block, 0, st, a);
     return hipGetLastError();
   }
@@ -1125,7 +1137,7 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   const dim3 grid((a.B + 63) / 64, (tiles + 3) / 4, channels), block(256);
 #define RVC_FIR_CASE(TKV)                                                             \
   case TKV:                                                                           \
-    if (a.delay == 0) hipLaunchKernelGGL((k_fir<TKV, 0>), grid, block, 0, st, a);     \
+    if (a.tag == 0) hipLaunchKernelGGL((k_fir<TKV, 0>), grid, block, 0, st, a);       \
     else hipLaunchKernelGGL((k_fir<TKV, 1>), grid, block, 0, st, a);                  \
     break;
   switch (tk) {
@@ -1134,7 +1146,7 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
     RVC_FIR_CASE(4)
     RVC_FIR_CASE(2)
     default:
-      if (a.delay == 0) hipLaunchKernelGGL((k_fir<1, 0>), grid, block, 0, st, a);
+      if (a.tag == 0) hipLaunchKernelGGL((k_fir<1, 0>), grid, block, 0, st, a);
       else hipLaunchKernelGGL((k_fir<1, 1>), grid, block, 0, st, a);
       break;
   }

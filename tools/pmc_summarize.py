@@ -19,7 +19,7 @@ import re
 def family(name: str, head_log: int, tail_log: int):
     m = re.search(r"k_fir(?:_lds|_row)?<(?:\d+, )?(\d)>", name)
     if m:
-        return "fir_head" if m.group(1) == "0" else "fir_tail"
+        return "fir_head" if m.group(1) == "0" else "fir_tail"   # <1> tail stage, <2> whole-IR line (timed as fir_tail)
     m = re.search(r"k_fft8?_(fwd|inv)<(\d+), float>", name)
     if m:
         lg = int(m.group(2))
