@@ -385,10 +385,10 @@ hipEvent_t get_event(rvc_set *s) {
 struct Timer {   // brackets one launch with events when timing is on
   rvc_set *s; int id; hipStream_t st; TimedLaunch t{}; bool on;
   Timer(rvc_set *s_, int id_, hipStream_t st_) : s(s_), id(id_), st(st_), on(s_->timing) {
-    if (on) { hipEventCreate(&t.a); hipEventCreate(&t.b); hipEventRecord(t.a, st); }
+    if (on) { hipEventCreate(&t.a); hipEventCreate(&t.b); rvc::set_launch_events(t.a, t.b); }
   }
   ~Timer() {
-    if (on) { hipEventRecord(t.b, st); s->timed[id].push_back(t); }
+    if (on) { rvc::set_launch_events(nullptr, nullptr); s->timed[id].push_back(t); }
   }
 };
 
@@ -684,8 +684,12 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
 }
 
 bool zero_device_out(rvc_set *s, float *d_out, size_t out_stride, size_t len) {
-  if (!s->streams_ok || len == 0) return true;
-  RVC_CK(hipMemset2DAsync(d_out, out_stride * sizeof(float), 0, len * sizeof(float), (size_t)s->nch, s->st_main));
+  if (len == 0 || !d_out) return true;
+  if (s->streams_ok) {
+    RVC_CK(hipMemset2DAsync(d_out, out_stride * sizeof(float), 0, len * sizeof(float), (size_t)s->nch, s->st_main));
+  } else if (hipSetDevice(s->device) == hipSuccess) {   // never initialised with a non-empty IR: no stream yet
+    (void)hipMemset2D(d_out, out_stride * sizeof(float), 0, len * sizeof(float), (size_t)s->nch);
+  }
   return true;
 }
 

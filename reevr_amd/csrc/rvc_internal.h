@@ -124,6 +124,8 @@ bool fwd_appends_ring(int logB);
 bool fused_supported(int logB, bool f64);
 hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t st);
 hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st);
+// arm (a, b) / disarm (nullptr, nullptr) kernel-exact timing events for the next launch on this thread
+void set_launch_events(hipEvent_t a, hipEvent_t b);
 // one-off: raise the dynamic-LDS limit of the large FFT kernels
 hipError_t prepare_kernels();
 

@@ -20,9 +20,23 @@
 //    is loaded is used TK times (time tiling; TK = 1 is the streaming case).
 #include "rvc_internal.h"
 
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 namespace rvc {
+
+// Optional per-launch timing: when a pair of events is armed (set_launch_events), the next launch
+// goes through hipExtLaunchKernelGGL, which stamps them at the kernel's own start and end -- the
+// same interval a profiler reports, without marker packets between kernels.
+static thread_local hipEvent_t t_ev_a = nullptr, t_ev_b = nullptr;
+void set_launch_events(hipEvent_t a, hipEvent_t b) { t_ev_a = a; t_ev_b = b; }
+#define RVC_LAUNCH(kernel, grid, block, lds, st, ...)                                              \
+  do {                                                                                             \
+    if (t_ev_a) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, t_ev_a, t_ev_b, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                            \
+  } while (0)
+
 
 // ----------------------------------------------------------------------------------------
 // complex helpers
@@ -1022,10 +1036,10 @@ template <int LOGB, typename R>
 static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStream_t st) {
   if constexpr (LOGB >= 9) {
     const size_t lds = sizeof(cx<R>) * Plan8<LOGB>::LDS_ELEMS;
-    hipLaunchKernelGGL((k_fft8_fwd<LOGB, R>), dim3(rows, channels), dim3(Plan8<LOGB>::NT), lds, st, a);
+    RVC_LAUNCH((k_fft8_fwd<LOGB, R>), dim3(rows, channels), dim3(Plan8<LOGB>::NT), lds, st, a);
   } else {
     const size_t lds = sizeof(cx<R>) << LOGB;
-    hipLaunchKernelGGL((k_fft_fwd<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
+    RVC_LAUNCH((k_fft_fwd<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
   }
   return hipGetLastError();
 }
@@ -1033,10 +1047,10 @@ template <int LOGB, typename R>
 static hipError_t launch_inv_t(const InvArgs &a, int rows, int channels, hipStream_t st) {
   if constexpr (LOGB >= 9) {
     const size_t lds = sizeof(cx<R>) * Plan8<LOGB>::LDS_ELEMS;
-    hipLaunchKernelGGL((k_fft8_inv<LOGB, R>), dim3(rows, channels), dim3(Plan8<LOGB>::NT), lds, st, a);
+    RVC_LAUNCH((k_fft8_inv<LOGB, R>), dim3(rows, channels), dim3(Plan8<LOGB>::NT), lds, st, a);
   } else {
     const size_t lds = sizeof(cx<R>) << LOGB;
-    hipLaunchKernelGGL((k_fft_inv<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
+    RVC_LAUNCH((k_fft_inv<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
   }
   return hipGetLastError();
 }
@@ -1100,7 +1114,7 @@ bool fused_supported(int logB, bool f64) { return !f64 && logB >= 9 && logB <= 1
 template <int LOGB>
 static hipError_t launch_fused_t(const FusedArgs &a, int channels, hipStream_t st) {
   const size_t lds = sizeof(cx<float>) * Plan8<LOGB>::LDS_ELEMS;
-  hipLaunchKernelGGL((k_fused_block<LOGB>), dim3(channels), dim3(Plan8<LOGB>::NT), lds, st, a);
+  RVC_LAUNCH((k_fused_block<LOGB>), dim3(channels), dim3(Plan8<LOGB>::NT), lds, st, a);
   return hipGetLastError();
 }
 
@@ -1121,15 +1135,15 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   if (a.M <= 0 || channels <= 0 || a.P <= 0) return hipSuccess;
   if (a.M >= 16 && (a.B % 64) == 0) {     // long call: LDS-staged, 64 rows x 64 bins per workgroup
     const dim3 grid(a.B / 64, (a.M + 63) / 64, channels), block(256);
-    if (a.tag == 0) hipLaunchKernelGGL((k_fir_lds<0>), grid, block, 0, st, a);
-    else if (a.tag == 1) hipLaunchKernelGGL((k_fir_lds<1>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_fir_lds<2>), grid, block, 0, st, a);
+    if (a.tag == 0) RVC_LAUNCH((k_fir_lds<0>), grid, block, 0, st, a);
+    else if (a.tag == 1) RVC_LAUNCH((k_fir_lds<1>), grid, block, 0, st, a);
+    else RVC_LAUNCH((k_fir_lds<2>), grid, block, 0, st, a);
     return hipGetLastError();
   }
   if (a.M == 1) {                         // one block: the latency-oriented row kernel
     const dim3 grid((a.B + 63) / 64, channels), block(256);
-    if (a.tag == 0) hipLaunchKernelGGL((k_fir_row<0>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_fir_row<1>), grid, block, 0, st, a);
+    if (a.tag == 0) RVC_LAUNCH((k_fir_row<0>), grid, block, 0, st, a);
+    else RVC_LAUNCH((k_fir_row<1>), grid, block, 0, st, a);
     return hipGetLastError();
   }
   const int tk = fir_time_tile(a.M);
@@ -1137,8 +1151,8 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   const dim3 grid((a.B + 63) / 64, (tiles + 3) / 4, channels), block(256);
 #define RVC_FIR_CASE(TKV)                                                             \
   case TKV:                                                                           \
-    if (a.tag == 0) hipLaunchKernelGGL((k_fir<TKV, 0>), grid, block, 0, st, a);       \
-    else hipLaunchKernelGGL((k_fir<TKV, 1>), grid, block, 0, st, a);                  \
+    if (a.tag == 0) RVC_LAUNCH((k_fir<TKV, 0>), grid, block, 0, st, a);       \
+    else RVC_LAUNCH((k_fir<TKV, 1>), grid, block, 0, st, a);                  \
     break;
   switch (tk) {
     RVC_FIR_CASE(16)
@@ -1146,8 +1160,8 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
     RVC_FIR_CASE(4)
     RVC_FIR_CASE(2)
     default:
-      if (a.tag == 0) hipLaunchKernelGGL((k_fir<1, 0>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((k_fir<1, 1>), grid, block, 0, st, a);
+      if (a.tag == 0) RVC_LAUNCH((k_fir<1, 0>), grid, block, 0, st, a);
+      else RVC_LAUNCH((k_fir<1, 1>), grid, block, 0, st, a);
       break;
   }
 #undef RVC_FIR_CASE
@@ -1158,7 +1172,7 @@ hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st) {
   if (a.len <= 0 || channels <= 0) return hipSuccess;
   long long blocks = (a.len + 1023) / 1024;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_ingest, dim3((unsigned)blocks, channels), dim3(256), 0, st, a);
+  RVC_LAUNCH(k_ingest, dim3((unsigned)blocks, channels), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -340,3 +340,20 @@ def test_mixed_long_and_short_calls_hand_state_over(fixed):
         for a in range(0, total - 4096, 4096):
             seg = slice(a, a + 4096)
             assert np.sqrt(np.mean((got[c, seg].astype(np.float64) - want[seg]) ** 2)) <= 5e-6
+
+
+def test_device_entry_zeros_before_init_and_with_empty_ir():
+    """process before init / with an all-zero IR writes zeros (FFTConvolver.cpp:157-161) -- also
+    through the device-pointer entry, which has no stream yet at that point."""
+    import torch
+    x = torch.ones(2, 700, device="cuda")
+    y = torch.full((2, 700), 3.0, device="cuda")
+    s = reevr_amd.ConvolverSet(2)
+    s.process_device(x, y)
+    torch.cuda.synchronize()
+    assert float(y.abs().max()) == 0.0
+    y.fill_(3.0)
+    assert s.init(64, 256, [np.zeros(10, np.float32)] * 2)
+    s.process_device(x, y)
+    torch.cuda.synchronize()
+    assert float(y.abs().max()) == 0.0
