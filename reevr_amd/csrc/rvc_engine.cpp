@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -647,26 +648,51 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     const long long tb = (long long)T.B;
     const long long m_first = n0 / tb, m_last = (n1 - 1) / tb;
     {
-      if (!tail_spectra(s, n0, n1, src2, in_stride, s->st_main, true, fft_ingests ? n1 - keep : -1)) return false;
-      rvc::FirArgs r{};
-      r.H = T.H; r.h_chan_stride = (long long)T.PF * tb;
-      r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
-      r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
-      r.k0 = m_first; r.M = (int)(m_last - m_first + 1); r.P = T.PF; r.delay = 0; r.B = (int)tb; r.tag = 2;
-      {
-        Timer t(s, 5, s->st_main);
-        RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
-      }
-      rvc::InvArgs v{};
-      v.Y = T.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp(); v.tw8 = T.t8p();
-      v.blk0 = m_first;
-      v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
-      v.lo = n0; v.hi = n1;
-      v.add = nullptr;
-      {
+      const long long ring_from = fft_ingests ? n1 - keep : -1;
+      const long long mb0 = s->tail_fft_done, mb1 = n1 / tb;
+      const int extra = (n1 % tb != 0) ? 1 : 0;       // the partly filled block the call ends in
+      // (A two-way pipeline over block time -- second half's transforms on the side stream under the
+      // first half's delay line -- was measured and lost 35 %: each half-size launch keeps ~8 us of
+      // fixed cost. One launch per stage it is.)
+      auto fwd = [&](long long r0, long long r1, hipStream_t st) -> bool {   // transforms of rows [r0, r1)
+        if (r1 <= r0) return true;
+        rvc::FwdArgs f{};
+        f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
+        f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
+        f.seg0 = (r0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
+        f.tw = T.twp(); f.wsplit = T.wsp(); f.tw8 = T.t8p();
+        f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = r0; f.row_mask = T.rows - 1;
+        if (ring_from >= 0) {
+          f.ring_out = s->xring; f.ring_out_chan_stride = (long long)s->ring_cap; f.ring_out_mask = s->ring_cap - 1;
+          f.ring_out_from = ring_from;
+        }
+        Timer t(s, 4, st);
+        RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(r1 - r0), s->nch, st));
+        return true;
+      };
+      auto fir_inv = [&](long long r0, long long r1) -> bool {               // output rows [r0, r1)
+        rvc::FirArgs r{};
+        r.H = T.H; r.h_chan_stride = (long long)T.PF * tb;
+        r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
+        r.Y = T.Y + (r0 - m_first) * tb; r.y_chan_stride = (long long)T.mcap * tb;
+        r.k0 = r0; r.M = (int)(r1 - r0); r.P = T.PF; r.delay = 0; r.B = (int)tb; r.tag = 2;
+        {
+          Timer t(s, 5, s->st_main);
+          RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
+        }
+        rvc::InvArgs v{};
+        v.Y = r.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp(); v.tw8 = T.t8p();
+        v.blk0 = r0;
+        v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
+        v.lo = n0; v.hi = n1;
+        v.add = nullptr;
         Timer t(s, 6, s->st_main);
         RVC_CK(rvc::launch_fft_inv(T.logB, T.f64, v, r.M, s->nch, s->st_main));
-      }
+        return true;
+      };
+      if (!fwd(mb0, mb1 + extra, s->st_main)) return false;
+      if (!fir_inv(m_first, m_last + 1)) return false;
+      if (mb1 > mb0) s->tail_fft_done = mb1;
       // tail-ring rows of blocks delivered directly are never needed; the one the call ends in is
       // computed lazily if a later short call continues inside it
       const long long done = (n1 % tb == 0) ? m_last + 1 : m_last;

@@ -877,6 +877,7 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
     const int ii = i < P ? i : P - 1;
     return *reinterpret_cast<const float4 *>(Hc + (long long)ii * B + lc);
   };
+  auto stageH = [&](float2 (*dst)[64], const float4 h) { *reinterpret_cast<float4 *>(&dst[lr][lc]) = h; };
   auto sXrow = [&](long long row) -> float2 * { return &sX[(int)((unsigned long long)row & (RING - 1))][0]; };
 
   // prologue. Register window of wave w = rows cbase .. cbase+15 (from global, one 8-byte load
@@ -902,36 +903,38 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
     for (int t = 0; t < TK; ++t) sXrow(cbase + t)[lane] = w[t];
   }
   *reinterpret_cast<float4 *>(sXrow(R0 - 1 - lr) + lc) = px[0];
-  *reinterpret_cast<float4 *>(&sH[0][lr][lc]) = phv[0];
+  stageH(sH[0], phv[0]);
   __syncthreads();
 
   // one chunk = 8 steps; PH = chunk parity: selects which half of the 16-slot register window
-  // rotates and which in-flight register set is which. Operands are requested TWO chunks
-  // (16 steps) ahead: chunk j requests chunk j+2 into set PH and, at its end, stages chunk j+1
-  // (requested one chunk earlier, set PH^1) into LDS.
+  // rotates, which in-flight register set is which and which sH buffer is current (all compile
+  // time). Operands are requested TWO chunks (16 steps) ahead: chunk j requests chunk j+2 into
+  // set PH and, at its end, stages chunk j+1 (requested one chunk earlier, set PH^1) into LDS.
+  // (A select-free copy of the loop for the workgroups that do not hold the packed bin 0 was
+  // tried: two copies of the unrolled loop spill 29 VGPRs and lose 25 %. Two selects per step stay.)
   auto chunk = [&](const int j, auto ph_tag) {
     constexpr int PH = decltype(ph_tag)::value;
-    const int buf = j & 1;
     if (j + 2 < nchunks) {                                // uniform
       px[PH] = gX(R0 - (long long)(j + 2) * CH - 1 - lr);
       phv[PH] = gH((j + 2) * CH + lr);
     }
     auto step = [&](const int i, const int u, const int u16) {
 #ifdef RVC_ABLATE_NOLDSREAD
-      const float2 h = make_float2(1.f + i, 0.5f), xin = make_float2(0.25f * u, 1.f);
+      const float4 h = make_float4(1.f + i, 1.f + i, 0.5f, 0.f);
+      const float2 xin = make_float2(0.25f * u, 1.f);
 #else
-      const float2 h = sH[buf][u][lane];
+      const float2 hh = sH[PH][u][lane];
       const float2 xin = sXrow(cbase - i - 1)[lane];
+      // (h.re, h3, hz): ordinary bin (re, re, im); packed bin 0 (DC gain, Nyquist gain, 0)
+      const float4 h = make_float4(hh.x, packed ? hh.y : hh.x, packed ? 0.f : hh.y, 0.f);
 #endif
-      const float hz = packed ? 0.f : h.y;
-      const float h3 = packed ? h.y : h.x;
 #pragma unroll
       for (int t = 0; t < TK; ++t) {
         const float2 x = w[(t - u16) & (TK - 1)];
         acc[t].x = fmaf(h.x, x.x, acc[t].x);
-        acc[t].x = fmaf(-hz, x.y, acc[t].x);
-        acc[t].y = fmaf(h3, x.y, acc[t].y);
-        acc[t].y = fmaf(hz, x.x, acc[t].y);
+        acc[t].y = fmaf(h.y, x.y, acc[t].y);
+        acc[t].x = fmaf(-h.z, x.y, acc[t].x);
+        acc[t].y = fmaf(h.z, x.x, acc[t].y);
       }
       w[(TK - 1 - u16) & (TK - 1)] = xin;                 // zero for rows < 0 was applied when staged
     };
@@ -942,9 +945,9 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
       // ONE barrier per chunk. The slots written here are free without a barrier in front:
       //  * ring: rows of chunk j+1 land on the slots of rows R0+48-8j .. R0+55-8j, above every
       //    row any wave reads in chunk j (<= R0+47-8j);
-      //  * sH[buf^1] was last read in chunk j-1, which every wave left before the previous barrier.
+      //  * sH[PH^1] was last read in chunk j-1, which every wave left before the previous barrier.
       *reinterpret_cast<float4 *>(sXrow(R0 - (long long)(j + 1) * CH - 1 - lr) + lc) = px[PH ^ 1];
-      *reinterpret_cast<float4 *>(&sH[buf ^ 1][lr][lc]) = phv[PH ^ 1];
+      stageH(sH[PH ^ 1], phv[PH ^ 1]);
       __syncthreads();
     }
   };
