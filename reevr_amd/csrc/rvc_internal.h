@@ -38,6 +38,7 @@ struct FwdArgs {            // real time-domain segment(s) -> spectrum row(s)
   long long dst_chan_stride;
   long long row0;           // absolute row index of row 0
   unsigned long long row_mask;   // row slot = (row0 + r) & row_mask
+  int rows;                 // set by the launcher (several small transforms share a workgroup)
 };
 
 struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency-domain delay line)
@@ -73,6 +74,7 @@ struct InvArgs {            // spectrum row(s) -> last B samples of the inverse 
   long long add_chan_stride;
   unsigned long long add_mask;
   long long add_from;       // add applies for n >= add_from
+  int rows;                 // set by the launcher
 };
 
 // One head block per call (the plugin's per-block process()): ingest + forward transform +
@@ -101,6 +103,7 @@ struct FusedArgs {
   long long add_chan_stride;
   unsigned long long add_mask;
   long long add_from;
+  int channels;             // set by the launcher
 };
 
 struct IngestArgs {
@@ -120,7 +123,7 @@ hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int ch
 hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st);
 // whether launch_fft_fwd honours FwdArgs::ring_out for this block size / precision
 bool fwd_appends_ring(int logB);
-// fused single-block step; supported for 9 <= logB <= 13 (float transforms only)
+// fused single-block step; supported for 6 <= logB <= 13 (float transforms only)
 bool fused_supported(int logB, bool f64);
 hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t st);
 hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st);

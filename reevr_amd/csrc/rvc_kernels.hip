@@ -263,6 +263,8 @@ template <int LOGB> struct Plan8 {
   static constexpr int Q = 1 << (LOGB % 3);       // final pass radix: 1 (none), 2 or 4
   static constexpr int S = (LOGB >= 14) ? 2 : 1;  // radix-8 butterflies per thread
   static constexpr int NT = B / (8 * S);          // threads per transform
+  static constexpr int TPW = NT < 64 ? 64 / NT : 1;   // transforms per workgroup (B < 512: several share a wave)
+  static constexpr int WG = NT * TPW;             // workgroup size
   static constexpr int E = 8 * S;                 // complex values per thread
   static constexpr int T = B / 8;                 // stride between the legs of a radix-8 butterfly
   static constexpr int LDS_ELEMS = B + B / 16;    // padded
@@ -436,14 +438,15 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
 }
 
 template <int LOGB, typename R>
-__global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
+__global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  C *lds = reinterpret_cast<C *>(smem_raw);
   constexpr int B = P::B;
-  const int tid = threadIdx.x;
-  const int r_ = blockIdx.x, c = blockIdx.y;
+  const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;   // sub-transform of this workgroup
+  C *lds = reinterpret_cast<C *>(smem_raw) + sub * P::LDS_ELEMS;
+  const int r_ = blockIdx.x * P::TPW + sub, c = blockIdx.y;
+  const bool live = r_ < a.rows;      // a dead sub-transform computes on zeros and stores nothing
   const float *src = a.src + (long long)c * a.src_chan_stride;
   const float *src2 = a.src2 ? a.src2 + (long long)c * a.src2_chan_stride : nullptr;
   const long long seg = a.seg0 + (long long)r_ * B;
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
   C v[P::E];
   // z[m] = x[2m] + i x[2m+1], m = in_idx(e). Fast path: the whole 2B segment is valid input
   // (wave-uniform test) -> one aligned 8-byte load per value, no per-sample checks.
-  const bool whole = (a.valid_len == 2 * B) && seg >= a.lo && seg + 2 * B <= a.hi;
+  const bool whole = live && (a.valid_len == 2 * B) && seg >= a.lo && seg + 2 * B <= a.hi;
   // with a second source the 8-byte loads need it even-aligned relative to the sample clock
   const bool s2ok = !src2 || (((a.src2_from & 1) == 0) && ((reinterpret_cast<uintptr_t>(src2) & 7u) == 0));
   float *ring_out = a.ring_out ? a.ring_out + (long long)c * a.ring_out_chan_stride : nullptr;
@@ -478,10 +481,10 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
       const int q = 2 * P::in_idx(tid, e);
       const long long n0 = seg + q, n1 = n0 + 1;
       float v0 = 0.f, v1 = 0.f;
-      if (q < a.valid_len && n0 >= a.lo && n0 < a.hi) v0 = load_sample(a, src, src2, n0);
-      if (q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi) v1 = load_sample(a, src, src2, n1);
+      if (live && q < a.valid_len && n0 >= a.lo && n0 < a.hi) v0 = load_sample(a, src, src2, n0);
+      if (live && q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi) v1 = load_sample(a, src, src2, n1);
       v[e] = mk<R>((R)v0, (R)v1);
-      if (ring_out && q >= B) {
+      if (live && ring_out && q >= B) {
         if (n0 >= a.ring_out_from && n0 >= a.lo && n0 < a.hi) ring_out[(unsigned long long)n0 & a.ring_out_mask] = v0;
         if (n1 >= a.ring_out_from && n1 >= a.lo && n1 < a.hi) ring_out[(unsigned long long)n1 & a.ring_out_mask] = v1;
       }
@@ -507,6 +510,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
   float2 *dst = a.dst + (long long)c * a.dst_chan_stride +
                 (long long)(((unsigned long long)(a.row0 + r_)) & a.row_mask) * B;
   const R half = (R)0.5;
+  if (!live) return;                                   // (after the last barrier)
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int k = P::out_idx(tid, e);
@@ -525,16 +529,19 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_fwd(const FwdArgs a) {
 }
 
 template <int LOGB, typename R>
-__global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_inv(const InvArgs a) {
+__global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  C *lds = reinterpret_cast<C *>(smem_raw);
   constexpr int B = P::B;
-  const int tid = threadIdx.x;
-  const int r_ = blockIdx.x, c = blockIdx.y;
+  const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;
+  C *lds = reinterpret_cast<C *>(smem_raw) + sub * P::LDS_ELEMS;
+  const int r_raw = blockIdx.x * P::TPW + sub, c = blockIdx.y;
+  const bool live_row = r_raw < a.rows;
+  const int r_ = live_row ? r_raw : a.rows - 1;              // dead sub-transforms shadow the last row, store nothing
   const long long nblk = (a.blk0 + r_) * (long long)B;
-  if (nblk >= a.hi || nblk + B <= a.lo) return;            // uniform
+  if (P::TPW == 1 && (nblk >= a.hi || nblk + B <= a.lo)) return;   // uniform early exit (one transform per workgroup)
+  const bool live = live_row && !(nblk >= a.hi || nblk + B <= a.lo);
   const float2 *Y = a.Y + (long long)c * a.y_chan_stride + (long long)r_ * B;
   const C *tw = reinterpret_cast<const C *>(a.tw);
   const C *tw8 = reinterpret_cast<const C *>(a.tw8);
@@ -565,7 +572,8 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_inv(const InvArgs a) {
   // z[m] = (s[2m], s[2m+1]); the overlap-save output is s[B..2B) = z[B/2..B): 8-byte stores
   float *dst = a.dst + (long long)c * a.dst_chan_stride;
   const float *add = a.add ? a.add + (long long)c * a.add_chan_stride : nullptr;
-  const bool whole = nblk >= a.lo && nblk + B <= a.hi;      // uniform: every sample of the block is wanted
+  const bool whole = nblk >= a.lo && nblk + B <= a.hi;      // every sample of the block is wanted
+  if (!live) return;                                        // (after the last barrier)
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int m = P::out_idx(tid, e);
@@ -606,14 +614,16 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fft8_inv(const InvArgs a) {
 // (TwoStageFFTConvolver.cpp:151-233 for len <= head block). One workgroup per channel.
 // ----------------------------------------------------------------------------------------
 template <int LOGB>
-__global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fused_block(const FusedArgs a) {
+__global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fused_block(const FusedArgs a) {
   typedef Plan8<LOGB> P;
   typedef cx<float> C;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  C *lds = reinterpret_cast<C *>(smem_raw);
   constexpr int B = P::B;
-  const int tid = threadIdx.x;
-  const int c = blockIdx.x;
+  const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;
+  C *lds = reinterpret_cast<C *>(smem_raw) + sub * P::LDS_ELEMS;
+  const int c_raw = blockIdx.x * P::TPW + sub;
+  const bool live = c_raw < a.channels;     // a dead sub-transform shadows the last channel and stores nothing
+  const int c = live ? c_raw : a.channels - 1;
   const float *in = a.in + (long long)c * a.in_chan_stride;
   float *ring = a.ring + (long long)c * a.ring_chan_stride;
   const C *tw = reinterpret_cast<const C *>(a.tw);
@@ -644,11 +654,11 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fused_block(const FusedArgs
     const long long n = seg + 2 * P::in_idx(tid, e);
     float s0 = 0.f, s1 = 0.f;
     if (n >= a.n0) {
-      if (n < a.n1) { s0 = in[n - a.n0]; ring[(unsigned long long)n & a.ring_mask] = s0; }
+      if (n < a.n1) { s0 = in[n - a.n0]; if (live) ring[(unsigned long long)n & a.ring_mask] = s0; }
     } else if (n >= 0) s0 = ring[(unsigned long long)n & a.ring_mask];
     const long long m = n + 1;
     if (m >= a.n0) {
-      if (m < a.n1) { s1 = in[m - a.n0]; ring[(unsigned long long)m & a.ring_mask] = s1; }
+      if (m < a.n1) { s1 = in[m - a.n0]; if (live) ring[(unsigned long long)m & a.ring_mask] = s1; }
     } else if (m >= 0) s1 = ring[(unsigned long long)m & a.ring_mask];
     v[e] = mk<float>(s0, s1);
   }
@@ -668,7 +678,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fused_block(const FusedArgs
     const float2 h = h0[e], yp = ypre[e];
     if (k == 0) {
       const float2 X = make_float2(A.x + A.y, A.x - A.y);             // packed (DC, Nyquist)
-      Xrow[0] = X;
+      if (live) Xrow[0] = X;
       y[e] = mk<float>(fmaf(h.x, X.x, yp.x), fmaf(h.y, X.y, yp.y));  // two real products
     } else {
       const C Bc = cconj(lds[lpad(B - k)]);
@@ -676,7 +686,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fused_block(const FusedArgs
       const C D = mk<float>(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
       const C O = mk<float>(D.y, -D.x);
       const C X = cadd(Ev, cmul(wso[e], O));
-      Xrow[k] = make_float2(X.x, X.y);
+      if (live) Xrow[k] = make_float2(X.x, X.y);
       y[e] = mk<float>(fmaf(h.x, X.x, fmaf(-h.y, X.y, yp.x)), fmaf(h.x, X.y, fmaf(h.y, X.x, yp.y)));
     }
   }
@@ -706,6 +716,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::NT) k_fused_block(const FusedArgs
   float *out = a.out + (long long)c * a.out_chan_stride;
   const float *add = a.add ? a.add + (long long)c * a.add_chan_stride : nullptr;
   const long long nblk = a.k * (long long)B;
+  if (!live) return;
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int m = P::out_idx(tid, e);
@@ -1037,9 +1048,12 @@ __global__ void __launch_bounds__(256) k_ingest(const IngestArgs a) {
 // ----------------------------------------------------------------------------------------
 template <int LOGB, typename R>
 static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStream_t st) {
-  if constexpr (LOGB >= 9) {
-    const size_t lds = sizeof(cx<R>) * Plan8<LOGB>::LDS_ELEMS;
-    RVC_LAUNCH((k_fft8_fwd<LOGB, R>), dim3(rows, channels), dim3(Plan8<LOGB>::NT), lds, st, a);
+  if constexpr (LOGB >= 6) {
+    typedef Plan8<LOGB> P;
+    const size_t lds = sizeof(cx<R>) * P::LDS_ELEMS * P::TPW;
+    FwdArgs b = a;
+    b.rows = rows;
+    RVC_LAUNCH((k_fft8_fwd<LOGB, R>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
   } else {
     const size_t lds = sizeof(cx<R>) << LOGB;
     RVC_LAUNCH((k_fft_fwd<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
@@ -1048,9 +1062,12 @@ static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStre
 }
 template <int LOGB, typename R>
 static hipError_t launch_inv_t(const InvArgs &a, int rows, int channels, hipStream_t st) {
-  if constexpr (LOGB >= 9) {
-    const size_t lds = sizeof(cx<R>) * Plan8<LOGB>::LDS_ELEMS;
-    RVC_LAUNCH((k_fft8_inv<LOGB, R>), dim3(rows, channels), dim3(Plan8<LOGB>::NT), lds, st, a);
+  if constexpr (LOGB >= 6) {
+    typedef Plan8<LOGB> P;
+    const size_t lds = sizeof(cx<R>) * P::LDS_ELEMS * P::TPW;
+    InvArgs b = a;
+    b.rows = rows;
+    RVC_LAUNCH((k_fft8_inv<LOGB, R>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
   } else {
     const size_t lds = sizeof(cx<R>) << LOGB;
     RVC_LAUNCH((k_fft_inv<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
@@ -1060,6 +1077,9 @@ static hipError_t launch_inv_t(const InvArgs &a, int rows, int channels, hipStre
 
 int fft8_table_entries(int logB) {   // entries of the tw8 table the radix-8 kernels expect (0: not used)
   switch (logB) {
+    case 6: return Plan8<6>::tw8_entries;
+    case 7: return Plan8<7>::tw8_entries;
+    case 8: return Plan8<8>::tw8_entries;
     case 9: return Plan8<9>::tw8_entries;
     case 10: return Plan8<10>::tw8_entries;
     case 11: return Plan8<11>::tw8_entries;
@@ -1110,19 +1130,25 @@ hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int ch
   }
 }
 
-bool fwd_appends_ring(int logB) { return logB >= 9; }
+bool fwd_appends_ring(int logB) { return logB >= 6; }
 
-bool fused_supported(int logB, bool f64) { return !f64 && logB >= 9 && logB <= 13; }
+bool fused_supported(int logB, bool f64) { return !f64 && logB >= 6 && logB <= 13; }
 
 template <int LOGB>
 static hipError_t launch_fused_t(const FusedArgs &a, int channels, hipStream_t st) {
-  const size_t lds = sizeof(cx<float>) * Plan8<LOGB>::LDS_ELEMS;
-  RVC_LAUNCH((k_fused_block<LOGB>), dim3(channels), dim3(Plan8<LOGB>::NT), lds, st, a);
+  typedef Plan8<LOGB> P;
+  const size_t lds = sizeof(cx<float>) * P::LDS_ELEMS * P::TPW;
+  FusedArgs b = a;
+  b.channels = channels;
+  RVC_LAUNCH((k_fused_block<LOGB>), dim3((channels + P::TPW - 1) / P::TPW), dim3(P::WG), lds, st, b);
   return hipGetLastError();
 }
 
 hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t st) {
   switch (logB) {
+    case 6: return launch_fused_t<6>(a, channels, st);
+    case 7: return launch_fused_t<7>(a, channels, st);
+    case 8: return launch_fused_t<8>(a, channels, st);
     case 9: return launch_fused_t<9>(a, channels, st);
     case 10: return launch_fused_t<10>(a, channels, st);
     case 11: return launch_fused_t<11>(a, channels, st);

@@ -357,3 +357,78 @@ def test_device_entry_zeros_before_init_and_with_empty_ir():
     s.process_device(x, y)
     torch.cuda.synchronize()
     assert float(y.abs().max()) == 0.0
+
+
+def _random_schedule(rng, total, head, tail):
+    """Call sizes mixing the regimes the engine treats differently: sub-block, exactly one block,
+    a few blocks, and long calls that take the adaptive whole-IR path."""
+    out, done = [], 0
+    while done < total:
+        kind = rng.randint(0, 6)
+        if kind == 0:
+            n = rng.randint(1, head + 1)
+        elif kind == 1:
+            n = head
+        elif kind == 2:
+            n = rng.randint(head, 4 * head + 1)
+        elif kind == 3:
+            n = rng.randint(1, 3 * tail)
+        elif kind == 4:
+            n = rng.randint(4 * tail, 9 * tail)
+        else:
+            n = head - (done % head) if done % head else head     # realign to the block grid
+        n = max(1, min(n, total - done))
+        out.append(n)
+        done += n
+    return out
+
+
+@pytest.mark.parametrize("seed", list(range(48)))
+def test_fuzz_geometry_and_call_pattern(seed):
+    """Seeded fuzz: random head/tail sizes (incl. non powers of two), IR lengths around the
+    stage boundaries, 1-3 channels of different lengths, flags, and call patterns; every run is
+    compared with the oracle sample by sample."""
+    rng = np.random.RandomState(1000 + seed)
+    head = int(rng.choice([1, 3, 8, 24, 64, 100, 256, 512, 1024]))
+    tail = int(rng.choice([max(head, 16), 2 * max(head, 8), 128, 512, 2048, 8192]))
+    if head > tail:
+        head, tail = tail, head
+    hb = 1 << (max(head, 1) - 1).bit_length()
+    tb = 1 << (max(tail, 1) - 1).bit_length()
+    nch = int(rng.randint(1, 4))
+    base = int(rng.choice([tb // 2 + 1, tb, tb + 1, 2 * tb - 1, 2 * tb, 2 * tb + 1, 3 * tb + 7, 7 * tb + 13, 12 * tb]))
+    base = max(1, min(base, 120000))
+    irs = []
+    for c in range(nch):
+        n = max(1, base - int(rng.randint(0, max(2, base // 3))) if c else base)
+        irs.append(synth.synth_ir(n, 1, 60 + 3 * seed + c)[0])
+    total = int(min(max(14 * tb, 4000), 200000))
+    sched = _random_schedule(rng, total, hb, tb)
+    bg = bool(rng.randint(0, 2))
+    fixed = bool(rng.randint(0, 2))
+    x = np.stack([synth.synth_input(total, 5 * seed + c) for c in range(nch)])
+    s = reevr_amd.ConvolverSet(nch, bg_stream=bg, fixed_partitions=fixed)
+    assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
+    clear_at = int(rng.randint(0, len(sched))) if rng.randint(0, 3) == 0 else -1
+    got = np.empty_like(x)
+    pos = 0
+    start = 0
+    for i, n in enumerate(sched):
+        if i == clear_at and pos % hb == 0:      # block-aligned clear (the mid-block quirk is documented)
+            s.clear()
+            start = pos
+        got[:, pos:pos + n] = s.process(x[:, pos:pos + n])
+        pos += n
+    assert s.last_error == 0, s.last_error_string
+    for c in range(nch):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        want = np.empty(total, np.float32)
+        want[:start] = o.process(x[c, :start]) if start else want[:0]
+        if start:
+            o.clear()
+        want[start:] = o.process(x[c, start:])
+        err = np.sqrt(np.mean((got[c].astype(np.float64) - want) ** 2))
+        ref = max(np.sqrt(np.mean(want.astype(np.float64) ** 2)), 1e-12)
+        assert err / ref <= TOL, (f"seed {seed}: head {head} tail {tail} nch {nch} ir {[len(i) for i in irs]} "
+                                  f"bg {bg} fixed {fixed} clear {clear_at}: rel rms {err / ref:.3e}")
