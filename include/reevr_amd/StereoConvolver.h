@@ -60,11 +60,17 @@ class StereoConvolver {
     // StereoConvolver.cpp:33-42
     const float *in[2] = {dataL, dataR};
     float *out[2] = {bufferLL.data(), bufferRR.data()};
-    rvc_set_process(_main, in, out, nsamples);
-    if (isQuad && !force2Chans) {
-      float *outx[2] = {bufferLR.data(), bufferRL.data()};   // LR is fed L, RL is fed R
-      rvc_set_process(_cross, in, outx, nsamples);
+    float *outx[2] = {bufferLR.data(), bufferRL.data()};   // LR is fed L, RL is fed R
+    const bool cross = isQuad && !force2Chans;
+    if (nsamples > static_cast<size_t>(size)) {            // longer than prepare() announced: blocking, split inside
+      rvc_set_process(_main, in, out, nsamples);
+      if (cross) rvc_set_process(_cross, in, outx, nsamples);
+      return;
     }
+    rvc_set_process_begin(_main, in, nsamples);            // both pairs in flight together, then collect
+    if (cross) rvc_set_process_begin(_cross, in, nsamples);
+    rvc_set_process_end(_main, out);
+    if (cross) rvc_set_process_end(_cross, outx);
   }
 
   void reset() {   // StereoConvolver.cpp:44-54

@@ -100,6 +100,13 @@ int rvc_set_init_uniform(rvc_set *s, size_t block, const float *const *irs,
  * an empty IR: zeros (FFTConvolver.cpp:157-161). */
 void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size_t len);
 
+/* Split form of rvc_set_process for callers that drive several sets per audio block (the LL/RR
+ * and LR/RL pairs of a quad StereoConvolver): _begin stages the input and enqueues copy-in,
+ * kernels and copy-out without waiting; _end waits and delivers into out[c]. One _begin must be
+ * followed by one _end on the same set before anything else; len <= max_len. */
+void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len);
+void rvc_set_process_end(rvc_set *s, float *const *out);
+
 /* Same, with DEVICE-resident buffers: channel c reads d_in + c*in_stride and writes
  * d_out + c*out_stride (strides in floats). Asynchronous on the set's stream
  * (rvc_set_stream); call rvc_set_sync or synchronise that stream before reading d_out

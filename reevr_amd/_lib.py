@@ -26,6 +26,8 @@ SIGNATURES = {
     "rvc_set_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, F32PP, SZP, C.c_size_t]),
     "rvc_set_init_uniform": (C.c_int, [C.c_void_p, C.c_size_t, F32PP, SZP, C.c_size_t]),
     "rvc_set_process": (None, [C.c_void_p, F32PP, F32PP, C.c_size_t]),
+    "rvc_set_process_begin": (None, [C.c_void_p, F32PP, C.c_size_t]),
+    "rvc_set_process_end": (None, [C.c_void_p, F32PP]),
     "rvc_set_process_device": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
     "rvc_set_process_device_blocks": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                              C.c_size_t]),

@@ -92,6 +92,22 @@ class ConvolverSet:
         self._lib.rvc_set_process(self._h, ins, outs, n)
         return out
 
+    def process_begin(self, x: np.ndarray):
+        """Non-blocking half of process(): stage x (n_channels, len <= max_len) and enqueue the work."""
+        x = _f32(x)
+        assert x.ndim == 2 and x.shape[0] == self.n_channels
+        self._pending = x
+        ins = (L.F32P * self.n_channels)(*[x[c].ctypes.data_as(L.F32P) for c in range(self.n_channels)])
+        self._lib.rvc_set_process_begin(self._h, ins, x.shape[1])
+
+    def process_end(self) -> np.ndarray:
+        """Wait for the work enqueued by process_begin and return its output."""
+        out = np.empty_like(self._pending)
+        outs = (L.F32P * self.n_channels)(*[out[c].ctypes.data_as(L.F32P) for c in range(self.n_channels)])
+        self._lib.rvc_set_process_end(self._h, outs)
+        self._pending = None
+        return out
+
     def process_device(self, d_in, d_out=None, sync: bool = True):
         """d_in / d_out: torch float32 CUDA tensors (n_channels, len), last dim contiguous.
         Runs on the set's own HIP stream; with sync=True waits for completion."""
@@ -274,11 +290,19 @@ class StereoConvolver:
     def process(self, dataL: np.ndarray, dataR: np.ndarray, nsamples: int, force2Chans: bool = False):
         # StereoConvolver.cpp:33-42
         x = np.stack([_f32(dataL)[:nsamples], _f32(dataR)[:nsamples]])
-        y = self._main.process(x)
+        cross = self.isQuad and not force2Chans
+        if nsamples > self.size:                 # longer than prepare() announced: blocking, split inside
+            y = self._main.process(x)
+            z = self._cross.process(x) if cross else None
+        else:                                    # both pairs in flight together, then collect
+            self._main.process_begin(x)
+            if cross:
+                self._cross.process_begin(x)     # LR is fed L, RL is fed R
+            y = self._main.process_end()
+            z = self._cross.process_end() if cross else None
         self.bufferLL[:nsamples] = y[0]
         self.bufferRR[:nsamples] = y[1]
-        if self.isQuad and not force2Chans:
-            z = self._cross.process(x)           # LR is fed L, RL is fed R
+        if cross:
             self.bufferLR[:nsamples] = z[0]
             self.bufferRL[:nsamples] = z[1]
 

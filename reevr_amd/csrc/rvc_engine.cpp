@@ -108,6 +108,9 @@ struct rvc_set {
   std::deque<Job> jobs;          // tail jobs enqueued on st_bg, oldest first
   std::vector<hipEvent_t> ev_pool;
 
+  size_t pending_len = 0;        // rvc_set_process_begin without its _end yet
+  bool pending_ok = false;
+
   bool timing = false;
   std::vector<TimedLaunch> timed[kNumKernelIds];
 };
@@ -791,28 +794,53 @@ void rvc_set_process_device_blocks(rvc_set *s, const float *d_in, size_t in_stri
     rvc_set_process_device(s, d_in + done, in_stride, d_out + done, out_stride, std::min(block, len - done));
 }
 
+void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
+  if (!s) return;
+  s->pending_len = len;
+  s->pending_ok = false;
+  if (len == 0 || !s->live || s->err != RVC_OK || !in) return;
+  if (len > s->max_len) { fail(s, RVC_ERR_BAD_ARG, hipSuccess, "process_begin: len > max_len"); return; }
+  if (!use_device(s)) return;
+  for (int c = 0; c < s->nch; ++c) std::memcpy(s->h_in + (size_t)c * len, in[c], len * sizeof(float));
+  bool ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * len * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
+  ok = ok && step_device(s, s->d_in, len, s->d_out, len, len);
+  ok = ok && hipMemcpyAsync(s->h_out, s->d_out, sizeof(float) * len * s->nch, hipMemcpyDeviceToHost, s->st_main) == hipSuccess;
+  if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_begin");
+  s->pending_ok = ok;
+}
+
+void rvc_set_process_end(rvc_set *s, float *const *out) {
+  if (!s || !out) return;
+  const size_t len = s->pending_len;
+  s->pending_len = 0;
+  if (len == 0) return;
+  bool ok = s->pending_ok;
+  if (ok) {
+    hipSetDevice(s->device);
+    ok = hipStreamSynchronize(s->st_main) == hipSuccess;
+    if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_end");
+  }
+  for (int c = 0; c < s->nch; ++c) {
+    if (!out[c]) continue;
+    if (ok) std::memcpy(out[c], s->h_out + (size_t)c * len, len * sizeof(float));
+    else std::memset(out[c], 0, len * sizeof(float));   // not initialised / empty IR / failed: zeros
+  }
+  s->pending_ok = false;
+}
+
 void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size_t len) {
   if (!s || len == 0 || !out) return;
-  auto zeros = [&]() {
-    for (int c = 0; c < s->nch; ++c)
-      if (out[c]) std::memset(out[c], 0, len * sizeof(float));
-  };
-  if (!s->live || s->err != RVC_OK || !in) { zeros(); return; }
-  if (!use_device(s)) { zeros(); return; }
   size_t done = 0;
-  while (done < len) {
-    const size_t chunk = std::min(len - done, s->max_len);
-    for (int c = 0; c < s->nch; ++c) std::memcpy(s->h_in + (size_t)c * chunk, in[c] + done, chunk * sizeof(float));
-    bool ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * chunk * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
-    ok = ok && step_device(s, s->d_in, chunk, s->d_out, chunk, chunk);
-    ok = ok && hipMemcpyAsync(s->h_out, s->d_out, sizeof(float) * chunk * s->nch, hipMemcpyDeviceToHost, s->st_main) == hipSuccess;
-    ok = ok && hipStreamSynchronize(s->st_main) == hipSuccess;
-    if (!ok) {
-      fail(s, RVC_ERR_HIP, hipGetLastError(), "process");
-      zeros();
-      return;
+  std::vector<const float *> ins(s->nch);
+  std::vector<float *> outs(s->nch);
+  while (done < len) {   // calls longer than max_len are split; results are call-pattern independent
+    const size_t chunk = std::min(len - done, s->max_len ? s->max_len : len);
+    for (int c = 0; c < s->nch; ++c) {
+      ins[c] = in ? in[c] + done : nullptr;
+      outs[c] = out[c] ? out[c] + done : nullptr;
     }
-    for (int c = 0; c < s->nch; ++c) std::memcpy(out[c] + done, s->h_out + (size_t)c * chunk, chunk * sizeof(float));
+    rvc_set_process_begin(s, in ? ins.data() : nullptr, chunk);
+    rvc_set_process_end(s, outs.data());
     done += chunk;
   }
 }

@@ -261,7 +261,7 @@ template <int LOGB> struct Plan8 {
   static constexpr int B = 1 << LOGB;
   static constexpr int N8 = LOGB / 3;             // radix-8 passes
   static constexpr int Q = 1 << (LOGB % 3);       // final pass radix: 1 (none), 2 or 4
-  static constexpr int S = (LOGB >= 14) ? 2 : 1;  // radix-8 butterflies per thread
+  static constexpr int S = (LOGB >= 14) ? 2 : 1;  // radix-8 butterflies per thread (16 values at B = 8192 was measured: forward transform 25 % slower)
   static constexpr int NT = B / (8 * S);          // threads per transform
   static constexpr int TPW = NT < 64 ? 64 / NT : 1;   // transforms per workgroup (B < 512: several share a wave)
   static constexpr int WG = NT * TPW;             // workgroup size
