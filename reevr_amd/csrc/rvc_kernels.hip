@@ -861,6 +861,7 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
   const int c = blockIdx.z;
   const long long T0 = (long long)blockIdx.y * 64;      // first output row of the workgroup
   const long long t0 = T0 + 16 * wave;                  // ... of this wave
+  const bool wave_active = t0 < a.M;
   const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride + bin0;
   const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride + bin0;
   const long long B = a.B;
@@ -949,9 +950,11 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
       }
       w[(TK - 1 - u16) & (TK - 1)] = xin;                 // zero for rows < 0 was applied when staged
     };
+    if (wave_active) {     // a wave whose 16 rows lie beyond M only helps with staging and barriers
 #pragma unroll
-    for (int u = 0; u < CH; ++u)
-      if (j * CH + u < P) step(j * CH + u, u, PH * CH + u);   // uniform (only the last chunk can be partial)
+      for (int u = 0; u < CH; ++u)
+        if (j * CH + u < P) step(j * CH + u, u, PH * CH + u);   // uniform (only the last chunk can be partial)
+    }
     if (j + 1 < nchunks) {
       // ONE barrier per chunk. The slots written here are free without a barrier in front:
       //  * ring: rows of chunk j+1 land on the slots of rows R0+48-8j .. R0+55-8j, above every
