@@ -73,6 +73,16 @@ class StereoConvolver {
     if (cross) rvc_set_process_end(_cross, outx);
   }
 
+  // Feed nsamples (any length) and discard the output: the reference's warm-up loop of block-sized
+  // process() calls (src/PluginProcessor.cpp:1716-1750) as one multi-block call per pair.
+  void warm(const float *dataL, const float *dataR, size_t nsamples, bool force2Chans = false) {
+    std::vector<float> sinkL(nsamples), sinkR(nsamples);
+    const float *in[2] = {dataL, dataR};
+    float *out[2] = {sinkL.data(), sinkR.data()};
+    rvc_set_process(_main, in, out, nsamples);
+    if (isQuad && !force2Chans) rvc_set_process(_cross, in, out, nsamples);
+  }
+
   void reset() {   // StereoConvolver.cpp:44-54
     rvc_set_reset(_main);
     rvc_set_reset(_cross);

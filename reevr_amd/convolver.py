@@ -306,6 +306,15 @@ class StereoConvolver:
             self.bufferLR[:nsamples] = z[0]
             self.bufferRL[:nsamples] = z[1]
 
+    def warm(self, dataL: np.ndarray, dataR: np.ndarray, nsamples: int, force2Chans: bool = False):
+        """Feed nsamples (any length, typically many blocks) and discard the output: what the
+        reference's warm-up loop of block-sized process() calls amounts to
+        (src/PluginProcessor.cpp:1716-1750). One multi-block call per pair."""
+        x = np.stack([_f32(dataL)[:nsamples], _f32(dataR)[:nsamples]])
+        self._main.process(x)
+        if self.isQuad and not force2Chans:
+            self._cross.process(x)
+
     def reset(self):                             # StereoConvolver.cpp:44-54
         self._main.reset()
         self._cross.reset()

@@ -1,0 +1,144 @@
+"""IR hot-swap around two StereoConvolvers -- SURVEY.md 8(f) row f-2 (and the wet-bus sum of f-3).
+
+Host-side mirror of the convolver section of the reference's processBlock
+(src/PluginProcessor.cpp:1655-1756 warm-up ring + load state machine, :1793-1838 process,
+crossfade, swap, wet sum; constants src/Globals.h:7-9), without JUCE:
+
+  kIdle -> request_impulse() -> kLoading (worker thread: loadConvolver.loadImpulse)
+        -> kReady  -> warm-up: the last 0.25 s of send signal replayed through the new convolver
+                      (force2Chans) -- here ONE multi-block process() call instead of the
+                      reference's loop of block-sized calls (same result: call-pattern independent)
+        -> kFading -> CONV_XFADE ms linear crossfade old/new, then swap -> kIdle
+
+The send-path IIR filters the reference applies to the replayed audio (irlowcut / irhighcut,
+:1702-1745) are outside the convolution path; they are identity at their default settings and the
+caller may pass an already filtered signal.
+"""
+from __future__ import annotations
+
+import math
+import threading
+
+import numpy as np
+
+CONV_XFADE_MS = 50            # src/Globals.h:7
+K_IDLE, K_LOADING, K_READY, K_FADING = range(4)
+
+
+class HotSwapStereoConvolver:
+    def __init__(self, make_stereo_convolver, threaded: bool = True):
+        """make_stereo_convolver() -> object with the reference StereoConvolver surface
+        (prepare/loadImpulse/process/clear + bufferLL/RR/LR/RL, isQuad, size)."""
+        self.convolver = make_stereo_convolver()
+        self.loadConvolver = make_stereo_convolver()
+        self.threaded = threaded
+        self.loadState = K_IDLE
+        self.xfade = 0
+        self.xfadelen = 0
+        self._worker = None
+
+    def prepare(self, sampleRate: float, samplesPerBlock: int):      # PluginProcessor.cpp:607-614
+        self.srate = float(sampleRate)
+        self.convolver.prepare(samplesPerBlock)
+        self.loadConvolver.prepare(samplesPerBlock)
+        self.warmer = np.zeros((2, int(math.ceil(sampleRate)) // 4), np.float32)   # 0.25 s, :610
+        self.warmwritepos = 0
+
+    def loadImpulse(self, imp):                                        # :638 (initial, synchronous)
+        self.convolver.loadImpulse(imp)
+
+    def request_impulse(self, imp) -> bool:                            # :1675-1691
+        if self.loadState != K_IDLE:
+            return False
+        self.loadState = K_LOADING
+
+        def job():
+            self.loadConvolver.loadImpulse(imp)
+            self.loadState = K_READY
+
+        if self.threaded:
+            self._worker = threading.Thread(target=job)
+            self._worker.start()
+        else:
+            job()
+        return True
+
+    def wait_loaded(self):
+        if self._worker is not None:
+            self._worker.join()
+            self._worker = None
+
+    def _warm_write(self, sendL, sendR, n):                            # :1655-1668
+        W = self.warmer.shape[1]
+        for ch, src in ((0, sendL), (1, sendR)):
+            space = W - self.warmwritepos
+            if n <= space:
+                self.warmer[ch, self.warmwritepos:self.warmwritepos + n] = src[:n]
+            else:
+                self.warmer[ch, self.warmwritepos:] = src[:space]
+                self.warmer[ch, :n - space] = src[space:n]
+        self.warmwritepos = (self.warmwritepos + n) % W
+
+    def _warm_up(self):                                                # :1695-1755
+        W = self.warmer.shape[1]
+        size = self.convolver.size
+        numBlocks = W // size
+        start = (self.warmwritepos + 1) % W
+        idx = (start + np.arange(numBlocks * size)) % W
+        replay = self.warmer[:, idx]
+        # one multi-block call; the reference issues numBlocks calls of `size` samples
+        if hasattr(self.loadConvolver, "warm"):
+            self.loadConvolver.warm(replay[0], replay[1], numBlocks * size, True)
+        else:
+            for i in range(numBlocks):
+                self.loadConvolver.process(replay[0, i * size:], replay[1, i * size:], size, True)
+        self.loadState = K_FADING
+        self.xfade = int(math.ceil(self.srate * CONV_XFADE_MS / 1000.0))
+        self.xfadelen = self.xfade
+
+    def process(self, sendL, sendR, delayedL, delayedR, numSamples: int, tsenabled: bool = True):
+        """One host block. send* feeds the warm-up ring and the fading-in convolver, delayed* (the
+        pre-delayed send) the current one. Returns the wet bus (L, R) before envelope/width."""
+        sendL = np.asarray(sendL, np.float32); sendR = np.asarray(sendR, np.float32)
+        self._warm_write(sendL, sendR, numSamples)
+        if self.loadState == K_READY:
+            self._warm_up()
+        conv = self.convolver
+        conv.process(delayedL, delayedR, numSamples)                   # :1793-1797
+        wet = np.zeros((2, numSamples), np.float32)
+        if self.loadState == K_FADING:                                 # :1800-1830
+            load = self.loadConvolver
+            load.process(sendL, sendR, numSamples, True)
+            nbuf = len(conv.bufferLL)                                  # the loop runs over the whole buffer
+            xf = self.xfade - np.arange(nbuf, dtype=np.float32)
+            alpha = np.clip(np.float32(1.0) - xf / np.float32(self.xfadelen), 0.0, 1.0).astype(np.float32)
+            conv.bufferLL[:nbuf] *= (np.float32(1.0) - alpha); conv.bufferRR[:nbuf] *= (np.float32(1.0) - alpha)
+            load.bufferLL[:nbuf] *= alpha; load.bufferRR[:nbuf] *= alpha
+            if conv.isQuad and tsenabled:
+                conv.bufferLR[:nbuf] *= (np.float32(1.0) - alpha); conv.bufferRL[:nbuf] *= (np.float32(1.0) - alpha)
+            self.xfade -= nbuf
+            if self.xfade <= 0:
+                self.loadState = K_IDLE
+                self.convolver, self.loadConvolver = self.loadConvolver, self.convolver
+            wet[0] += self.loadConvolver.bufferLL[:numSamples]
+            wet[1] += self.loadConvolver.bufferRR[:numSamples]
+        conv = self.convolver                                          # :1833-1838 (after a possible swap)
+        wet[0] += conv.bufferLL[:numSamples]
+        wet[1] += conv.bufferRR[:numSamples]
+        if conv.isQuad and tsenabled:
+            wet[0] += conv.bufferRL[:numSamples]
+            wet[1] += conv.bufferLR[:numSamples]
+        return wet
+
+
+def wet_bus(wet, yrev, width: float, drygain: float, wetgain: float, dry):
+    """Reverb envelope, mid/side width and dry/wet mix (src/PluginProcessor.cpp:1840-1876)."""
+    lin = wet[0] * yrev
+    rin = wet[1] * yrev
+    mid = (lin + rin) * np.float32(0.5)
+    side = (lin - rin) * np.float32(0.5)
+    norm = np.float32(1.0 / (1.0 + width))
+    lout = (mid + side * np.float32(width)) * norm
+    rout = (mid - side * np.float32(width)) * norm
+    return np.stack([dry[0] * np.float32(drygain) + lout * np.float32(wetgain),
+                     dry[1] * np.float32(drygain) + rout * np.float32(wetgain)]).astype(np.float32)

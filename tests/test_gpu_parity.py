@@ -432,3 +432,45 @@ def test_fuzz_geometry_and_call_pattern(seed):
         ref = max(np.sqrt(np.mean(want.astype(np.float64) ** 2)), 1e-12)
         assert err / ref <= TOL, (f"seed {seed}: head {head} tail {tail} nch {nch} ir {[len(i) for i in irs]} "
                                   f"bg {bg} fixed {fixed} clear {clear_at}: rel rms {err / ref:.3e}")
+
+
+def test_ir_hot_swap_matches_reference_sequence():
+    """load -> warm-up replay (one multi-block call here, a loop of block calls
+    in the reference) -> 50 ms crossfade -> swap, for a quad impulse, against the oracle-side
+    restatement of src/PluginProcessor.cpp:1655-1756, 1793-1838."""
+    from reevr_amd.hotswap import HotSwapStereoConvolver
+    from tests.ref_hotswap import RefHotSwap
+
+    class Imp:
+        pass
+
+    def imp(inst, n, quad):
+        irs = synth.synth_ir(n, 4, inst)
+        m = Imp()
+        m.bufferLL, m.bufferRR, m.bufferLR, m.bufferRL = irs
+        m.isQuad = quad
+        return m
+
+    sr, blk, nblocks = 48000, 480, 70
+    a, b = imp(70, 30000, True), imp(71, 22000, True)
+    L = synth.synth_input(blk * nblocks, 0); R = synth.synth_input(blk * nblocks, 1)
+    gpu = HotSwapStereoConvolver(lambda: reevr_amd.StereoConvolver(), threaded=True)
+    ref = RefHotSwap()
+    for h in (gpu, ref):
+        h.prepare(sr, blk)
+        h.loadImpulse(a)
+    got, want = [], []
+    for i in range(nblocks):
+        s = slice(i * blk, (i + 1) * blk)
+        if i == 30:
+            assert gpu.request_impulse(b)
+            gpu.wait_loaded()                 # deterministic test: the load finishes before the next block
+            ref.request_impulse(b)
+        got.append(gpu.process(L[s], R[s], L[s], R[s], blk))
+        want.append(ref.process(L[s], R[s], L[s], R[s], blk))
+    got = np.concatenate(got, axis=1); want = np.concatenate(want, axis=1)
+    assert gpu.loadState == 0 and ref.state == 0          # faded and swapped
+    for c in range(2):
+        assert rel_rms(got[c], want[c]) <= TOL
+    fade = slice(31 * blk, 38 * blk)                      # the crossfade region itself
+    assert np.sqrt(np.mean((got[:, fade].astype(np.float64) - want[:, fade]) ** 2)) <= 5e-6
