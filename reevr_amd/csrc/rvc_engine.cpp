@@ -399,28 +399,20 @@ struct Timer {   // brackets one launch with events when timing is on
 // ---- tail stage pieces -------------------------------------------------------------------
 // Spectra of the tail blocks a call ending at n1 completed. `src2` = the call's own input when
 // the ring does not hold it yet (long single-stream calls), else nullptr.
-// with_partial: also transform the block the call ends in (zero-padded beyond n1); it is transformed
-// again when it completes, exactly like a partly filled head block.
-bool tail_spectra(rvc_set *s, long long n0, long long n1, const float *src2, size_t in_stride, hipStream_t st,
-                  bool with_partial = false, long long ring_from = -1) {
+bool tail_spectra(rvc_set *s, long long n0, long long n1, const float *src2, size_t in_stride, hipStream_t st) {
   Stage &T = s->T;
   const long long tb = (long long)T.B;
   const long long mb0 = s->tail_fft_done, mb1 = n1 / tb;   // tail blocks [mb0, mb1) completed by this call
-  const int extra = (with_partial && n1 % tb != 0) ? 1 : 0;
-  if (mb1 + extra <= mb0) return true;
+  if (mb1 <= mb0) return true;
   rvc::FwdArgs f{};
   f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
   f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
   f.seg0 = (mb0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
   f.tw = T.twp(); f.wsplit = T.wsp(); f.tw8 = T.t8p();
   f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = mb0; f.row_mask = T.rows - 1;
-  if (ring_from >= 0) {   // the transform kernel also appends the call's recent samples to the time ring
-    f.ring_out = s->xring; f.ring_out_chan_stride = (long long)s->ring_cap; f.ring_out_mask = s->ring_cap - 1;
-    f.ring_out_from = ring_from;
-  }
   Timer t(s, 4, st);
-  RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(mb1 - mb0) + extra, s->nch, st));
-  if (mb1 > mb0) s->tail_fft_done = mb1;
+  RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(mb1 - mb0), s->nch, st));
+  s->tail_fft_done = mb1;
   return true;
 }
 
