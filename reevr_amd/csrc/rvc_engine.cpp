@@ -110,6 +110,8 @@ struct rvc_set {
 
   size_t pending_len = 0;        // rvc_set_process_begin without its _end yet
   bool pending_ok = false;
+  size_t out_copy_len = 0;       // host-pointer call in flight: copy d_out -> h_out as soon as the output
+  hipEvent_t ev_out = nullptr;   // kernel is enqueued (before the off-critical-path work) and mark it here
 
   bool timing = false;
   std::vector<TimedLaunch> timed[kNumKernelIds];
@@ -150,6 +152,7 @@ bool ensure_streams(rvc_set *s) {
   RVC_CK(hipStreamCreateWithFlags(&s->st_main, hipStreamNonBlocking));
   RVC_CK(hipStreamCreateWithFlags(&s->st_bg, hipStreamNonBlocking));
   RVC_CK(hipEventCreateWithFlags(&s->ev_ingest, hipEventDisableTiming));
+  RVC_CK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
   s->streams_ok = true;
   return true;
 }
@@ -562,6 +565,19 @@ bool run_premultiply(rvc_set *s, long long kb) {
   return true;
 }
 
+// Host-pointer calls: the moment the kernel that produces the call's output is enqueued, enqueue
+// the copy back to the pinned buffer and an event behind it. The host then waits for THAT event,
+// not for the stream: the pre-multiplied accumulator and the tail job of the next block keep
+// running after process() has returned (they were never on the reference's critical path either).
+bool emit_output_copy(rvc_set *s) {
+  if (s->out_copy_len == 0) return true;
+  const size_t len = s->out_copy_len;
+  s->out_copy_len = 0;
+  RVC_CK(hipMemcpyAsync(s->h_out, s->d_out, sizeof(float) * len * s->nch, hipMemcpyDeviceToHost, s->st_main));
+  RVC_CK(hipEventRecord(s->ev_out, s->st_main));
+  return true;
+}
+
 // one process() step of at most max_len samples, device buffers, asynchronous
 bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len) {
   Stage &A = s->A, &T = s->T;
@@ -599,6 +615,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       Timer t(s, 7, s->st_main);
       RVC_CK(rvc::launch_fused(A.logB, g, s->nch, s->st_main));
     }
+    if (!emit_output_copy(s)) return false;
     s->xa_next = (n1 % hb == 0) ? k0 + 1 : k0;
     // off the latency path: the tail job if a tail block just completed, and the pre-multiplied
     // accumulator of the next block if this one is complete
@@ -738,6 +755,7 @@ void rvc_set_destroy(rvc_set *s) {
   if (s->streams_ok) {
     for (auto e : s->ev_pool) hipEventDestroy(e);
     hipEventDestroy(s->ev_ingest);
+    hipEventDestroy(s->ev_out);
     hipStreamDestroy(s->st_bg);
     hipStreamDestroy(s->st_main);
   }
@@ -795,8 +813,10 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   if (!use_device(s)) return;
   for (int c = 0; c < s->nch; ++c) std::memcpy(s->h_in + (size_t)c * len, in[c], len * sizeof(float));
   bool ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * len * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
+  s->out_copy_len = len;                       // step_device emits the copy-back right behind the output kernel
   ok = ok && step_device(s, s->d_in, len, s->d_out, len, len);
-  ok = ok && hipMemcpyAsync(s->h_out, s->d_out, sizeof(float) * len * s->nch, hipMemcpyDeviceToHost, s->st_main) == hipSuccess;
+  ok = ok && emit_output_copy(s);              // (paths whose last kernel is the output kernel)
+  s->out_copy_len = 0;
   if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_begin");
   s->pending_ok = ok;
 }
@@ -809,7 +829,7 @@ void rvc_set_process_end(rvc_set *s, float *const *out) {
   bool ok = s->pending_ok;
   if (ok) {
     hipSetDevice(s->device);
-    ok = hipStreamSynchronize(s->st_main) == hipSuccess;
+    ok = hipEventSynchronize(s->ev_out) == hipSuccess;   // output copied back; later stream work may still run
     if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_end");
   }
   for (int c = 0; c < s->nch; ++c) {
