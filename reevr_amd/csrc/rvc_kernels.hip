@@ -355,11 +355,17 @@ template <int LOGB, typename R> struct Tw8 {
   }
   // twiddle of radix-8 pass j >= 1, butterfly slot s, leg r = 1..7
   __device__ __forceinline__ cx<R> w8(const int j, const int s, const int r) const {
+#ifdef RVC_ABLATE_NOTW
+    return mk<R>((R)(0.5f + 0.01f * r + 0.001f * (tid_ & 3)), (R)(0.25f * (s + 1) + 0.002f * j));
+#endif
     if constexpr (EAGER) return t8[j - 1][s][r - 1];
     else return p8[P::off8(j) + ((tid_ + s * P::NT) & ((1 << (3 * j)) - 1)) * 8 + r];
   }
   // twiddle of the final pass: butterfly jb, leg r (radix-2: r = 1; radix-4: r = 1..3)
   __device__ __forceinline__ cx<R> wq(const int jb, const int r) const {
+#ifdef RVC_ABLATE_NOTW
+    return mk<R>((R)(0.5f + 0.01f * r + 0.001f * (tid_ & 3)), (R)(0.25f * (jb + 1)));
+#endif
     if constexpr (EAGER) return P::Q == 2 ? tq[jb] : tq[jb * 3 + r - 1];
     else return P::Q == 2 ? p1[tid_ + jb * P::NT] : p8[P::offq + (tid_ + jb * P::NT) * 4 + r];
   }
@@ -378,11 +384,23 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
     for (int s = 0; s < P::S; ++s) {
       C *a = v + 8 * s;
       if (j > 0) {
+        if constexpr (Tw8<LOGB, R>::EAGER) {
 #pragma unroll
-        for (int r = 1; r < 8; ++r) {
-          C w = T.w8(j > 0 ? j : 1, s, r);
-          if (INV) w.y = -w.y;
-          a[r] = cmul(a[r], w);
+          for (int r = 1; r < 8; ++r) {
+            C w = T.w8(j, s, r);
+            if (INV) w.y = -w.y;
+            a[r] = cmul(a[r], w);
+          }
+        } else {
+          // big transforms (B >= 8192) re-read their twiddles from L2 in every pass, 7 x 8 bytes per
+          // thread -- more bytes than the data itself. Fetch w^k, w^2k, w^4k only and build the other
+          // four with one complex multiply each (twiddle error <= 2 roundings instead of 1).
+          C w1 = T.w8(j, s, 1), w2 = T.w8(j, s, 2), w4 = T.w8(j, s, 4);
+          if (INV) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; }
+          const C w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4);
+          const C w7 = cmul(w3, w4);
+          a[1] = cmul(a[1], w1); a[2] = cmul(a[2], w2); a[3] = cmul(a[3], w3); a[4] = cmul(a[4], w4);
+          a[5] = cmul(a[5], w5); a[6] = cmul(a[6], w6); a[7] = cmul(a[7], w7);
         }
       }
       dft8<R, INV>(a);
