@@ -948,16 +948,19 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
       px[PH] = gX(R0 - (long long)(j + 2) * CH - 1 - lr);
       phv[PH] = gH((j + 2) * CH + lr);
     }
-    auto step = [&](const int i, const int u, const int u16) {
+    // operands of step u+1 are read from LDS while step u's FMAs issue (one exposed LDS latency
+    // per chunk instead of one per step)
+    auto operands = [&](const int u, float2 &hh, float2 &xin) {
 #ifdef RVC_ABLATE_NOLDSREAD
-      const float4 h = make_float4(1.f + i, 1.f + i, 0.5f, 0.f);
-      const float2 xin = make_float2(0.25f * u, 1.f);
+      hh = make_float2(1.f + u, 0.5f); xin = make_float2(0.25f * u, 1.f);
 #else
-      const float2 hh = sH[PH][u][lane];
-      const float2 xin = sXrow(cbase - i - 1)[lane];
+      hh = sH[PH][u][lane];
+      xin = sXrow(cbase - (long long)(j * CH + u) - 1)[lane];
+#endif
+    };
+    auto fmas = [&](const float2 hh, const float2 xin, const int u16) {
       // (h.re, h3, hz): ordinary bin (re, re, im); packed bin 0 (DC gain, Nyquist gain, 0)
       const float4 h = make_float4(hh.x, packed ? hh.y : hh.x, packed ? 0.f : hh.y, 0.f);
-#endif
 #pragma unroll
       for (int t = 0; t < TK; ++t) {
         const float2 x = w[(t - u16) & (TK - 1)];
@@ -969,9 +972,15 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
       w[(TK - 1 - u16) & (TK - 1)] = xin;                 // zero for rows < 0 was applied when staged
     };
     if (wave_active) {     // a wave whose 16 rows lie beyond M only helps with staging and barriers
+      float2 hh, xin;
+      operands(0, hh, xin);
 #pragma unroll
-      for (int u = 0; u < CH; ++u)
-        if (j * CH + u < P) step(j * CH + u, u, PH * CH + u);   // uniform (only the last chunk can be partial)
+      for (int u = 0; u < CH; ++u) {
+        float2 hn = hh, xn = xin;
+        if (u + 1 < CH) operands(u + 1, hn, xn);
+        if (j * CH + u < P) fmas(hh, xin, PH * CH + u);   // uniform (only the last chunk can be partial)
+        hh = hn; xin = xn;
+      }
     }
     if (j + 1 < nchunks) {
       // ONE barrier per chunk. The slots written here are free without a barrier in front:
