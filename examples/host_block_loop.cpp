@@ -43,6 +43,13 @@ int main(int argc, char **argv) {
   auto t0 = std::chrono::steady_clock::now();
   conv.loadImpulse(imp);
   const double load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  // IR hot-swap: a new IR of the same length into the already prepared convolver (the loadConvolver
+  // case, src/PluginProcessor.cpp:1680-1691) keeps every device buffer and only refreshes the spectra
+  make_ir(imp.bufferLL); make_ir(imp.bufferRR);
+  if (quad) { make_ir(imp.bufferLR); make_ir(imp.bufferRL); }
+  t0 = std::chrono::steady_clock::now();
+  conv.loadImpulse(imp);
+  const double reload_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
   std::vector<float> L(block), R(block);
   std::vector<double> us(blocks);
@@ -58,9 +65,9 @@ int main(int argc, char **argv) {
   std::sort(us.begin(), us.end());
   double sum = 0;
   for (double u : us) sum += u;
-  std::printf("{\"block\": %d, \"channels\": %d, \"loadImpulse_ms\": %.2f, \"call_us_median\": %.1f, \"call_us_p99\": %.1f, "
+  std::printf("{\"block\": %d, \"channels\": %d, \"loadImpulse_ms\": %.2f, \"reloadImpulse_ms\": %.2f, \"call_us_median\": %.1f, \"call_us_p99\": %.1f, "
               "\"call_us_max\": %.1f, \"Msamples_per_s\": %.2f, \"block_period_us\": %.1f, \"checksum\": %.6f}\n",
-              block, quad ? 4 : 2, load_ms, us[blocks / 2], us[(size_t)(blocks * 0.99)], us.back(),
+              block, quad ? 4 : 2, load_ms, reload_ms, us[blocks / 2], us[(size_t)(blocks * 0.99)], us.back(),
               (quad ? 4.0 : 2.0) * block * blocks / sum, 1e6 * block / sr, checksum);
   return 0;
 }

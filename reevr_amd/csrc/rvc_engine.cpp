@@ -63,6 +63,7 @@ struct Stage {
   size_t rows = 0;    // X ring rows (power of two)
   size_t mcap = 0;    // Y rows (max output rows per call)
   float2 *H = nullptr, *X = nullptr, *Y = nullptr;
+  float *d_ir = nullptr;   // time-domain partitions (kept so that a re-init only re-uploads and re-transforms)
   float2 *tw = nullptr, *wsplit = nullptr, *tw8 = nullptr;       // float twiddles
   double2 *twd = nullptr, *wsplitd = nullptr, *tw8d = nullptr;   // double twiddles (B <= 8192): IR spectra, f64 mode
   bool f64 = false;                              // run this stage's transforms in double
@@ -87,6 +88,7 @@ struct rvc_set {
   bool inited = false;   // init succeeded (possibly with an empty IR)
   bool live = false;     // device state exists (non-empty IR)
   size_t head = 0, tail = 0, max_len = 0;
+  bool two_stage = false;
   Stage A, T;
   float *xring = nullptr, *tailring = nullptr;
   size_t ring_cap = 0;
@@ -158,7 +160,7 @@ bool ensure_streams(rvc_set *s) {
 }
 
 void free_stage(Stage &g) {
-  hipFree(g.H); hipFree(g.X); hipFree(g.Y); hipFree(g.tw); hipFree(g.wsplit);
+  hipFree(g.H); hipFree(g.X); hipFree(g.Y); hipFree(g.d_ir); hipFree(g.tw); hipFree(g.wsplit);
   hipFree(g.twd); hipFree(g.wsplitd); hipFree(g.tw8); hipFree(g.tw8d);
   g = Stage();
 }
@@ -264,12 +266,11 @@ bool upload_ir_stage(rvc_set *s, Stage &g, const std::vector<std::vector<float>>
   std::vector<float> host((size_t)s->nch * padded, 0.f);
   for (int c = 0; c < s->nch; ++c)
     std::copy(parts[c].begin(), parts[c].end(), host.begin() + (size_t)c * padded);
-  float *d_ir = nullptr;
-  RVC_CK(hipMalloc(&d_ir, sizeof(float) * host.size()));
-  RVC_CK(hipMemcpy(d_ir, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
-  RVC_CK(hipMalloc(&g.H, sizeof(float2) * (size_t)s->nch * g.hrows() * g.B));
+  if (!g.d_ir) RVC_CK(hipMalloc(&g.d_ir, sizeof(float) * host.size()));
+  RVC_CK(hipMemcpy(g.d_ir, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
+  if (!g.H) RVC_CK(hipMalloc(&g.H, sizeof(float2) * (size_t)s->nch * g.hrows() * g.B));
   rvc::FwdArgs a{};
-  a.src = d_ir; a.src_chan_stride = (long long)padded; a.src_mask = ~0ull;
+  a.src = g.d_ir; a.src_chan_stride = (long long)padded; a.src_mask = ~0ull;
   a.seg0 = 0; a.valid_len = (int)g.B; a.lo = 0; a.hi = (long long)padded;
   // One-off, so always in double where the LDS allows it (B <= 8192): the IR spectra then carry
   // only the float rounding of the stored bins, like the reference's (AudioFFT.cpp:114-137).
@@ -280,22 +281,26 @@ bool upload_ir_stage(rvc_set *s, Stage &g, const std::vector<std::vector<float>>
   a.dst = g.H; a.dst_chan_stride = (long long)g.hrows() * (long long)g.B; a.row0 = 0; a.row_mask = ~0ull;
   hipError_t e = rvc::launch_fft_fwd(g.logB, ir64, a, g.hrows(), s->nch, s->st_main);
   if (e == hipSuccess) e = hipStreamSynchronize(s->st_main);
-  hipFree(d_ir);
   if (e != hipSuccess) return fail(s, RVC_ERR_HIP, e, "IR spectra");
   return true;
 }
 
 bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
              const float *const *irs, const size_t *ir_lens, size_t max_len) {
-  if (s->streams_ok || s->live) free_device_state(s);
+  // The reference's init() starts with reset() (TwoStageFFTConvolver.cpp:92, FFTConvolver.cpp:95).
+  // Here everything is released only when the new geometry differs; an IR swap with unchanged
+  // block sizes / partition counts (the plug-in's hot-swap, src/PluginProcessor.cpp:1680-1691)
+  // keeps every buffer and only re-uploads and re-transforms the IR.
+  auto drop = [&]() { if (s->streams_ok || s->live) free_device_state(s); };
   s->err = RVC_OK;
   s->errstr.clear();
   if (head_block == 0 || (two_stage && tail_block == 0)) {   // TwoStageFFTConvolver.cpp:94-97, FFTConvolver.cpp:97-100
+    drop();
     s->err = RVC_ERR_BAD_ARG;
     s->errstr = "block size 0";
     return false;
   }
-  if (!irs || !ir_lens) return fail(s, RVC_ERR_BAD_ARG, hipSuccess, "irs");
+  if (!irs || !ir_lens) { drop(); return fail(s, RVC_ERR_BAD_ARG, hipSuccess, "irs"); }
   if (two_stage && head_block > tail_block) std::swap(head_block, tail_block);   // :100-104
 
   // trailing |x| < 1e-6 is ignored (TwoStageFFTConvolver.cpp:107-110, FFTConvolver.cpp:102-106)
@@ -312,21 +317,18 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   const bool want64 = (s->flags & RVC_FLAG_FFT_F64) != 0;
   const size_t max_block = want64 ? RVC_MAX_BLOCK / 2 : RVC_MAX_BLOCK;
   if (hb > max_block || tb > max_block) {
+    drop();
     s->err = RVC_ERR_UNSUPPORTED;
     s->errstr = want64 ? "block size above RVC_MAX_BLOCK/2 (f64 FFT mode)" : "block size above RVC_MAX_BLOCK";
     return false;
   }
   if (longest == 0) {   // empty IR: success, process() gives zeros (:112-115)
+    drop();
     s->inited = true;
     s->head = hb; s->tail = tb; s->max_len = max_len ? max_len : hb;
     return true;
   }
-  if (!ensure_streams(s)) return false;
-  if (!use_device(s)) return false;
-
-  s->head = hb;
-  s->tail = tb;
-  s->max_len = max_len ? max_len : hb;
+  const size_t eff_max_len = max_len ? max_len : hb;
   const size_t split = two_stage ? 2 * tb : (size_t)-1;
 
   // partition counts (ceil(float/float) as FFTConvolver.cpp:115; exact below 2^24 samples)
@@ -340,6 +342,29 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   }
   if (pt > 0)   // the tail stage keeps the WHOLE IR at block T (see Stage::PF)
     for (int c = 0; c < s->nch; ++c) partsT[c].assign(irs[c], irs[c] + len[c]);
+
+  // ---- IR swap with unchanged geometry: keep all device state, refresh the spectra ----
+  if (s->live && s->two_stage == two_stage && s->head == hb && s->tail == tb && s->max_len == eff_max_len &&
+      s->A.P == (int)pa && s->T.P == (int)pt) {
+    if (!use_device(s)) return false;
+    hipStreamSynchronize(s->st_bg);
+    hipStreamSynchronize(s->st_main);
+    for (auto &j : s->jobs) s->ev_pool.push_back(j.ev);
+    s->jobs.clear();
+    if (!upload_ir_stage(s, s->A, partsA)) { free_device_state(s); return false; }
+    if (pt > 0 && !upload_ir_stage(s, s->T, partsT)) { free_device_state(s); return false; }
+    s->n = 0; s->tail_fft_done = 0; s->tail_out_done = 2; s->xa_next = 0; s->ypre_block = -1;
+    return true;
+  }
+
+  drop();
+  if (!ensure_streams(s)) return false;
+  if (!use_device(s)) return false;
+
+  s->head = hb;
+  s->tail = tb;
+  s->two_stage = two_stage;
+  s->max_len = eff_max_len;
   Stage &A = s->A, &T = s->T;
   A.B = hb; A.logB = ilog2(hb); A.P = (int)pa; A.delay = 0; A.f64 = want64;
   A.mcap = s->max_len / hb + 2;

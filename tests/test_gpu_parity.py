@@ -474,3 +474,20 @@ def test_ir_hot_swap_matches_reference_sequence():
         assert rel_rms(got[c], want[c]) <= TOL
     fade = slice(31 * blk, 38 * blk)                      # the crossfade region itself
     assert np.sqrt(np.mean((got[:, fade].astype(np.float64) - want[:, fade]) ** 2)) <= 5e-6
+
+
+def test_reinit_same_geometry_keeps_buffers_and_is_exact():
+    """IR hot-swap: init() with a new IR of unchanged geometry re-uses all device state (fast path);
+    with a different partition count it rebuilds. Either way the result is that of a fresh object."""
+    x = synth.synth_input(512 * 60, 0)
+    ir_a = synth.synth_ir(50000, 1, 80)[0]
+    ir_b = synth.synth_ir(50000, 1, 81)[0]          # same length -> same partition counts
+    ir_c = synth.synth_ir(23000, 1, 82)[0]          # fewer tail partitions -> full re-init
+    s = reevr_amd.TwoStageFFTConvolver()
+    assert s.init(512, 8192, ir_a)
+    s.process(x[:512 * 37 + 100])                   # leave it mid-block with history
+    for ir in (ir_b, ir_c, ir_a):
+        assert s.init(512, 8192, ir)
+        got = np.concatenate([s.process(x[i:i + 512]) for i in range(0, len(x), 512)])
+        o = O.TwoStageFFTConvolver("orc"); assert o.init(512, 8192, ir)
+        assert rel_rms(got, o.process(x)) <= TOL
