@@ -62,7 +62,11 @@ class StereoConvolver {
     float *out[2] = {bufferLL.data(), bufferRR.data()};
     float *outx[2] = {bufferLR.data(), bufferRL.data()};   // LR is fed L, RL is fed R
     const bool cross = isQuad && !force2Chans;
-    if (nsamples > static_cast<size_t>(size)) {            // longer than prepare() announced: blocking, split inside
+    if (nsamples > static_cast<size_t>(size)) {            // longer than prepare() announced (the reference would
+      bufferLL.resize(nsamples); bufferRR.resize(nsamples);   // overrun its buffers): grow them, blocking call
+      bufferLR.resize(nsamples); bufferRL.resize(nsamples);
+      out[0] = bufferLL.data(); out[1] = bufferRR.data();
+      outx[0] = bufferLR.data(); outx[1] = bufferRL.data();
       rvc_set_process(_main, in, out, nsamples);
       if (cross) rvc_set_process(_cross, in, outx, nsamples);
       return;

@@ -291,6 +291,9 @@ class StereoConvolver:
         # StereoConvolver.cpp:33-42
         x = np.stack([_f32(dataL)[:nsamples], _f32(dataR)[:nsamples]])
         cross = self.isQuad and not force2Chans
+        if nsamples > len(self.bufferLL):        # the reference would overrun its buffers: grow them
+            for name in ("bufferLL", "bufferRR", "bufferLR", "bufferRL"):
+                setattr(self, name, np.zeros(nsamples, np.float32))
         if nsamples > self.size:                 # longer than prepare() announced: blocking, split inside
             y = self._main.process(x)
             z = self._cross.process(x) if cross else None

@@ -908,7 +908,12 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
     return *reinterpret_cast<const float4 *>(Hc + (long long)ii * B + lc);
   };
   auto stageH = [&](float2 (*dst)[64], const float4 h) { *reinterpret_cast<float4 *>(&dst[lr][lc]) = h; };
-  auto sXrow = [&](long long row) -> float2 * { return &sX[(int)((unsigned long long)row & (RING - 1))][0]; };
+  // ring slot of an input row, counted from row R0-8: the 8 rows a wave consumes in one chunk then
+  // always sit in one aligned group of 8 slots (never wrap), so the per-step LDS address is a
+  // per-chunk base plus a compile-time offset
+  auto sXrow = [&](long long row) -> float2 * {
+    return &sX[(int)((unsigned long long)(row - R0 + CH) & (RING - 1))][0];
+  };
 
   // prologue. Register window of wave w = rows cbase .. cbase+15 (from global, one 8-byte load
   // each); waves 0..2 also publish theirs into the ring (rows R0 .. R0+47 are what the other
@@ -950,12 +955,14 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
     }
     // operands of step u+1 are read from LDS while step u's FMAs issue (one exposed LDS latency
     // per chunk instead of one per step)
+    // rows cbase-8j-1-u, u = 0..7, are slots g*8 + (7-u) of group g = (2*wave - j) & 7
+    const float2 *xgrp = &sX[((2 * wave - j) & 7) * CH][0] + lane;
     auto operands = [&](const int u, float2 &hh, float2 &xin) {
 #ifdef RVC_ABLATE_NOLDSREAD
       hh = make_float2(1.f + u, 0.5f); xin = make_float2(0.25f * u, 1.f);
 #else
       hh = sH[PH][u][lane];
-      xin = sXrow(cbase - (long long)(j * CH + u) - 1)[lane];
+      xin = xgrp[(CH - 1 - u) * 64];
 #endif
     };
     auto fmas = [&](const float2 hh, const float2 xin, const int u16) {
@@ -972,14 +979,12 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
       w[(TK - 1 - u16) & (TK - 1)] = xin;                 // zero for rows < 0 was applied when staged
     };
     if (wave_active) {     // a wave whose 16 rows lie beyond M only helps with staging and barriers
-      float2 hh, xin;
-      operands(0, hh, xin);
+      float2 hq[2], xq[2];   // ping-pong operand registers (static indices after unrolling: no copies)
+      operands(0, hq[0], xq[0]);
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
-        float2 hn = hh, xn = xin;
-        if (u + 1 < CH) operands(u + 1, hn, xn);
-        if (j * CH + u < P) fmas(hh, xin, PH * CH + u);   // uniform (only the last chunk can be partial)
-        hh = hn; xin = xn;
+        if (u + 1 < CH) operands(u + 1, hq[(u + 1) & 1], xq[(u + 1) & 1]);
+        if (j * CH + u < P) fmas(hq[u & 1], xq[u & 1], PH * CH + u);   // uniform (only the last chunk can be partial)
       }
     }
     if (j + 1 < nchunks) {
