@@ -1,0 +1,36 @@
+# Top-level convenience targets (plain make; no cmake needed).
+#   make            libreevr_amd.so (hipcc, gfx950) + the oracle's C restatement
+#   make ref        the untouched reference built where it lies (needs /root/reference)
+#   make example    examples/host_block_loop (g++, links the C ABI)
+#   make test       CPU test-suite;   make test-gpu   on an MI355X
+HIPCC ?= /opt/rocm/bin/hipcc
+CSRC  := reevr_amd/csrc
+LIB   := $(CSRC)/libreevr_amd.so
+
+all: $(LIB) oracle
+
+$(LIB): $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_engine.cpp $(CSRC)/rvc_internal.h include/reevr_amd/rvc.h
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip -ffp-contract=fast \
+	  -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -o $@ $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_engine.cpp
+
+oracle:
+	$(MAKE) -C oracle
+
+ref:
+	$(MAKE) -C oracle ref
+
+example: $(LIB)
+	g++ -O2 -std=c++17 -I include examples/host_block_loop.cpp -L $(CSRC) -lreevr_amd \
+	  -Wl,-rpath,'$$ORIGIN/../$(CSRC)' -o examples/host_block_loop
+
+test: all
+	python -m pytest tests -q -m "not gpu"
+
+test-gpu: all
+	python -m pytest tests -q -m gpu
+
+clean:
+	rm -f $(LIB) examples/host_block_loop
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle ref example test test-gpu clean

@@ -514,7 +514,7 @@ bool wait_tail_jobs(rvc_set *s, long long n1) {
 // Forward transforms of head blocks [k_lo, k_hi] (samples at or beyond n_hi read as zero: the
 // unplayed rest of a partly filled block).
 bool head_spectra(rvc_set *s, long long k_lo, long long k_hi, long long n_hi, const float *src2,
-                  size_t in_stride, long long src2_from) {
+                  size_t in_stride, long long src2_from, long long ring_from = -1) {
   Stage &A = s->A;
   const long long hb = (long long)A.B;
   rvc::FwdArgs f{};
@@ -523,6 +523,10 @@ bool head_spectra(rvc_set *s, long long k_lo, long long k_hi, long long n_hi, co
   f.seg0 = (k_lo - 1) * hb; f.valid_len = (int)(2 * hb); f.lo = 0; f.hi = n_hi;
   f.tw = A.twp(); f.wsplit = A.wsp(); f.tw8 = A.t8p();
   f.dst = A.X; f.dst_chan_stride = (long long)A.rows * hb; f.row0 = k_lo; f.row_mask = A.rows - 1;
+  if (ring_from >= 0) {   // the transform kernel also appends the call's recent samples to the time ring
+    f.ring_out = s->xring; f.ring_out_chan_stride = (long long)s->ring_cap; f.ring_out_mask = s->ring_cap - 1;
+    f.ring_out_from = ring_from;
+  }
   Timer t(s, 1, s->st_main);
   RVC_CK(rvc::launch_fft_fwd(A.logB, A.f64, f, (int)(k_hi - k_lo + 1), s->nch, s->st_main));
   return true;
@@ -539,13 +543,13 @@ long long head_fft_from(const rvc_set *s, long long ka) {
 // Zero-latency stage over samples [na, nb) of the current call (which starts at n0): FFT, delay
 // line, inverse FFT + tail ring -> d_out[na - n0 ..).
 bool head_stage(rvc_set *s, long long n0, long long na, long long nb, const float *src2, size_t in_stride,
-                float *d_out, size_t out_stride, bool bg) {
+                float *d_out, size_t out_stride, bool bg, long long ring_from = -1) {
   Stage &A = s->A, &T = s->T;
   const bool has_tail = T.P > 0;
   const long long hb = (long long)A.B;
   const long long ka = na / hb, kb = (nb - 1) / hb;
   const int M = (int)(kb - ka + 1);
-  if (!head_spectra(s, head_fft_from(s, ka), kb, nb, src2, in_stride, n0)) return false;
+  if (!head_spectra(s, head_fft_from(s, ka), kb, nb, src2, in_stride, n0, ring_from)) return false;
   s->xa_next = (nb % hb == 0) ? kb + 1 : kb;
   rvc::FirArgs r{};
   r.H = A.H; r.h_chan_stride = (long long)A.P * hb;
@@ -663,7 +667,9 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   const bool adaptive = has_tail && !bg && (s->flags & RVC_FLAG_FIXED_PARTITIONS) == 0 &&
                         ((n1 - 1) / tbq - n0 / tbq) >= 3;
   const bool fft_ingests = adaptive && fuse_in && rvc::fwd_appends_ring(T.logB) && (n0 / tbq) >= s->tail_fft_done;
-  if (!fft_ingests) {
+  // (likewise the head stage's forward transform when the call goes through the two-stage path)
+  const bool head_ingests = !adaptive && fuse_in && rvc::fwd_appends_ring(A.logB);
+  if (!fft_ingests && !head_ingests) {
     rvc::IngestArgs a{};
     const long long skip = fuse_in ? (long long)len - keep : 0;
     a.src = d_in + skip; a.src_chan_stride = (long long)in_stride;
@@ -741,7 +747,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
 
   // 3. two-stage path: tail job one period ahead, then the zero-latency stage over the whole call
   if (has_tail && !run_tail_job(s, n0, n1, src2, in_stride, bg)) return false;
-  if (!head_stage(s, n0, n0, n1, src2, in_stride, d_out, out_stride, bg)) return false;
+  if (!head_stage(s, n0, n0, n1, src2, in_stride, d_out, out_stride, bg, head_ingests ? n1 - keep : -1)) return false;
   s->n = n1;
   return true;
 }
