@@ -278,6 +278,10 @@ template <int LOGB> struct Plan8 {
     if constexpr (Q == 1) return in_idx(tid, e);
     else return tid + (e / Q) * NT + (e % Q) * (B / Q);
   }
+  // whether out_idx(tid, e) < B/2 -- a property of e alone (tid + (..)*NT stays below the leg stride)
+  __host__ __device__ static constexpr bool out_is_low(int e) {
+    return Q == 1 ? (e & 7) < 4 : (e % Q) < Q / 2;
+  }
 };
 
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
@@ -508,40 +512,50 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
       }
     }
   }
-  C ws[P::E];                                   // split twiddles: requested before the transform when
-  constexpr bool kEager = Tw8<LOGB, R>::EAGER;  // the register budget allows, else after it
-  if constexpr (kEager) {
+  // Real split in PAIRS: the values a thread holds after the transform are half "low" bins
+  // (k < B/2) and half "high" bins (compile-time: see Plan8::out_is_low). From its low Z[k] and the
+  // partner Z[B-k] (one LDS read) a thread produces BOTH X[k] = E + w^k O and X[B-k] = conj(E - w^k O):
+  // one split twiddle, one partner read and one E/O evaluation per two output bins.
+  C ws[P::E / 2];
+  constexpr bool kEager = Tw8<LOGB, R>::EAGER;   // twiddles requested before the transform when registers allow
+  auto load_ws = [&]() {
+    int q = 0;
 #pragma unroll
-    for (int e = 0; e < P::E; ++e) ws[e] = wsplit[P::out_idx(tid, e)];
-  }
+    for (int e = 0; e < P::E; ++e)
+      if (P::out_is_low(e)) ws[q++] = wsplit[P::out_idx(tid, e)];
+  };
+  if constexpr (kEager) load_ws();
   fft8_core<LOGB, false, R>(v, lds, T, tid);
-  if constexpr (!kEager) {
-#pragma unroll
-    for (int e = 0; e < P::E; ++e) ws[e] = wsplit[P::out_idx(tid, e)];
-  }
+  if constexpr (!kEager) load_ws();
 
-  // real split through LDS: X[k] = E + w^k O with the partner Z[B-k] held by another thread
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = v[e];
+  for (int e = 0; e < P::E; ++e)
+    if (!P::out_is_low(e)) lds[lpad(P::out_idx(tid, e))] = v[e];   // only the high half is ever fetched by a partner
   __syncthreads();
   float2 *dst = a.dst + (long long)c * a.dst_chan_stride +
                 (long long)(((unsigned long long)(a.row0 + r_)) & a.row_mask) * B;
   const R half = (R)0.5;
   if (!live) return;                                   // (after the last barrier)
+  int q = 0;
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int k = P::out_idx(tid, e);
     const C A = v[e];
-    if (k == 0) {
-      dst[0] = make_float2((float)(A.x + A.y), (float)(A.x - A.y));   // packed (DC, Nyquist)
-    } else {
-      const C Bc = cconj(lds[lpad(B - k)]);
-      const C Ev = mk<R>(half * (A.x + Bc.x), half * (A.y + Bc.y));
-      const C D = mk<R>(half * (A.x - Bc.x), half * (A.y - Bc.y));
-      const C O = mk<R>(D.y, -D.x);                  // -i * D
-      const C X = cadd(Ev, cmul(ws[e], O));          // wsplit has B entries: e^{-i pi k / B}
-      dst[k] = make_float2((float)X.x, (float)X.y);
+    if (P::out_is_low(e)) {
+      const C w = ws[q++];
+      if (k == 0) {
+        dst[0] = make_float2((float)(A.x + A.y), (float)(A.x - A.y));   // packed (DC, Nyquist)
+      } else {
+        const C Bc = cconj(lds[lpad(B - k)]);
+        const C Ev = mk<R>(half * (A.x + Bc.x), half * (A.y + Bc.y));
+        const C D = mk<R>(half * (A.x - Bc.x), half * (A.y - Bc.y));
+        const C wO = cmul(w, mk<R>(D.y, -D.x));        // w^k * (-i D)
+        dst[k] = make_float2((float)(Ev.x + wO.x), (float)(Ev.y + wO.y));
+        dst[B - k] = make_float2((float)(Ev.x - wO.x), (float)(wO.y - Ev.y));   // conj(E - w^k O)
+      }
+    } else if (k == B / 2) {
+      dst[k] = make_float2((float)A.x, (float)-A.y);   // X[B/2] = conj(Z[B/2]) (its own partner)
     }
   }
 }
