@@ -579,26 +579,39 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   const C *tw8 = reinterpret_cast<const C *>(a.tw8);
   const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
 
-  // Z[k] = E + iO straight from global: Y[k] ascending and Y[B-k] descending are both coalesced
+  // Inverse split in PAIRS (mirror of the forward kernel): the first pass wants Z[in_idx(e)]; half of a
+  // thread's indices are "low" (k < B/2). For each low k it loads Y[k], Y[B-k] and one twiddle and
+  // forms BOTH Z[k] = E + iO (kept) and Z[B-k] = conj(E) + i conj(O) (handed to its owner through
+  // LDS). One exchange instead of loading every Y twice and every twiddle once per bin.
   Tw8<LOGB, R> T;
   T.load(tw8, tw, tid);
   C v[P::E];
   const R sc = (R)0.5 / (R)B;
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
-    const int k = P::in_idx(tid, e);
-    const float2 yk = Y[k];
-    if (k == 0) {
-      v[e] = mk<R>(sc * ((R)yk.x + (R)yk.y), sc * ((R)yk.x - (R)yk.y));
-    } else {
-      const float2 yc = Y[B - k];
-      const C Yk = mk<R>((R)yk.x, (R)yk.y), Yc = mk<R>((R)yc.x, -(R)yc.y);
-      const C Ev = mk<R>(sc * (Yk.x + Yc.x), sc * (Yk.y + Yc.y));
-      const C D = mk<R>(sc * (Yk.x - Yc.x), sc * (Yk.y - Yc.y));
-      const C O = cmul(cconj(wsplit[k]), D);
-      v[e] = mk<R>(Ev.x - O.y, Ev.y + O.x);
+    if ((e & 7) < 4) {                                   // in_idx(tid, e) < B/2
+      const int k = P::in_idx(tid, e);
+      const float2 yk = Y[k];
+      if (k == 0) {
+        v[e] = mk<R>(sc * ((R)yk.x + (R)yk.y), sc * ((R)yk.x - (R)yk.y));
+        const float2 yh = Y[B / 2];                      // and the self-paired bin B/2: Z = conj(Y) / B
+        lds[lpad(B / 2)] = mk<R>((R)2 * sc * (R)yh.x, -(R)2 * sc * (R)yh.y);
+      } else {
+        const float2 yc = Y[B - k];
+        const C Yk = mk<R>((R)yk.x, (R)yk.y), Yc = mk<R>((R)yc.x, -(R)yc.y);
+        const C Ev = mk<R>(sc * (Yk.x + Yc.x), sc * (Yk.y + Yc.y));
+        const C D = mk<R>(sc * (Yk.x - Yc.x), sc * (Yk.y - Yc.y));
+        const C O = cmul(cconj(wsplit[k]), D);
+        v[e] = mk<R>(Ev.x - O.y, Ev.y + O.x);            // Z[k]   = E + iO
+        lds[lpad(B - k)] = mk<R>(Ev.x + O.y, O.x - Ev.y);   // Z[B-k] = conj(E) + i conj(O)
+      }
     }
   }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < P::E; ++e)
+    if ((e & 7) >= 4) v[e] = lds[lpad(P::in_idx(tid, e))];
+  __syncthreads();                                       // the transform's first exchange overwrites the buffer
   fft8_core<LOGB, true, R>(v, lds, T, tid);
 
   // z[m] = (s[2m], s[2m+1]); the overlap-save output is s[B..2B) = z[B/2..B): 8-byte stores
