@@ -23,6 +23,7 @@ int main(int argc, char **argv) {
   const int block = argc > 1 ? std::atoi(argv[1]) : 512;
   const int sr = 48000, ir_len = 10 * sr, blocks = argc > 2 ? std::atoi(argv[2]) : 4000;
   const bool quad = argc > 3 && std::atoi(argv[3]) != 0;
+  const int gap_us = argc > 4 ? std::atoi(argv[4]) : 0;   // idle time between calls (a real host sleeps ~10 ms)
   if (rvc_device_count() < 1) { std::puts("no GPU: this engine has no CPU fallback"); return 2; }
 
   Impulse imp;
@@ -60,14 +61,18 @@ int main(int argc, char **argv) {
     conv.process(L.data(), R.data(), (size_t)block);
     auto z = std::chrono::steady_clock::now();
     if (b >= 200) us[b - 200] = std::chrono::duration<double, std::micro>(z - a).count();
+    if (gap_us > 0) {   // busy-wait: lets the deferred work (next block's pre-multiply, tail job) drain
+      const auto until = z + std::chrono::microseconds(gap_us);
+      while (std::chrono::steady_clock::now() < until) {}
+    }
     checksum += conv.bufferLL[block / 2] + conv.bufferRR[block / 3];
   }
   std::sort(us.begin(), us.end());
   double sum = 0;
   for (double u : us) sum += u;
-  std::printf("{\"block\": %d, \"channels\": %d, \"loadImpulse_ms\": %.2f, \"reloadImpulse_ms\": %.2f, \"call_us_median\": %.1f, \"call_us_p99\": %.1f, "
+  std::printf("{\"block\": %d, \"gap_us\": %d, \"channels\": %d, \"loadImpulse_ms\": %.2f, \"reloadImpulse_ms\": %.2f, \"call_us_median\": %.1f, \"call_us_p99\": %.1f, "
               "\"call_us_max\": %.1f, \"Msamples_per_s\": %.2f, \"block_period_us\": %.1f, \"checksum\": %.6f}\n",
-              block, quad ? 4 : 2, load_ms, reload_ms, us[blocks / 2], us[(size_t)(blocks * 0.99)], us.back(),
+              block, gap_us, quad ? 4 : 2, load_ms, reload_ms, us[blocks / 2], us[(size_t)(blocks * 0.99)], us.back(),
               (quad ? 4.0 : 2.0) * block * blocks / sum, 1e6 * block / sr, checksum);
   return 0;
 }

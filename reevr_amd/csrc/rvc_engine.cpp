@@ -112,6 +112,7 @@ struct rvc_set {
 
   size_t pending_len = 0;        // rvc_set_process_begin without its _end yet
   bool pending_ok = false;
+  bool zero_copy = false;        // this host-pointer call lets the fused kernel read/write the pinned buffers itself
   size_t out_copy_len = 0;       // host-pointer call in flight: copy d_out -> h_out as soon as the output
   hipEvent_t ev_out = nullptr;   // kernel is enqueued (before the off-critical-path work) and mark it here
 
@@ -602,7 +603,8 @@ bool emit_output_copy(rvc_set *s) {
   if (s->out_copy_len == 0) return true;
   const size_t len = s->out_copy_len;
   s->out_copy_len = 0;
-  RVC_CK(hipMemcpyAsync(s->h_out, s->d_out, sizeof(float) * len * s->nch, hipMemcpyDeviceToHost, s->st_main));
+  if (!s->zero_copy)
+    RVC_CK(hipMemcpyAsync(s->h_out, s->d_out, sizeof(float) * len * s->nch, hipMemcpyDeviceToHost, s->st_main));
   RVC_CK(hipEventRecord(s->ev_out, s->st_main));
   return true;
 }
@@ -843,9 +845,17 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   if (len > s->max_len) { fail(s, RVC_ERR_BAD_ARG, hipSuccess, "process_begin: len > max_len"); return; }
   if (!use_device(s)) return;
   for (int c = 0; c < s->nch; ++c) std::memcpy(s->h_in + (size_t)c * len, in[c], len * sizeof(float));
-  bool ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * len * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
-  s->out_copy_len = len;                       // step_device emits the copy-back right behind the output kernel
-  ok = ok && step_device(s, s->d_in, len, s->d_out, len, len);
+  // Per-block calls (the latency path: one fused launch) skip both DMA copies: the pinned staging
+  // buffers are device-visible, the kernel reads its 2 KB per channel over PCIe and writes the
+  // result straight back; the host waits for the event behind that kernel. Longer calls use DMA.
+  const long long hb = (long long)s->A.B;
+  s->zero_copy = rvc::fused_supported(s->A.logB, s->A.f64) && (s->n / hb) == ((s->n + (long long)len - 1) / hb);
+  bool ok = true;
+  if (!s->zero_copy)
+    ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * len * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
+  s->out_copy_len = len;                       // step_device emits the copy-back / event right behind the output kernel
+  ok = ok && (s->zero_copy ? step_device(s, s->h_in, len, s->h_out, len, len)
+                           : step_device(s, s->d_in, len, s->d_out, len, len));
   ok = ok && emit_output_copy(s);              // (paths whose last kernel is the output kernel)
   s->out_copy_len = 0;
   if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_begin");
