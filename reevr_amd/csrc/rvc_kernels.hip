@@ -1,23 +1,30 @@
 // rvc_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the partitioned-convolution engine.
 //
 // Replaces, on the device, the reference's CPU loops (paths relative to the reference tree):
-//   k_fft_fwd   OouraFFT::fft            libs/FFTConvolver/AudioFFT.cpp:114-137  (+ CopyAndPad, Utilities.h:311-317)
-//   k_fir       ComplexMultiplyAccumulate libs/FFTConvolver/Utilities.cpp:62-111, driven by FFTConvolver.cpp:176-187
-//   k_fft_inv   OouraFFT::ifft           AudioFFT.cpp:139-159 (+ Sum / overlap, FFTConvolver.cpp:193,204;
-//                                         tail add-back TwoStageFFTConvolver.cpp:171-190)
+//   k_fft8_fwd / k_fft_fwd     OouraFFT::fft   libs/FFTConvolver/AudioFFT.cpp:114-137 (+ CopyAndPad, Utilities.h:311-317)
+//   k_fir_lds / k_fir / k_fir_row   ComplexMultiplyAccumulate   libs/FFTConvolver/Utilities.cpp:62-111,
+//                                   driven by FFTConvolver.cpp:176-187
+//   k_fft8_inv / k_fft_inv     OouraFFT::ifft  AudioFFT.cpp:139-159 (+ Sum / overlap, FFTConvolver.cpp:193,204;
+//                                              tail add-back TwoStageFFTConvolver.cpp:171-190)
+//   k_fused_block              one whole per-block process() call (TwoStageFFTConvolver.cpp:151-233, len <= head)
+//   k_ingest                   the memcpy into _inputBuffer / _tailInput (FFTConvolver.cpp:166-169, TwoStage..:196-197)
 //
 // Design notes (DESIGN.md has the full picture):
 //  * wave64 everywhere; no MFMA -- this is a pointwise / FFT path (arithmetic intensity ~1 flop/B).
-//  * One workgroup = one 2B-point real transform, done as a B-point complex Stockham FFT
-//    (radix-4 passes + one radix-2 pass when log2 B is odd) entirely in LDS, followed /
-//    preceded by the real split. LDS holds B float2 (<= 128 KiB of the CU's 160 KiB).
+//  * One workgroup = one 2B-point real transform (several for B < 512), done as a B-point complex
+//    FFT followed / preceded by the real split. B >= 64: radix-8 Stockham with the butterflies in
+//    registers and padded-LDS exchanges between passes (Plan8 / fft8_core); B < 64: generic
+//    radix-4/2 passes in LDS (cfft_lds). Scalar type float, or double for RVC_FLAG_FFT_F64 and
+//    for the IR spectra at init.
 //  * Overlap-SAVE instead of the reference's overlap-add: the segment of block k is
 //    [x_{k-1}; x_k], the last B samples of the inverse are the output. Same linear
 //    convolution, no overlap buffer and no dependency between output blocks.
-//  * k_fir is the frequency-domain delay line as a per-bin complex FIR over block time.
-//    lane = bin (coalesced 512 B per wave per row), each thread keeps TK consecutive output
-//    blocks in registers and slides a TK-row window of input spectra, so every IR row that
-//    is loaded is used TK times (time tiling; TK = 1 is the streaming case).
+//  * The frequency-domain delay line is a per-bin complex FIR over block time. lane = bin
+//    (coalesced 512 B per wave per row); each thread keeps 16 consecutive output blocks in
+//    registers and slides a 16-row window of input spectra, so every IR row loaded is used 16
+//    times per wave and 64 times per workgroup (k_fir_lds stages both operands in LDS).
+//  * RVC_ABLATE_* macros (off by default) knock out one ingredient of a kernel for the
+//    ablation measurements quoted in DESIGN.md; they produce wrong results by design.
 #include "rvc_internal.h"
 
 #include <hip/hip_ext.h>
