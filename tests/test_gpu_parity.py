@@ -491,3 +491,37 @@ def test_reinit_same_geometry_keeps_buffers_and_is_exact():
         got = np.concatenate([s.process(x[i:i + 512]) for i in range(0, len(x), 512)])
         o = O.TwoStageFFTConvolver("orc"); assert o.init(512, 8192, ir)
         assert rel_rms(got, o.process(x)) <= TOL
+
+
+def test_device_entry_with_misaligned_views_and_strides():
+    """rvc_set_process_device on tensor VIEWS: pointers that are only 4-byte aligned and row strides
+    larger than the call (the vectorised 8/16-byte paths must fall back, not misread)."""
+    import torch
+    ir = synth.synth_ir(40000, 2, 95)
+    frames = 8192 * 6 + 37
+    x = np.stack([synth.synth_input(frames, c) for c in range(2)])
+    want = []
+    for c in range(2):
+        o = O.TwoStageFFTConvolver("orc"); assert o.init(512, 8192, ir[c])
+        want.append(o.process(x[c]))
+    want = np.stack(want)
+    for off_in, off_out in ((1, 3), (2, 1), (0, 0), (3, 2)):
+        big_in = torch.zeros(2, frames + 8, device="cuda")
+        big_out = torch.zeros(2, frames + 8, device="cuda")
+        big_in[:, off_in:off_in + frames] = torch.from_numpy(x).cuda()
+        s = reevr_amd.ConvolverSet(2)
+        assert s.init(512, 8192, list(ir), max_len=frames)
+        # one long call (adaptive path, input read in place), then the same stream in awkward pieces
+        s.process_device(big_in[:, off_in:off_in + frames], big_out[:, off_out:off_out + frames])
+        got = big_out[:, off_out:off_out + frames].cpu().numpy()
+        for c in range(2):
+            assert rel_rms(got[c], want[c]) <= TOL
+        s.clear()
+        pos = 0
+        for n in (511, 513, 8191, 20000, frames - 29215):
+            s.process_device(big_in[:, off_in + pos:off_in + pos + n], big_out[:, off_out + pos:off_out + pos + n])
+            pos += n
+        assert pos == frames
+        got = big_out[:, off_out:off_out + frames].cpu().numpy()
+        for c in range(2):
+            assert rel_rms(got[c], want[c]) <= TOL
