@@ -259,6 +259,10 @@ def main():
                         "time. The kernel tiles 64 blocks of time per workgroup and, for long calls, uses 8192-sample "
                         "partitions for the whole IR, so physical HBM traffic (`traffic`) is ~50x below the "
                         "algorithmic figure: frac > 1 is expected, the kernel is fp32-FMA bound (DESIGN.md 7)."}
+    # every timed kernel family against the HBM roofline (algorithmic numerator), for the record
+    roof_all = {k: {"avg_launch_ms": round(v["avg_ms"], 5),
+                    "achieved_GBs": round(alg[k] / (v["avg_ms"] * 1e-3) / 1e9, 1),
+                    "frac": round(alg[k] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in kern.items()}
     bps = alg_bytes_per_sample(head, tail, IR_LEN)
     path_gbs = value / world * 1e6 * bps / 1e9
 
@@ -310,9 +314,12 @@ def main():
                    "partitions": {"head+tail0": PA, "tail": PT},
                    "call": "one process() per step, device-resident I/O", "gather": do_gather,
                    "partitioning": "fixed head/tail" if not adaptive else
-                                   "adaptive: long call -> one uniform delay line at the tail block size (P = %d)" % (PT + 2),
+                                   ("adaptive: long call -> one uniform delay line at block 16384 (P = %d)" % conv.partitions(2)
+                                    if conv.partitions(2) > 0 and frames >= 4 * 16384 else
+                                    "adaptive: long call -> one uniform delay line at the tail block size (P = %d)" % (PT + 2)),
                    "sharding": "one independent stereo instance per rank (unit mod world), no data-path collective"},
         "roofline": roof,
+        "roofline_all": roof_all,
         "path_roofline": {"alg_bytes_per_sample": round(bps, 1), "achieved_GBs_per_gpu": round(path_gbs, 1),
                           "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4),
                           "x_realtime_per_gpu": round(value / world * 1e6 / (SR * nch), 1)},

@@ -59,7 +59,9 @@ enum {
                                    call (>= 5 tail blocks) computes the tail blocks that lie entirely
                                    inside it with ONE uniform delay line at the tail block size over the
                                    whole IR -- same result (it does not depend on partition sizes), no
-                                   512-sample work where no 512-sample latency is needed. */
+                                   512-sample work where no 512-sample latency is needed; a call spanning
+                                   >= 4 blocks of 16384 uses a delay line at THAT size when the IR is long
+                                   enough (float transforms, max_len >= 65536). */
 
 /* ---- lifetime ---------------------------------------------------------------------- */
 
@@ -142,8 +144,9 @@ int rvc_set_channels(const rvc_set *s);
 size_t rvc_set_head_block(const rvc_set *s);   /* after rounding; 0 before init */
 size_t rvc_set_tail_block(const rvc_set *s);   /* 0 for a uniform (single-stage) set */
 size_t rvc_set_max_len(const rvc_set *s);
-/* partitions of the zero-latency stage (head + tail0 merged) and of the tail stage */
-int rvc_set_partitions(const rvc_set *s, int stage /*0 = head, 1 = tail*/);
+/* partitions of the zero-latency stage (head + tail0 merged), of the tail stage, and of the wide
+ * stage (whole IR at block 16384, used by very long calls; 0 when absent) */
+int rvc_set_partitions(const rvc_set *s, int stage /*0 = head, 1 = tail, 2 = wide*/);
 /* hipStream_t of the foreground stream, as void*; (stage 1: the tail stream) */
 void *rvc_set_stream(rvc_set *s, int which);
 int rvc_last_error(const rvc_set *s);

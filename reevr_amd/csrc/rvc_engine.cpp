@@ -90,6 +90,12 @@ struct rvc_set {
   size_t head = 0, tail = 0, max_len = 0;
   bool two_stage = false;
   Stage A, T;
+  Stage W;                       // optional "wide" stage: the whole IR at block 16384, used by calls that span
+                                 // several such blocks (P = irLen/16384: half the delay-line work of stage T)
+  long long w_next = 0;          // wide delay line: rows [w_next-P+1, w_next) are valid (cf. xa_next)
+  long long xt_valid_lo = 0;     // tail delay line: rows [xt_valid_lo, tail_fft_done) hold spectra; a wide call
+                                 // skips the tail transforms, later short calls rebuild what they need
+  long long keep = 0;            // input history (samples) a long call leaves in the time ring
   float *xring = nullptr, *tailring = nullptr;
   size_t ring_cap = 0;
   float2 *ypre = nullptr;        // [nch][head block]: pre-multiplied accumulator of block ypre_block
@@ -184,6 +190,7 @@ void free_device_state(rvc_set *s) {
   drop_timing(s);
   free_stage(s->A);
   free_stage(s->T);
+  free_stage(s->W);
   hipFree(s->xring); hipFree(s->tailring); hipFree(s->d_in); hipFree(s->d_out); hipFree(s->ypre);
   s->ypre = nullptr;
   s->ypre_block = -1;
@@ -198,6 +205,8 @@ void free_device_state(rvc_set *s) {
   s->tail_fft_done = 0;
   s->tail_out_done = 2;
   s->xa_next = 0;
+  s->w_next = 0;
+  s->xt_valid_lo = 0;
 }
 
 bool make_twiddles(rvc_set *s, Stage &g) {
@@ -343,10 +352,16 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   }
   if (pt > 0)   // the tail stage keeps the WHOLE IR at block T (see Stage::PF)
     for (int c = 0; c < s->nch; ++c) partsT[c].assign(irs[c], irs[c] + len[c]);
+  // wide stage: only for float transforms (136 KiB of LDS), a tail block below 16384 and an IR of
+  // several wide blocks; and only if calls can be long enough to use it
+  const size_t wb = (size_t)RVC_MAX_BLOCK;
+  const bool wide = pt > 0 && !want64 && tb < wb && longest > 4 * wb && eff_max_len >= 4 * wb &&
+                    (s->flags & (RVC_FLAG_FIXED_PARTITIONS | RVC_FLAG_BG_STREAM)) == 0;
+  const size_t pw = wide ? (longest + wb - 1) / wb : 0;
 
   // ---- IR swap with unchanged geometry: keep all device state, refresh the spectra ----
   if (s->live && s->two_stage == two_stage && s->head == hb && s->tail == tb && s->max_len == eff_max_len &&
-      s->A.P == (int)pa && s->T.P == (int)pt) {
+      s->A.P == (int)pa && s->T.P == (int)pt && s->W.P == (int)pw) {
     if (!use_device(s)) return false;
     hipStreamSynchronize(s->st_bg);
     hipStreamSynchronize(s->st_main);
@@ -354,7 +369,9 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     s->jobs.clear();
     if (!upload_ir_stage(s, s->A, partsA)) { free_device_state(s); return false; }
     if (pt > 0 && !upload_ir_stage(s, s->T, partsT)) { free_device_state(s); return false; }
+    if (pw > 0 && !upload_ir_stage(s, s->W, partsT)) { free_device_state(s); return false; }
     s->n = 0; s->tail_fft_done = 0; s->tail_out_done = 2; s->xa_next = 0; s->ypre_block = -1;
+    s->w_next = 0; s->xt_valid_lo = 0;
     return true;
   }
 
@@ -383,8 +400,24 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     RVC_CK(hipMalloc(&T.X, sizeof(float2) * (size_t)s->nch * T.rows * T.B));
     RVC_CK(hipMalloc(&T.Y, sizeof(float2) * (size_t)s->nch * T.mcap * T.B));
   }
+  Stage &W = s->W;
+  if (pw > 0) {
+    W.B = wb; W.logB = ilog2(wb); W.P = (int)pw; W.delay = 0; W.f64 = false;
+    W.mcap = s->max_len / wb + 3;
+    W.rows = next_pow2(pw + W.mcap + 2);
+    if (!make_twiddles(s, W)) return false;
+    if (!upload_ir_stage(s, W, partsT)) return false;      // partsT = the whole IR
+    RVC_CK(hipMalloc(&W.X, sizeof(float2) * (size_t)s->nch * W.rows * W.B));
+    RVC_CK(hipMalloc(&W.Y, sizeof(float2) * (size_t)s->nch * W.mcap * W.B));
+  }
+  // input history a long call must leave behind: 2 tail blocks for the tail transforms, P+2 head
+  // blocks for a rebuild of the head delay line; with a wide stage also a whole wide / tail delay
+  // line of history (their rows are rebuilt from the ring when the call pattern changes)
   const size_t span = std::max(hb, tb);
-  s->ring_cap = next_pow2(s->max_len + 6 * span + 4 * hb);
+  s->keep = 2 * (long long)span + ((long long)pa + 2) * (long long)hb;
+  if (pw > 0) s->keep = std::max<long long>(s->keep, std::max<long long>((long long)(pw + 2) * (long long)wb,
+                                                                        (long long)(pt + 4) * (long long)tb));
+  s->ring_cap = next_pow2(s->max_len + (size_t)s->keep + 6 * std::max(span, pw > 0 ? wb : (size_t)0) + 4 * hb);
   RVC_CK(hipMalloc(&s->xring, sizeof(float) * (size_t)s->nch * s->ring_cap));
   if (pt > 0) RVC_CK(hipMalloc(&s->tailring, sizeof(float) * (size_t)s->nch * s->ring_cap));
   RVC_CK(hipMalloc(&s->ypre, sizeof(float2) * (size_t)s->nch * A.B));
@@ -399,6 +432,8 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   s->tail_fft_done = 0;
   s->tail_out_done = 2;
   s->xa_next = 0;
+  s->w_next = 0;
+  s->xt_valid_lo = 0;
   s->live = true;
   s->inited = true;
   return true;
@@ -445,6 +480,25 @@ bool tail_spectra(rvc_set *s, long long n0, long long n1, const float *src2, siz
   return true;
 }
 
+// A wide call skips the tail transforms, so the tail delay line may have a hole below
+// xt_valid_lo. Rebuild rows [lo, xt_valid_lo) from the time ring (complete blocks; the ring keeps
+// a whole delay line of history when a wide stage exists).
+bool ensure_tail_spectra(rvc_set *s, long long lo, hipStream_t st) {
+  Stage &T = s->T;
+  if (lo < 0) lo = 0;
+  if (lo >= s->xt_valid_lo) return true;
+  const long long tb = (long long)T.B;
+  rvc::FwdArgs f{};
+  f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
+  f.seg0 = (lo - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = s->xt_valid_lo * tb;
+  f.tw = T.twp(); f.wsplit = T.wsp(); f.tw8 = T.t8p();
+  f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = lo; f.row_mask = T.rows - 1;
+  Timer t(s, 4, st);
+  RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64, f, (int)(s->xt_valid_lo - lo), s->nch, st));
+  s->xt_valid_lo = lo;
+  return true;
+}
+
 // Tail contributions (IR[2T,..), delivered two tail blocks late) for output blocks
 // [tail_out_done, m_hi) into the time-indexed tail ring. Needs spectra of blocks < m_hi - 2.
 bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
@@ -452,6 +506,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
   const long long tb = (long long)T.B;
   const long long m_lo = s->tail_out_done;
   if (m_hi <= m_lo) return true;
+  if (!ensure_tail_spectra(s, m_lo - 2 - (long long)T.P + 1, st)) return false;
   rvc::FirArgs r{};
   r.H = T.H + 2 * tb; r.h_chan_stride = (long long)T.PF * tb;       // partitions 2.. of the whole-IR table
   r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
@@ -662,13 +717,16 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   // can still need is copied: 2 tail blocks for the tail transforms, P+2 head blocks for a
   // rebuild of the head delay line. (With the tail on the second stream the job may outlive the
   // caller's buffer, so everything is copied; those calls are short.)
-  const long long keep = 2 * (long long)std::max(A.B, T.B) + ((long long)A.P + 2) * hb;
+  const long long keep = s->keep;
   const bool fuse_in = !bg && (long long)len > keep;
   // (the adaptive long-call path below lets its forward transform append the history: no ingest launch)
   const long long tbq = has_tail ? (long long)T.B : 1;
-  const bool adaptive = has_tail && !bg && (s->flags & RVC_FLAG_FIXED_PARTITIONS) == 0 &&
+  const long long wbq = s->W.P > 0 ? (long long)s->W.B : 1;
+  const bool wide = s->W.P > 0 && !bg && ((n1 - 1) / wbq - n0 / wbq) >= 3;
+  const bool adaptive = !wide && has_tail && !bg && (s->flags & RVC_FLAG_FIXED_PARTITIONS) == 0 &&
                         ((n1 - 1) / tbq - n0 / tbq) >= 3;
-  const bool fft_ingests = adaptive && fuse_in && rvc::fwd_appends_ring(T.logB) && (n0 / tbq) >= s->tail_fft_done;
+  const bool fft_ingests = (wide && fuse_in) ||
+                           (adaptive && fuse_in && rvc::fwd_appends_ring(T.logB) && (n0 / tbq) >= s->tail_fft_done);
   // (likewise the head stage's forward transform when the call goes through the two-stage path)
   const bool head_ingests = !adaptive && fuse_in && rvc::fwd_appends_ring(A.logB);
   if (!fft_ingests && !head_ingests) {
@@ -681,6 +739,63 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     RVC_CK(rvc::launch_ingest(a, s->nch, s->st_main));
   }
   const float *src2 = fuse_in ? d_in : nullptr;
+
+  // 2a. very long calls: the same idea one size up. A call touching >= 4 blocks of 16384 samples
+  // goes through the wide stage (whole IR at block 16384: half the partitions of stage T). Neither
+  // the head nor the tail stage runs; their state is rebuilt lazily by later, shorter calls.
+  if (wide) {
+    Stage &W = s->W;
+    const long long wb = (long long)W.B;
+    const long long m_first = n0 / wb, m_last = (n1 - 1) / wb;
+    long long fft_lo = m_first;
+    if (m_first > s->w_next) {                    // not contiguous with the last wide call: rebuild history rows
+      fft_lo = m_first - (long long)W.P + 1;
+      if (fft_lo < 0) fft_lo = 0;
+    }
+    {
+      rvc::FwdArgs f{};
+      f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
+      f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
+      f.seg0 = (fft_lo - 1) * wb; f.valid_len = (int)(2 * wb); f.lo = 0; f.hi = n1;
+      f.tw = W.twp(); f.wsplit = W.wsp(); f.tw8 = W.t8p();
+      f.dst = W.X; f.dst_chan_stride = (long long)W.rows * wb; f.row0 = fft_lo; f.row_mask = W.rows - 1;
+      if (fft_ingests) {
+        f.ring_out = s->xring; f.ring_out_chan_stride = (long long)s->ring_cap; f.ring_out_mask = s->ring_cap - 1;
+        f.ring_out_from = n1 - keep;
+      }
+      Timer t(s, 4, s->st_main);
+      RVC_CK(rvc::launch_fft_fwd(W.logB, false, f, (int)(m_last - fft_lo + 1), s->nch, s->st_main));
+    }
+    s->w_next = (n1 % wb == 0) ? m_last + 1 : m_last;
+    rvc::FirArgs r{};
+    r.H = W.H; r.h_chan_stride = (long long)W.P * wb;
+    r.X = W.X; r.x_chan_stride = (long long)W.rows * wb; r.x_row_mask = W.rows - 1;
+    r.Y = W.Y; r.y_chan_stride = (long long)W.mcap * wb;
+    r.k0 = m_first; r.M = (int)(m_last - m_first + 1); r.P = W.P; r.delay = 0; r.B = (int)wb; r.tag = 2;
+    {
+      Timer t(s, 5, s->st_main);
+      RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
+    }
+    rvc::InvArgs v{};
+    v.Y = W.Y; v.y_chan_stride = r.y_chan_stride; v.tw = W.twp(); v.wsplit = W.wsp(); v.tw8 = W.t8p();
+    v.blk0 = m_first;
+    v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
+    v.lo = n0; v.hi = n1;
+    v.add = nullptr;
+    {
+      Timer t(s, 6, s->st_main);
+      RVC_CK(rvc::launch_fft_inv(W.logB, false, v, r.M, s->nch, s->st_main));
+    }
+    // the tail stage saw none of this: its transforms are marked missing (rebuilt on demand) and the
+    // tail-ring rows of blocks delivered directly are never needed
+    const long long tb = (long long)T.B;
+    s->tail_fft_done = n1 / tb;
+    s->xt_valid_lo = s->tail_fft_done;
+    const long long done = (n1 % tb == 0) ? (n1 - 1) / tb + 1 : (n1 - 1) / tb;
+    if (s->tail_out_done < done) s->tail_out_done = done;
+    s->n = n1;
+    return true;
+  }
 
   // 2. adaptive partitioning for long calls. The result does not depend on the partition sizes,
   // only the latency does -- and a call that hands over many tail blocks at once has no use for
@@ -696,6 +811,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       const long long ring_from = fft_ingests ? n1 - keep : -1;
       const long long mb0 = s->tail_fft_done, mb1 = n1 / tb;
       const int extra = (n1 % tb != 0) ? 1 : 0;       // the partly filled block the call ends in
+      if (!ensure_tail_spectra(s, m_first - (long long)T.PF + 1, s->st_main)) return false;   // (after a wide call)
       // (A two-way pipeline over block time -- second half's transforms on the side stream under the
       // first half's delay line -- was measured and lost 35 %: each half-size launch keeps ~8 us of
       // fixed cost. One launch per stage it is.)
@@ -911,6 +1027,8 @@ void rvc_set_clear(rvc_set *s) {
   s->tail_out_done = 2;
   s->ypre_block = -1;
   s->xa_next = 0;
+  s->w_next = 0;
+  s->xt_valid_lo = 0;
 }
 
 void rvc_set_reset(rvc_set *s) {
@@ -937,7 +1055,9 @@ int rvc_set_channels(const rvc_set *s) { return s ? s->nch : 0; }
 size_t rvc_set_head_block(const rvc_set *s) { return s ? s->head : 0; }
 size_t rvc_set_tail_block(const rvc_set *s) { return s ? s->tail : 0; }
 size_t rvc_set_max_len(const rvc_set *s) { return s ? s->max_len : 0; }
-int rvc_set_partitions(const rvc_set *s, int stage) { return !s ? 0 : (stage == 0 ? s->A.P : s->T.P); }
+int rvc_set_partitions(const rvc_set *s, int stage) {
+  return !s ? 0 : (stage == 0 ? s->A.P : (stage == 1 ? s->T.P : s->W.P));
+}
 void *rvc_set_stream(rvc_set *s, int which) { return !s ? nullptr : (which == 0 ? (void *)s->st_main : (void *)s->st_bg); }
 int rvc_last_error(const rvc_set *s) { return s ? s->err : RVC_ERR_BAD_ARG; }
 const char *rvc_last_error_string(const rvc_set *s) { return s ? s->errstr.c_str() : "null handle"; }

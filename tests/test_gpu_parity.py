@@ -312,15 +312,18 @@ def test_handles_are_independent_across_threads():
         assert rel_rms(got[c], want[c]) <= TOL
 
 
+@pytest.mark.parametrize("ir_len", [60000, 150000])
 @pytest.mark.parametrize("fixed", [False, True])
-def test_mixed_long_and_short_calls_hand_state_over(fixed):
+def test_mixed_long_and_short_calls_hand_state_over(fixed, ir_len):
     """Adaptive partitioning: a long call is served by one uniform delay line at the tail block
     size and leaves the head stage's state (delay-line history, tail-ring rows, pre-multiplied
     accumulator) stale; the next short call must rebuild it lazily. Any interleaving of long,
     block-sized and ragged calls has to give the reference's stream."""
-    ir = synth.synth_ir(60000, 2, 50)
+    # ir_len 150000 (> 4 x 16384) also creates the wide stage: 70000 / 90001-frame calls go through it,
+    # 8192*5-frame calls through the tail-size line, and each switch rebuilds the other's delay line
+    ir = synth.synth_ir(ir_len, 2, 50)
     sched = [512] * 3 + [70000] + [512] * 40 + [37, 475, 512, 300] + [8192 * 5] + [100] + [512] * 20 + \
-            [8192 * 4 + 5] + [8187] + [512] * 33 + [90001] + [511, 1] + [512] * 17
+            [8192 * 4 + 5] + [8187] + [512] * 33 + [90001] + [511, 1] + [512] * 17 + [8192 * 6] + [66000] + [512] * 5
     total = sum(sched)
     x = np.stack([synth.synth_input(total, c) for c in range(2)])
     s = reevr_amd.ConvolverSet(2, fixed_partitions=fixed)
