@@ -45,6 +45,20 @@ HOST_BLOCK = 512
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+ROOF_NOTES = {
+    "fir": "achieved = ALGORITHMIC bytes of the reference structure this launch replaces (16 B per partition x bin of "
+           "the head, tail0 and tail delay lines, SURVEY.md 8d) / measured launch time. The kernel tiles 64 blocks of "
+           "time per workgroup and, for long calls, uses one delay line at a larger block for the whole IR, so physical "
+           "HBM traffic (`traffic`) is ~50x below the algorithmic figure: frac > 1 is expected, the kernel is fp32-FMA "
+           "bound (DESIGN.md 7).",
+    "fft": "achieved = ALGORITHMIC bytes of the reference transforms this launch replaces (4 B per input sample + 8 B "
+           "per spectrum bin, for every head AND tail block of the call, SURVEY.md 8d) / measured launch time; `traffic` "
+           "is what the kernel physically moved (overlap-save reads 2B samples per B-sample block, one transform per "
+           "16384-sample block on the long-call path). The FIR kernel takes about the same time per step "
+           "(kernels_ms / roofline_all); which of the two is 'dominant' can flip run to run.",
+}
+
+
 def alg_bytes_block(B: int, P: int) -> int:
     """algorithmic bytes of one block of one reference sub-convolver."""
     return 16 * P * (B + 1) + 8 * (B + 1) + 16 * B
@@ -254,11 +268,7 @@ def main():
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": alg[dominant], "avg_launch_ms": round(kern[dominant]["avg_ms"], 5),
                 "traffic_source": tsrc,
-                "note": "achieved = ALGORITHMIC bytes of the reference structure this launch replaces (16 B per "
-                        "partition x bin of the head, tail0 and tail delay lines, SURVEY.md 8d) / measured launch "
-                        "time. The kernel tiles 64 blocks of time per workgroup and, for long calls, uses 8192-sample "
-                        "partitions for the whole IR, so physical HBM traffic (`traffic`) is ~50x below the "
-                        "algorithmic figure: frac > 1 is expected, the kernel is fp32-FMA bound (DESIGN.md 7)."}
+                "note": ROOF_NOTES["fir" if dominant.startswith("fir") else "fft"]}
     # every timed kernel family against the HBM roofline (algorithmic numerator), for the record
     roof_all = {k: {"avg_launch_ms": round(v["avg_ms"], 5),
                     "achieved_GBs": round(alg[k] / (v["avg_ms"] * 1e-3) / 1e9, 1),
