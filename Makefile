@@ -9,9 +9,9 @@ LIB   := $(CSRC)/libreevr_amd.so
 
 all: $(LIB) oracle
 
-$(LIB): $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_engine.cpp $(CSRC)/rvc_internal.h include/reevr_amd/rvc.h
+$(LIB): $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_impulse.hip $(CSRC)/rvc_engine.cpp $(CSRC)/rvc_internal.h $(CSRC)/rvc_fft_lds.hpp include/reevr_amd/rvc.h
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip -ffp-contract=fast \
-	  -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -o $@ $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_engine.cpp
+	  -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -o $@ $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_impulse.hip $(CSRC)/rvc_engine.cpp
 
 oracle:
 	$(MAKE) -C oracle

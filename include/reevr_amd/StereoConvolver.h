@@ -45,6 +45,14 @@ class StereoConvolver {
     }
   }
 
+  // Same, from an impulse prepared on the device (reevr_amd/ImpulseStages.h): no host round trip.
+  void loadImpulse(rvc_impulse *prepared) {
+    const int main_ch[2] = {0, 1}, cross_ch[2] = {2, 3};   // LL, RR | LR, RL
+    rvc_set_init_impulse(_main, headBlockSize, tailBlockSize, prepared, main_ch, (size_t)size);
+    isQuad = rvc_impulse_channels(prepared) == 4;
+    if (isQuad) rvc_set_init_impulse(_cross, headBlockSize, tailBlockSize, prepared, cross_ch, (size_t)size);
+  }
+
   void prepare(int samplesPerBlock) {   // StereoConvolver.cpp:8-20
     size = samplesPerBlock;
     headBlockSize = 1;

@@ -171,6 +171,65 @@ void rvc_reset(rvc_set *h);
 int rvc_is_finished(rvc_set *h);
 void rvc_destroy(rvc_set *h);
 
+/* ---- impulse preparation on the device ------------------------- */
+
+/* The deterministic array stages of Impulse::recalcImpulse (src/dsp/Impulse.cpp:307-360), i.e.
+ * everything between Impulse::load and StereoConvolver::loadImpulse except resampling / stretch
+ * (juce::ResamplingAudioSource, :362-434) and the serial IIR paramEQ (:501-533). The prepared IR
+ * stays in HBM and can be handed to rvc_set_init_impulse without a host round trip.
+ *   stage A = auto gain (:691-708, :319-328) -> reverse (:330-338) -> peak (:343-349)
+ *             -> trim (:436-470) -> gain (:472-486)
+ *   [a host that has paramEQ bands reads the buffers, filters, writes them back here]
+ *   stage B = STFT decay EQ (:601-649; 4096-point frames, hop 1024) -> clip (:488-499)
+ *             -> attack/decay envelope (:651-680) */
+typedef struct rvc_impulse rvc_impulse;
+
+#define RVC_IMPULSE_FFT_SIZE 4096                       /* Impulse.h:22 */
+#define RVC_IMPULSE_LUT_SIZE (RVC_IMPULSE_FFT_SIZE / 2 + 1)
+
+typedef struct rvc_impulse_params {
+  int reverse;             /* Impulse.h:71 */
+  float trim_left;         /* fraction of the length, Impulse.h:66 */
+  float trim_right;        /* Impulse.h:67 */
+  float gain;              /* Impulse.h:70 */
+  float attack;            /* fraction of the trimmed length, Impulse.h:64 */
+  float decay;             /* Impulse.h:65 */
+  double srate;            /* Impulse.h:58 */
+  const double *decay_lut; /* RVC_IMPULSE_LUT_SIZE per-frame decay factors per bin (the table
+                            * applyDecayEQ builds, Impulse.cpp:561-590), or NULL: no decay EQ bands */
+} rvc_impulse_params;
+
+rvc_impulse *rvc_impulse_create(int device);
+void rvc_impulse_destroy(rvc_impulse *m);
+/* The product of Impulse::load (Impulse.cpp:160-196): n_channels = 2 (rawBufferLL, rawBufferRR)
+ * or 4 (+ rawBufferLR, rawBufferRL; isQuad), all `len` samples. Copied; 1 = ok. */
+int rvc_impulse_set_raw(rvc_impulse *m, int n_channels, const float *const *raw, size_t len);
+/* Impulse::recalcImpulse = stage A then stage B. 1 = ok. */
+int rvc_impulse_recalc(rvc_impulse *m, const rvc_impulse_params *p);
+int rvc_impulse_stage_a(rvc_impulse *m, const rvc_impulse_params *p);
+int rvc_impulse_stage_b(rvc_impulse *m, const rvc_impulse_params *p);
+/* The decay table of applyDecayEQ (Impulse.cpp:561-590) from the filters' combined magnitude at
+ * the RVC_IMPULSE_LUT_SIZE bin frequencies (SVF::getMagnitude is filter design, host side). */
+void rvc_impulse_decay_lut(const float *mag, double srate, float decay_rate, double *lut);
+int rvc_impulse_channels(const rvc_impulse *m);
+size_t rvc_impulse_size(const rvc_impulse *m);               /* bufferLL.size() */
+float rvc_impulse_peak(const rvc_impulse *m);                /* Impulse.h:54 */
+int rvc_impulse_trim_left_samples(const rvc_impulse *m);     /* Impulse.h:55 */
+int rvc_impulse_trim_right_samples(const rvc_impulse *m);    /* Impulse.h:56 */
+/* bufferLL / RR / LR / RL (channel 0..3) to / from the host; n <= rvc_impulse_size. 1 = ok. */
+int rvc_impulse_read(rvc_impulse *m, int channel, float *dst, size_t n);
+int rvc_impulse_write(rvc_impulse *m, int channel, const float *src, size_t n);
+/* device pointer of a prepared channel (valid until the next set_raw / destroy) */
+const float *rvc_impulse_device_ptr(rvc_impulse *m, int channel);
+int rvc_impulse_last_error(const rvc_impulse *m);
+const char *rvc_impulse_last_error_string(const rvc_impulse *m);
+
+/* StereoConvolver::loadImpulse (src/dsp/StereoConvolver.cpp:22-31) without the host round trip:
+ * channel c of the set is initialised from prepared channel channels[c] of the impulse (same
+ * device). Same return conventions as rvc_set_init. */
+int rvc_set_init_impulse(rvc_set *s, size_t head_block, size_t tail_block, rvc_impulse *m,
+                         const int *channels, size_t max_len);
+
 /* ---- library ----------------------------------------------------------------------- */
 
 /* Number of visible HIP devices (0 when there is none or the runtime cannot start). */

@@ -172,3 +172,77 @@ def run_schedule(conv, x: np.ndarray, schedule) -> np.ndarray:
         pos += n
     assert pos == len(x)
     return out
+
+
+# ---- impulse preparation stages (impulse_oracle.c) ---------------------
+
+IMP_FFT_SIZE = 4096
+IMP_LUT_SIZE = IMP_FFT_SIZE // 2 + 1
+
+
+class _ImpParams(C.Structure):
+    _fields_ = [("n_channels", C.c_int), ("reverse", C.c_int), ("trim_left", C.c_float),
+                ("trim_right", C.c_float), ("gain", C.c_float), ("attack", C.c_float),
+                ("decay", C.c_float), ("srate", C.c_double), ("decay_lut", _F64P)]
+
+
+def _imp_lib(fft: str = "orc"):
+    """liboracle.so with the STFT stage running on this repo's FFT ("orc") or on the reference's
+    AudioFFT from oracle/_ref ("ref")."""
+    lib = backend("orc").lib
+    if not getattr(lib, "_imp_ready", False):
+        lib.orc_impulse_auto_gain.restype = C.c_float
+        lib.orc_impulse_auto_gain.argtypes = [_F32P, _F32P, C.c_size_t]
+        lib.orc_impulse_decay_lut.restype = None
+        lib.orc_impulse_decay_lut.argtypes = [_F32P, C.c_double, C.c_float, _F64P]
+        lib.orc_impulse_apply_decay.restype = None
+        lib.orc_impulse_apply_decay.argtypes = [_F32P, C.c_size_t, _F64P, C.c_double]
+        lib.orc_impulse_stage_a.restype = C.c_size_t
+        lib.orc_impulse_stage_a.argtypes = [C.POINTER(_ImpParams), C.POINTER(_F32P), C.c_size_t, C.POINTER(_F32P),
+                                            _F32P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.orc_impulse_stage_b.restype = None
+        lib.orc_impulse_stage_b.argtypes = [C.POINTER(_ImpParams), C.POINTER(_F32P), C.c_size_t]
+        lib.orc_impulse_set_fft.restype = None
+        lib.orc_impulse_set_fft.argtypes = [C.c_void_p, C.c_void_p]
+        lib._imp_ready = True
+    if fft == "ref":
+        r = backend("ref").lib
+        lib.orc_impulse_set_fft(C.cast(r.ref_rfft, C.c_void_p), C.cast(r.ref_irfft, C.c_void_p))
+    else:
+        lib.orc_impulse_set_fft(None, None)
+    return lib
+
+
+def impulse_decay_lut(mag: np.ndarray, srate: float, decay_rate: float) -> np.ndarray:
+    mag = np.ascontiguousarray(mag, np.float32)
+    assert mag.size == IMP_LUT_SIZE
+    lut = np.empty(IMP_LUT_SIZE, np.float64)
+    _imp_lib().orc_impulse_decay_lut(_fp(mag), srate, decay_rate, lut.ctypes.data_as(_F64P))
+    return lut
+
+
+def impulse_recalc(raw, *, reverse=False, trim_left=0.0, trim_right=0.0, gain=1.0, attack=0.0, decay=0.0,
+                   srate=48000.0, decay_lut=None, fft: str = "orc", stage: str = "ab", param_eq=None):
+    """raw: list of 2 (LL, RR) or 4 (LL, RR, LR, RL) equal-length float32 arrays.
+    Returns dict(buffers=[...], peak, trim_left_samples, trim_right_samples)."""
+    lib = _imp_lib(fft)
+    raw = [np.ascontiguousarray(r, np.float32) for r in raw]
+    nc, n = len(raw), raw[0].size
+    lut = None if decay_lut is None else np.ascontiguousarray(decay_lut, np.float64)
+    p = _ImpParams(nc, int(bool(reverse)), trim_left, trim_right, gain, attack, decay, srate,
+                   lut.ctypes.data_as(_F64P) if lut is not None else None)
+    out = [np.zeros(max(n, 1), np.float32) for _ in range(nc)]
+    rawp = (_F32P * nc)(*[_fp(r) for r in raw])
+    outp = (_F32P * nc)(*[_fp(o) for o in out])
+    peak = C.c_float(0)
+    tl, tr = C.c_int(0), C.c_int(0)
+    m = lib.orc_impulse_stage_a(C.byref(p), rawp, n, outp, _fp(np.ctypeslib.as_array(C.pointer(peak), (1,))),
+                                C.byref(tl), C.byref(tr))
+    if param_eq is not None and m:     # applyParamEQ sits between applyGain and applyDecayEQ (Impulse.cpp:355-357)
+        for o in out:
+            o[:m] = np.asarray(param_eq(o[:m].copy()), np.float32)
+    if "b" in stage and m:
+        lib.orc_impulse_stage_b(C.byref(p), outp, m)
+    lib.orc_impulse_set_fft(None, None)
+    return {"buffers": [o[:m].copy() for o in out], "peak": float(peak.value),
+            "trim_left_samples": tl.value, "trim_right_samples": tr.value}

@@ -5,4 +5,6 @@ convolver classes used by the tests and bench.py."""
 from .convolver import (KERNEL_NAMES, Convolver, ConvolverSet, FFTConvolver, RvcError,  # noqa: F401
                         StereoConvolver, TwoStageFFTConvolver)
 
+from .impulse import Impulse  # noqa: F401,E402
+
 __version__ = "0.1.0"

@@ -53,9 +53,37 @@ SIGNATURES = {
     "rvc_reset": (None, [C.c_void_p]),
     "rvc_is_finished": (C.c_int, [C.c_void_p]),
     "rvc_destroy": (None, [C.c_void_p]),
+    "rvc_impulse_create": (C.c_void_p, [C.c_int]),
+    "rvc_impulse_destroy": (None, [C.c_void_p]),
+    "rvc_impulse_set_raw": (C.c_int, [C.c_void_p, C.c_int, F32PP, C.c_size_t]),
+    "rvc_impulse_recalc": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rvc_impulse_stage_a": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rvc_impulse_stage_b": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rvc_impulse_decay_lut": (None, [F32P, C.c_double, C.c_float, C.POINTER(C.c_double)]),
+    "rvc_impulse_channels": (C.c_int, [C.c_void_p]),
+    "rvc_impulse_size": (C.c_size_t, [C.c_void_p]),
+    "rvc_impulse_peak": (C.c_float, [C.c_void_p]),
+    "rvc_impulse_trim_left_samples": (C.c_int, [C.c_void_p]),
+    "rvc_impulse_trim_right_samples": (C.c_int, [C.c_void_p]),
+    "rvc_impulse_read": (C.c_int, [C.c_void_p, C.c_int, F32P, C.c_size_t]),
+    "rvc_impulse_write": (C.c_int, [C.c_void_p, C.c_int, F32P, C.c_size_t]),
+    "rvc_impulse_device_ptr": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "rvc_impulse_last_error": (C.c_int, [C.c_void_p]),
+    "rvc_impulse_last_error_string": (C.c_char_p, [C.c_void_p]),
+    "rvc_set_init_impulse": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(C.c_int), C.c_size_t]),
     "rvc_device_count": (C.c_int, []),
     "rvc_version": (C.c_char_p, []),
 }
+
+RVC_IMPULSE_FFT_SIZE = 4096
+RVC_IMPULSE_LUT_SIZE = RVC_IMPULSE_FFT_SIZE // 2 + 1
+
+
+class ImpulseParams(C.Structure):       # struct rvc_impulse_params
+    _fields_ = [("reverse", C.c_int), ("trim_left", C.c_float), ("trim_right", C.c_float), ("gain", C.c_float),
+                ("attack", C.c_float), ("decay", C.c_float), ("srate", C.c_double),
+                ("decay_lut", C.POINTER(C.c_double))]
+
 
 _lib = None
 

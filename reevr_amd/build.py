@@ -15,8 +15,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libreevr_amd.so")
-SOURCES = ["rvc_kernels.hip", "rvc_engine.cpp"]
-HEADERS = ["rvc_internal.h", os.path.join("..", "..", "include", "reevr_amd", "rvc.h")]
+SOURCES = ["rvc_kernels.hip", "rvc_impulse.hip", "rvc_engine.cpp"]
+HEADERS = ["rvc_internal.h", "rvc_fft_lds.hpp", os.path.join("..", "..", "include", "reevr_amd", "rvc.h")]
 
 
 def _hipcc() -> str:

@@ -76,6 +76,14 @@ class ConvolverSet:
         del keep
         return ok
 
+    def init_impulse(self, headBlockSize: int, tailBlockSize: int, imp, channels: Sequence[int], max_len: int = 0) -> bool:
+        """init() from a device-resident reevr_amd.Impulse: set channel c <- prepared channel channels[c]
+        (0 LL, 1 RR, 2 LR, 3 RL). No host round trip (rvc_set_init_impulse)."""
+        if len(channels) != self.n_channels:
+            raise ValueError("one impulse channel index per set channel")
+        idx = (C.c_int * self.n_channels)(*[int(c) for c in channels])
+        return bool(self._lib.rvc_set_init_impulse(self._h, headBlockSize, tailBlockSize, imp._h, idx, max_len))
+
     # -- process ------------------------------------------------------------------------
     def process(self, x: np.ndarray) -> np.ndarray:
         """x: (n_channels, len) host array -> (n_channels, len) float32."""
@@ -282,6 +290,12 @@ class StereoConvolver:
             setattr(self, name, np.zeros(self.size, np.float32))
 
     def loadImpulse(self, imp):                  # StereoConvolver.cpp:22-31
+        if getattr(imp, "_h", None) and hasattr(imp, "device_ptr"):   # device-resident reevr_amd.Impulse
+            self._main.init_impulse(self.headBlockSize, self.tailBlockSize, imp, [0, 1], self.size)
+            self.isQuad = bool(imp.isQuad)
+            if self.isQuad:
+                self._cross.init_impulse(self.headBlockSize, self.tailBlockSize, imp, [2, 3], self.size)
+            return
         self._main.init(self.headBlockSize, self.tailBlockSize, [imp.bufferLL, imp.bufferRR], self.size)
         self.isQuad = bool(imp.isQuad)
         if self.isQuad:

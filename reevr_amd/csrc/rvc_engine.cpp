@@ -271,13 +271,15 @@ bool make_twiddles(rvc_set *s, Stage &g) {
 
 // IR partitions -> spectra: one batched forward launch over all partitions of all channels
 // (replaces the per-partition loop FFTConvolver.cpp:129-137).
-bool upload_ir_stage(rvc_set *s, Stage &g, const std::vector<std::vector<float>> &parts) {
+bool upload_ir_stage(rvc_set *s, Stage &g, const float *const *irs, const std::vector<size_t> &counts, bool on_device) {
+  // d_ir: [channel][hrows * B] zero-padded samples; irs[c] may be host or (rvc_set_init_impulse) device memory
   const size_t padded = (size_t)g.hrows() * g.B;
-  std::vector<float> host((size_t)s->nch * padded, 0.f);
+  if (!g.d_ir) RVC_CK(hipMalloc(&g.d_ir, sizeof(float) * (size_t)s->nch * padded));
+  RVC_CK(hipMemsetAsync(g.d_ir, 0, sizeof(float) * (size_t)s->nch * padded, s->st_main));
   for (int c = 0; c < s->nch; ++c)
-    std::copy(parts[c].begin(), parts[c].end(), host.begin() + (size_t)c * padded);
-  if (!g.d_ir) RVC_CK(hipMalloc(&g.d_ir, sizeof(float) * host.size()));
-  RVC_CK(hipMemcpy(g.d_ir, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
+    if (counts[c])
+      RVC_CK(hipMemcpyAsync(g.d_ir + (size_t)c * padded, irs[c], sizeof(float) * counts[c],
+                            on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->st_main));
   if (!g.H) RVC_CK(hipMalloc(&g.H, sizeof(float2) * (size_t)s->nch * g.hrows() * g.B));
   rvc::FwdArgs a{};
   a.src = g.d_ir; a.src_chan_stride = (long long)padded; a.src_mask = ~0ull;
@@ -296,7 +298,7 @@ bool upload_ir_stage(rvc_set *s, Stage &g, const std::vector<std::vector<float>>
 }
 
 bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
-             const float *const *irs, const size_t *ir_lens, size_t max_len) {
+             const float *const *irs, const size_t *ir_lens, size_t max_len, bool on_device = false) {
   // The reference's init() starts with reset() (TwoStageFFTConvolver.cpp:92, FFTConvolver.cpp:95).
   // Here everything is released only when the new geometry differs; an IR swap with unchanged
   // block sizes / partition counts (the plug-in's hot-swap, src/PluginProcessor.cpp:1680-1691)
@@ -318,7 +320,8 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   size_t longest = 0;
   for (int c = 0; c < s->nch; ++c) {
     size_t l = irs[c] ? ir_lens[c] : 0;
-    while (l > 0 && std::fabs(irs[c][l - 1]) < 0.000001f) --l;
+    if (!on_device)   // device-resident IRs arrive with the scan already done (rvc::impulse_view)
+      while (l > 0 && std::fabs(irs[c][l - 1]) < 0.000001f) --l;
     len[c] = l;
     longest = std::max(longest, l);
   }
@@ -342,16 +345,14 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   const size_t split = two_stage ? 2 * tb : (size_t)-1;
 
   // partition counts (ceil(float/float) as FFTConvolver.cpp:115; exact below 2^24 samples)
-  std::vector<std::vector<float>> partsA(s->nch), partsT(s->nch);
-  size_t pa = 0, pt = 0;
+  std::vector<size_t> lenA(s->nch);   // samples the zero-latency stage covers; the tail and wide
+  size_t pa = 0, pt = 0;              // stages keep the WHOLE IR at their block size (see Stage::PF)
   for (int c = 0; c < s->nch; ++c) {
     const size_t la = std::min(len[c], split);
-    partsA[c].assign(irs[c], irs[c] + la);
+    lenA[c] = la;
     pa = std::max(pa, (la + hb - 1) / hb);
     if (len[c] > split) pt = std::max(pt, (len[c] - split + tb - 1) / tb);
   }
-  if (pt > 0)   // the tail stage keeps the WHOLE IR at block T (see Stage::PF)
-    for (int c = 0; c < s->nch; ++c) partsT[c].assign(irs[c], irs[c] + len[c]);
   // wide stage: only for float transforms (136 KiB of LDS), a tail block below 16384 and an IR of
   // several wide blocks; and only if calls can be long enough to use it
   const size_t wb = (size_t)RVC_MAX_BLOCK;
@@ -367,9 +368,9 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     hipStreamSynchronize(s->st_main);
     for (auto &j : s->jobs) s->ev_pool.push_back(j.ev);
     s->jobs.clear();
-    if (!upload_ir_stage(s, s->A, partsA)) { free_device_state(s); return false; }
-    if (pt > 0 && !upload_ir_stage(s, s->T, partsT)) { free_device_state(s); return false; }
-    if (pw > 0 && !upload_ir_stage(s, s->W, partsT)) { free_device_state(s); return false; }
+    if (!upload_ir_stage(s, s->A, irs, lenA, on_device)) { free_device_state(s); return false; }
+    if (pt > 0 && !upload_ir_stage(s, s->T, irs, len, on_device)) { free_device_state(s); return false; }
+    if (pw > 0 && !upload_ir_stage(s, s->W, irs, len, on_device)) { free_device_state(s); return false; }
     s->n = 0; s->tail_fft_done = 0; s->tail_out_done = 2; s->xa_next = 0; s->ypre_block = -1;
     s->w_next = 0; s->xt_valid_lo = 0;
     return true;
@@ -388,7 +389,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   A.mcap = s->max_len / hb + 2;
   A.rows = next_pow2(pa + A.mcap + 1);
   if (!make_twiddles(s, A)) return false;
-  if (!upload_ir_stage(s, A, partsA)) return false;
+  if (!upload_ir_stage(s, A, irs, lenA, on_device)) return false;
   RVC_CK(hipMalloc(&A.X, sizeof(float2) * (size_t)s->nch * A.rows * A.B));
   RVC_CK(hipMalloc(&A.Y, sizeof(float2) * (size_t)s->nch * A.mcap * A.B));
   if (pt > 0) {
@@ -396,7 +397,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     T.mcap = s->max_len / tb + 3;
     T.rows = next_pow2(pt + 2 + T.mcap + 2);
     if (!make_twiddles(s, T)) return false;
-    if (!upload_ir_stage(s, T, partsT)) return false;
+    if (!upload_ir_stage(s, T, irs, len, on_device)) return false;
     RVC_CK(hipMalloc(&T.X, sizeof(float2) * (size_t)s->nch * T.rows * T.B));
     RVC_CK(hipMalloc(&T.Y, sizeof(float2) * (size_t)s->nch * T.mcap * T.B));
   }
@@ -406,7 +407,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     W.mcap = s->max_len / wb + 3;
     W.rows = next_pow2(pw + W.mcap + 2);
     if (!make_twiddles(s, W)) return false;
-    if (!upload_ir_stage(s, W, partsT)) return false;      // partsT = the whole IR
+    if (!upload_ir_stage(s, W, irs, len, on_device)) return false;
     RVC_CK(hipMalloc(&W.X, sizeof(float2) * (size_t)s->nch * W.rows * W.B));
     RVC_CK(hipMalloc(&W.Y, sizeof(float2) * (size_t)s->nch * W.mcap * W.B));
   }
@@ -923,6 +924,32 @@ int rvc_set_init_uniform(rvc_set *s, size_t block, const float *const *irs, cons
                          size_t max_len) {
   if (!s) return 0;
   const bool ok = do_init(s, block, 0, false, irs, ir_lens, max_len);
+  if (!ok && s->live) free_device_state(s);
+  return ok ? 1 : 0;
+}
+
+int rvc_set_init_impulse(rvc_set *s, size_t head_block, size_t tail_block, rvc_impulse *m, const int *channels,
+                         size_t max_len) {
+  if (!s) return 0;
+  rvc::ImpulseView v{};
+  if (!m || !channels || !rvc::impulse_view(m, &v)) {
+    s->err = RVC_OK;
+    fail(s, RVC_ERR_BAD_ARG, hipSuccess, "impulse");
+    return 0;
+  }
+  std::vector<const float *> irs(s->nch, nullptr);
+  std::vector<size_t> lens(s->nch, 0);
+  for (int c = 0; c < s->nch; ++c) {
+    const int k = channels[c];
+    if (k < 0 || k >= v.channels || v.device != s->device) {
+      s->err = RVC_OK;
+      fail(s, RVC_ERR_BAD_ARG, hipSuccess, "impulse channel / device");
+      return 0;
+    }
+    irs[c] = v.size ? v.ch[k] : nullptr;
+    lens[c] = v.trimmed[k];
+  }
+  const bool ok = do_init(s, head_block, tail_block, true, irs.data(), lens.data(), max_len, /*on_device=*/true);
   if (!ok && s->live) free_device_state(s);
   return ok ? 1 : 0;
 }

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+struct rvc_impulse;
+
 namespace rvc {
 
 // Everything time-domain is addressed by ABSOLUTE sample index n (samples since the last
@@ -139,5 +141,16 @@ int fft8_table_entries(int logB);
 
 // time-tile (output rows per thread) the FIR launcher will pick for M rows
 int fir_time_tile(int M);
+
+// A prepared impulse as rvc_set_init_impulse sees it (rvc_impulse.hip): device pointers of the
+// prepared channels and their lengths with trailing |x| < 1e-6 dropped (TwoStageFFTConvolver.cpp:107-110).
+struct ImpulseView {
+  int device;
+  int channels;
+  size_t size;
+  const float *ch[4];
+  size_t trimmed[4];
+};
+bool impulse_view(rvc_impulse *m, ImpulseView *v);   // synchronises the impulse's stream
 
 }  // namespace rvc

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "reevr_amd/Convolver.h"
+#include "reevr_amd/ImpulseStages.h"
 #include "reevr_amd/StereoConvolver.h"
 
 int main() {
@@ -30,6 +31,20 @@ int main() {
     sc.loadImpulse(imp);
     sc.process(in.data(), in.data(), 128);
     if (std::fabs(sc.bufferLL[3] - 2.0f) > 1e-5f) { std::puts("stereo wrong"); return 1; }
+    // prepared on the device: gain 0.5, no other stage active (energy 1.25 -> auto gain 1/sqrt(2.5))
+    reevr_amd::ImpulseStages st;
+    st.decay = 0.0f; st.gain = 0.5f; st.srate = 48000.0;
+    if (!st.setRaw(ir, ir) || !st.recalc() || st.size() != ir.size()) { std::puts("impulse stages failed"); return 1; }
+    std::vector<float> ll;
+    st.fetch(0, ll);
+    const float g = (float)(1.0 / std::sqrt(2.5));
+    if (std::fabs(ll[0] - g * 0.5f) > 1e-6f || std::fabs(ll[50] - 0.5f * g * 0.5f) > 1e-6f) { std::puts("impulse stages wrong"); return 1; }
+    sc.loadImpulse(st.handle());
+    sc.process(in.data(), in.data(), 128);
+    if (std::fabs(sc.bufferLL[3] - 2.0f * g * 0.5f) > 1e-5f) { std::puts("device impulse -> convolver wrong"); return 1; }
+  } else {
+    reevr_amd::ImpulseStages st;
+    if (st.setRaw(ir, ir)) { std::puts("setRaw must fail without a GPU"); return 1; }
   }
   std::puts("ok");
   return 0;
