@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libreevr_amd.so")
+# REEVR_AMD_LIB: development override used by the ablation measurements (tools/abl_build.py)
+LIB_PATH = os.environ.get("REEVR_AMD_LIB") or os.path.join(_HERE, "csrc", "libreevr_amd.so")
 
 F32P = C.POINTER(C.c_float)
 F32PP = C.POINTER(F32P)

@@ -242,17 +242,17 @@ bool make_twiddles(rvc_set *s, Stage &g) {
     std::vector<float2> t8((size_t)n8e);
     size_t o = 0;
     const int N8 = g.logB / 3;
-    for (int j = 1; j < N8; ++j) {
+    for (int j = 1; j < N8; ++j) {            // leg-major [r][k]: coalesced per-leg loads (Plan8::off8)
       const size_t p = (size_t)1 << (3 * j);
-      for (size_t k = 0; k < p; ++k)
-        for (int r = 0; r < 8; ++r) {
+      for (int r = 0; r < 8; ++r)
+        for (size_t k = 0; k < p; ++k) {
           const double ang = -2.0 * kPi * (double)r * (double)k / (double)(8 * p);
           t8d[o++] = make_double2(std::cos(ang), std::sin(ang));
         }
     }
     if (g.logB % 3 == 2) {
-      for (size_t k = 0; k < B / 4; ++k)
-        for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < 4; ++r)
+        for (size_t k = 0; k < B / 4; ++k) {
           const double ang = -2.0 * kPi * (double)r * (double)k / (double)B;
           t8d[o++] = make_double2(std::cos(ang), std::sin(ang));
         }

@@ -28,6 +28,23 @@
 #include "rvc_internal.h"
 #include "rvc_fft_lds.hpp"
 
+#ifdef RVC_PHASE_TIMES
+// Development instrumentation (tools/phase_times.py): thread 0 of a few workgroups stamps the shader clock
+// at phase boundaries of the big kernels. Waits are forced at the stamps, so the kernel is slower with it.
+__device__ unsigned long long g_phase[3][16][8];   // [kernel 0 fwd 1 fir 2 inv][sampled workgroup][stamp]
+#define RVC_STAMP(kern, i)                                                                       \
+  do {                                                                                           \
+    __builtin_amdgcn_s_waitcnt(0);                                                               \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x % 8) == 0 && blockIdx.x / 8 < 16)     \
+      g_phase[kern][blockIdx.x / 8][i] = __builtin_readcyclecounter();                          \
+  } while (0)
+extern "C" int rvc_debug_phase_times(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 3 * 16 * 8);
+}
+#else
+#define RVC_STAMP(kern, i) do {} while (0)
+#endif
+
 #include <hip/hip_ext.h>
 
 #include <type_traits>
@@ -46,6 +63,15 @@ void set_launch_events(hipEvent_t a, hipEvent_t b) { t_ev_a = a; t_ev_b = b; }
   } while (0)
 
 
+
+// address of sample n of the input timeline (the call's own input buffer for n >= src2_from, else the
+// ring) when `ok`; else the address of sample a.lo in the ring, which always exists
+__device__ __forceinline__ const float *sample_ptr(const FwdArgs &a, const float *ring, const float *src2, long long n,
+                                                   bool ok) {
+  const bool s2 = ok && src2 && n >= a.src2_from;
+  const long long nn = ok ? n : a.lo;
+  return s2 ? src2 + (n - a.src2_from) : ring + ((unsigned long long)nn & a.src_mask);
+}
 
 // sample n of the input timeline: the call's own input buffer for n >= src2_from, else the ring
 __device__ __forceinline__ float load_sample(const FwdArgs &a, const float *ring, const float *src2, long long n) {
@@ -166,7 +192,7 @@ __global__ void __launch_bounds__(fft_threads(LOGB)) k_fft_inv(const InvArgs a) 
 // pass is fed straight from global memory and the last pass leaves natural-order results in
 // registers for the epilogue, so a 512-point complex transform (1024 real samples) makes 2 LDS
 // round trips for the FFT + 1 for the real split instead of 6. Twiddles come from small
-// per-pass tables [k][r] (contiguous per thread, L1/L2 resident), computed in double on the host.
+// per-pass tables [r][k] (leg-major: coalesced across a wave, L1/L2 resident), computed in double on the host.
 // ========================================================================================
 template <int LOGB> struct Plan8 {
   static constexpr int B = 1 << LOGB;
@@ -179,9 +205,15 @@ template <int LOGB> struct Plan8 {
   static constexpr int E = 8 * S;                 // complex values per thread
   static constexpr int T = B / 8;                 // stride between the legs of a radix-8 butterfly
   static constexpr int LDS_ELEMS = B + B / 16;    // padded
-  // offset (in entries) of the [k][8] table of radix-8 pass j >= 1 (p = 8^j) inside tw8
+  static constexpr bool kLin = (NT % 16 == 0) && (T % 16 == 0);   // all index strides 16-aligned (B >= 128): see lpad_c
+  // out_idx(tid, e) - tid and in_idx(tid, e) - tid
+  static constexpr int in_c(int e) { return (e >> 3) * NT + (e & 7) * T; }
+  static constexpr int out_c(int e) { return Q == 1 ? in_c(e) : (e / Q) * NT + (e % Q) * (B / Q); }
+  // offset (in entries) of the [r][k] table of radix-8 pass j >= 1 (p = 8^j, 8 legs x p entries) inside tw8.
+  // Leg-major: for a given leg, consecutive threads read consecutive entries (one coalesced 512-byte
+  // request per wave; with the k-major layout every lane touched its own 64-byte row).
   static constexpr int off8(int j) { int o = 0; for (int i = 1; i < j; ++i) o += (1 << (3 * i)) * 8; return o; }
-  static constexpr int offq = off8(N8);           // the final radix-4 table [k][4] (Q == 4 only)
+  static constexpr int offq = off8(N8);           // the final radix-4 table [r][k], 4 legs x B/4 (Q == 4 only)
   static constexpr int tw8_entries = offq + (Q == 4 ? B : 0);
   // natural-order index of held value e after the whole transform / before the first pass
   __device__ static __forceinline__ int in_idx(int tid, int e) { return tid + (e >> 3) * NT + (e & 7) * T; }
@@ -196,6 +228,16 @@ template <int LOGB> struct Plan8 {
 };
 
 __device__ __forceinline__ int lpad(int i) { return i + (i >> 4); }
+// The padding is linear over 16-aligned offsets: lpad(a + c) == lpad(a) + lpad_c(c) for c % 16 == 0 (c >= 0),
+// and lpad(c - t) == lpad_neg(t) + lpad_c(c) for 0 <= t <= c. Spelling that out leaves ONE runtime base
+// per thread and compile-time offsets on every LDS access of a pass (the compiler does not see through
+// the shift: it spent ~4 VALU instructions per access on it, more than the butterflies themselves).
+__host__ __device__ constexpr int lpad_c(int c) { return c + c / 16; }
+__device__ __forceinline__ int lpad_neg(int t) { return -t - ((t + 15) >> 4); }
+// offset of leg r of a radix-8 butterfly stored at stride p behind lpad(base), base = 8 (i - k) + k, k < p
+__host__ __device__ constexpr int lpad_leg(int p, int r) {
+  return p >= 16 ? r * p + (r * p) / 16 : (p == 8 ? 8 * r + (r >> 1) : r);
+}
 
 template <typename R, bool INV>
 __device__ __forceinline__ void dft4(cx<R> &u0, cx<R> &u1, cx<R> &u2, cx<R> &u3) {
@@ -250,9 +292,9 @@ template <int LOGB, typename R> struct Tw8 {
 #pragma unroll
         for (int s = 0; s < P::S; ++s) {
           const int k = (tid + s * P::NT) & (p - 1);
-          const cx<R> *t = tw8 + P::off8(j) + k * 8;
+          const cx<R> *t = tw8 + P::off8(j) + k;
 #pragma unroll
-          for (int r = 1; r < 8; ++r) t8[j - 1][s][r - 1] = t[r];
+          for (int r = 1; r < 8; ++r) t8[j - 1][s][r - 1] = t[r * p];
         }
       }
       if constexpr (P::Q == 2) {
@@ -261,9 +303,9 @@ template <int LOGB, typename R> struct Tw8 {
       } else if constexpr (P::Q == 4) {
 #pragma unroll
         for (int jb = 0; jb < P::E / 4; ++jb) {
-          const cx<R> *t = tw8 + P::offq + (tid + jb * P::NT) * 4;
+          const cx<R> *t = tw8 + P::offq + (tid + jb * P::NT);
 #pragma unroll
-          for (int r = 1; r < 4; ++r) tq[jb * 3 + r - 1] = t[r];
+          for (int r = 1; r < 4; ++r) tq[jb * 3 + r - 1] = t[r * (P::B / 4)];
         }
       }
     }
@@ -274,7 +316,7 @@ template <int LOGB, typename R> struct Tw8 {
     return mk<R>((R)(0.5f + 0.01f * r + 0.001f * (tid_ & 3)), (R)(0.25f * (s + 1) + 0.002f * j));
 #endif
     if constexpr (EAGER) return t8[j - 1][s][r - 1];
-    else return p8[P::off8(j) + ((tid_ + s * P::NT) & ((1 << (3 * j)) - 1)) * 8 + r];
+    else return p8[P::off8(j) + r * (1 << (3 * j)) + ((tid_ + s * P::NT) & ((1 << (3 * j)) - 1))];
   }
   // twiddle of the final pass: butterfly jb, leg r (radix-2: r = 1; radix-4: r = 1..3)
   __device__ __forceinline__ cx<R> wq(const int jb, const int r) const {
@@ -282,24 +324,74 @@ template <int LOGB, typename R> struct Tw8 {
     return mk<R>((R)(0.5f + 0.01f * r + 0.001f * (tid_ & 3)), (R)(0.25f * (jb + 1)));
 #endif
     if constexpr (EAGER) return P::Q == 2 ? tq[jb] : tq[jb * 3 + r - 1];
-    else return P::Q == 2 ? p1[tid_ + jb * P::NT] : p8[P::offq + (tid_ + jb * P::NT) * 4 + r];
+    else return P::Q == 2 ? p1[tid_ + jb * P::NT] : p8[P::offq + r * (P::B / 4) + tid_ + jb * P::NT];
   }
 };
 
 // v[e] = x[in_idx(e)] on entry, X[out_idx(e)] on exit (unscaled). `lds` holds LDS_ELEMS values.
 // Ends with all LDS reads done but NO trailing barrier.
+#ifdef RVC_ABLATE_NOBARRIER
+#define RVC_CORE_SYNC() do {} while (0)
+#else
+#define RVC_CORE_SYNC() __syncthreads()
+#endif
+#ifdef RVC_ABLATE_CORE_NOLDS
+#define RVC_CORE_LDS(stmt) do {} while (0)
+#else
+#define RVC_CORE_LDS(stmt) stmt
+#endif
 template <int LOGB, bool INV, typename R>
 __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, R> &T, const int tid) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
+  constexpr bool kLin = P::kLin;
+  constexpr bool kEager = Tw8<LOGB, R>::EAGER;
+  const int lt = lpad(tid);
+  // Big transforms (B >= 8192) cannot hold all their twiddles in registers and fetch them from L2 per
+  // pass. All waves of a workgroup reach a pass together (barriers), so a fetch issued where it is used
+  // stalls the whole CU for an L2 round trip, once per pass. They are requested ONE PASS AHEAD instead
+  // (w^k, w^2k, w^4k of the next radix-8 pass; the final radix-2/4 pass's during the last radix-8 pass):
+  // the latency hides behind this pass's butterflies and exchange.
+  constexpr int NQW = P::Q == 4 ? 3 * (P::E / 4) : (P::Q == 2 ? P::E / 2 : 1);
+  C nxt[P::S][3], tqn[NQW];
+  auto fetch8 = [&](const int j) {
+#pragma unroll
+    for (int s = 0; s < P::S; ++s) {
+      nxt[s][0] = T.w8(j, s, 1); nxt[s][1] = T.w8(j, s, 2); nxt[s][2] = T.w8(j, s, 4);
+    }
+  };
+  auto fetchq = [&]() {
+    if constexpr (P::Q == 2) {
+#pragma unroll
+      for (int jb = 0; jb < P::E / 2; ++jb) tqn[jb] = T.wq(jb, 1);
+    } else if constexpr (P::Q == 4) {
+#pragma unroll
+      for (int jb = 0; jb < P::E / 4; ++jb)
+#pragma unroll
+        for (int r = 1; r < 4; ++r) tqn[jb * 3 + r - 1] = T.wq(jb, r);
+    }
+  };
+  if constexpr (!kEager) {
+    if constexpr (P::N8 > 1) fetch8(1); else fetchq();
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int j = 0; j < P::N8; ++j) {
     const int p = 1 << (3 * j);
+    C cur[P::S][3];
+    if constexpr (!kEager) {
+      if (j > 0) {
+#pragma unroll
+        for (int s = 0; s < P::S; ++s) { cur[s][0] = nxt[s][0]; cur[s][1] = nxt[s][1]; cur[s][2] = nxt[s][2]; }
+        if (j + 1 < P::N8) fetch8(j + 1); else fetchq();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < P::S; ++s) {
       C *a = v + 8 * s;
       if (j > 0) {
-        if constexpr (Tw8<LOGB, R>::EAGER) {
+        if constexpr (kEager) {
 #pragma unroll
           for (int r = 1; r < 8; ++r) {
             C w = T.w8(j, s, r);
@@ -307,10 +399,9 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
             a[r] = cmul(a[r], w);
           }
         } else {
-          // big transforms (B >= 8192) re-read their twiddles from L2 in every pass, 7 x 8 bytes per
-          // thread -- more bytes than the data itself. Fetch w^k, w^2k, w^4k only and build the other
-          // four with one complex multiply each (twiddle error <= 2 roundings instead of 1).
-          C w1 = T.w8(j, s, 1), w2 = T.w8(j, s, 2), w4 = T.w8(j, s, 4);
+          // Fetch w^k, w^2k, w^4k only and build the other four with one complex multiply each: the seven
+          // twiddles of a butterfly are more bytes than its data (twiddle error <= 2 roundings instead of 1).
+          C w1 = cur[s][0], w2 = cur[s][1], w4 = cur[s][2];
           if (INV) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; }
           const C w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4);
           const C w7 = cmul(w3, w4);
@@ -320,27 +411,35 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
       }
       dft8<R, INV>(a);
     }
+#ifdef RVC_PHASE_TIMES
+    if (!INV && LOGB == 14 && j < 4) RVC_STAMP(1, 2 * j);
+#endif
     const bool last8 = (j == P::N8 - 1);
     if (!(last8 && P::Q == 1)) {
-      if (j > 0) __syncthreads();               // previous exchange fully read before overwriting
+      if (j > 0) RVC_CORE_SYNC();               // previous exchange fully read before overwriting
 #pragma unroll
       for (int s = 0; s < P::S; ++s) {
         const int i = tid + s * P::NT;
         const int k = i & (p - 1);
-        const int base = ((i - k) << 3) + k;
+        const int wb = lpad(((i - k) << 3) + k);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) lds[lpad(base + r * p)] = v[8 * s + r];
+        for (int r = 0; r < 8; ++r) RVC_CORE_LDS(lds[wb + lpad_leg(p, r)] = v[8 * s + r]);
       }
-      __syncthreads();
+      RVC_CORE_SYNC();
       if (!last8) {
 #pragma unroll
         for (int s = 0; s < P::S; ++s) {
-          const int i = tid + s * P::NT;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[8 * s + r] = lds[lpad(i + r * P::T)];
+          for (int r = 0; r < 8; ++r) {
+            if constexpr (kLin) RVC_CORE_LDS(v[8 * s + r] = lds[lt + lpad_c(s * P::NT + r * P::T)]);
+            else RVC_CORE_LDS(v[8 * s + r] = lds[lpad(tid + s * P::NT + r * P::T)]);
+          }
         }
       }
     }
+#ifdef RVC_PHASE_TIMES
+    if (!INV && LOGB == 14 && j < 4) RVC_STAMP(1, 2 * j + 1);
+#endif
   }
   if constexpr (P::Q > 1) {                      // final radix-2 / radix-4 pass, p = B/Q, k = i
     constexpr int NBF = P::E / P::Q;
@@ -350,9 +449,12 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
       const int i = tid + jb * P::NT;
       C *b = v + jb * P::Q;
 #pragma unroll
-      for (int r = 0; r < P::Q; ++r) b[r] = lds[lpad(i + r * ST)];
+      for (int r = 0; r < P::Q; ++r) {
+        if constexpr (kLin) RVC_CORE_LDS(b[r] = lds[lt + lpad_c(jb * P::NT + r * ST)]);
+        else RVC_CORE_LDS(b[r] = lds[lpad(i + r * ST)]);
+      }
       if constexpr (P::Q == 2) {
-        C w = T.wq(jb, 1);                       // e^{-2 pi i k / B}
+        C w = kEager ? T.wq(jb, 1) : tqn[jb];    // e^{-2 pi i k / B}
         if (INV) w.y = -w.y;
         const C x1 = cmul(b[1], w);
         const C x0 = b[0];
@@ -360,7 +462,7 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
       } else {
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
-          C w = T.wq(jb, r);
+          C w = kEager ? T.wq(jb, r) : tqn[jb * 3 + r - 1];
           if (INV) w.y = -w.y;
           b[r] = cmul(b[r], w);
         }
@@ -378,7 +480,20 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   constexpr int B = P::B;
   const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;   // sub-transform of this workgroup
   C *lds = reinterpret_cast<C *>(smem_raw) + sub * P::LDS_ELEMS;
-  const int r_ = blockIdx.x * P::TPW + sub, c = blockIdx.y;
+  // XCD-aware placement: consecutive rows read overlapping input (block k-1 | block k), and workgroups
+  // go to the 8 XCDs (one L2 each) round-robin by linear id. Give every XCD a CONTIGUOUS run of
+  // (channel, row) items so that the shared half of two neighbours meets in one L2 instead of being
+  // fetched from HBM twice.
+  int bx = blockIdx.x, c = blockIdx.y;
+  {
+    const unsigned G = gridDim.x, total = G * gridDim.y;
+    const unsigned lin = blockIdx.x + G * blockIdx.y;
+    const unsigned xcd = lin & 7u, slot = lin >> 3;
+    const unsigned item = xcd * (total >> 3) + (xcd < (total & 7u) ? xcd : (total & 7u)) + slot;
+    bx = (int)(item % G);
+    c = (int)(item / G);
+  }
+  const int r_ = bx * P::TPW + sub;
   const bool live = r_ < a.rows;      // a dead sub-transform computes on zeros and stores nothing
   const float *src = a.src + (long long)c * a.src_chan_stride;
   const float *src2 = a.src2 ? a.src2 + (long long)c * a.src2_chan_stride : nullptr;
@@ -387,6 +502,10 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   const C *tw8 = reinterpret_cast<const C *>(a.tw8);
   const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
 
+  RVC_STAMP(0, 0);
+#if defined(RVC_ABLATE_FWD_STOP) && RVC_ABLATE_FWD_STOP == 0
+  if (a.rows > 0) return;
+#endif
   Tw8<LOGB, R> T;
   T.load(tw8, tw, tid);
   C v[P::E];
@@ -396,7 +515,40 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   // with a second source the 8-byte loads need it even-aligned relative to the sample clock
   const bool s2ok = !src2 || (((a.src2_from & 1) == 0) && ((reinterpret_cast<uintptr_t>(src2) & 7u) == 0));
   float *ring_out = a.ring_out ? a.ring_out + (long long)c * a.ring_out_chan_stride : nullptr;
+  // Each half of the segment (block k-1 and block k) usually lies contiguously in ONE source -- the ring
+  // or the call's own input: then a wave-uniform base pointer + 32-bit lane offsets address it, instead of
+  // 64-bit masked index arithmetic per value. (e & 7) < 4 <=> the value belongs to the first half.
+  const float *half_base[2] = {nullptr, nullptr};
   if (whole && s2ok) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const long long n0 = seg + (long long)h * B;
+      if (src2 && n0 >= a.src2_from) half_base[h] = src2 + (n0 - a.src2_from);
+      else if (!src2 || n0 + B <= a.src2_from) {
+        const unsigned long long o = (unsigned long long)n0 & a.src_mask;
+        if (a.src_mask == ~0ull || o + B <= a.src_mask + 1ull) half_base[h] = src + o;   // no wrap inside
+      }
+    }
+  }
+  const bool keep_hist = ring_out && seg + 2 * B > a.ring_out_from;   // uniform: only the last rows of a call
+  if (half_base[0] && half_base[1]) {
+    const float2 *b0 = reinterpret_cast<const float2 *>(half_base[0]);
+    const float2 *b1 = reinterpret_cast<const float2 *>(half_base[1]) - B / 2;
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      const unsigned m = (unsigned)P::in_idx(tid, e);
+#ifdef RVC_ABLATE_FFT_NOLOAD
+      const float2 x = make_float2(1e-3f * (float)(m & 1023), (float)(m & 7) + (b0 == nullptr ? 1.f : 0.f));
+#else
+      const float2 x = ((e & 7) < 4 ? b0 : b1)[m];
+#endif
+      v[e] = mk<R>((R)x.x, (R)x.y);
+      if ((e & 7) >= 4 && keep_hist) {
+        const long long n = seg + 2 * (long long)m;
+        if (n >= a.ring_out_from) *reinterpret_cast<float2 *>(ring_out + ((unsigned long long)n & a.ring_out_mask)) = x;
+      }
+    }
+  } else if (whole && s2ok) {
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       const int m = P::in_idx(tid, e);
@@ -413,9 +565,13 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
     for (int e = 0; e < P::E; ++e) {
       const int q = 2 * P::in_idx(tid, e);
       const long long n0 = seg + q, n1 = n0 + 1;
-      float v0 = 0.f, v1 = 0.f;
-      if (live && q < a.valid_len && n0 >= a.lo && n0 < a.hi) v0 = load_sample(a, src, src2, n0);
-      if (live && q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi) v1 = load_sample(a, src, src2, n1);
+      // Unconditional loads from a clamped, always legal address + a select: loads under a branch are
+      // issued one at a time (32 serialised memory round trips per thread -- the boundary rows of a long
+      // call then took longer than all the other rows together and set the kernel's duration).
+      const bool ok0 = live && q < a.valid_len && n0 >= a.lo && n0 < a.hi;
+      const bool ok1 = live && q + 1 < a.valid_len && n1 >= a.lo && n1 < a.hi;
+      const float x0 = *sample_ptr(a, src, src2, n0, ok0), x1 = *sample_ptr(a, src, src2, n1, ok1);
+      const float v0 = ok0 ? x0 : 0.f, v1 = ok1 ? x1 : 0.f;
       v[e] = mk<R>((R)v0, (R)v1);
       if (live && ring_out && q >= B) {
         if (n0 >= a.ring_out_from && n0 >= a.lo && n0 < a.hi) ring_out[(unsigned long long)n0 & a.ring_out_mask] = v0;
@@ -433,42 +589,80 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
     int q = 0;
 #pragma unroll
     for (int e = 0; e < P::E; ++e)
-      if (P::out_is_low(e)) ws[q++] = wsplit[P::out_idx(tid, e)];
+      if (P::out_is_low(e)) ws[q++] = wsplit[(unsigned)P::out_idx(tid, e)];
   };
-  if constexpr (kEager) load_ws();
+#if defined(RVC_ABLATE_FWD_STOP) && RVC_ABLATE_FWD_STOP == 1
+  if (a.rows > 0) { if (v[0].x == (R)12345.678) a.dst[0] = make_float2((float)v[1].x, (float)v[P::E - 1].y); return; }
+#endif
+  load_ws();   // requested before the transform: the latency hides behind it
+  RVC_STAMP(0, 1);
+#ifndef RVC_ABLATE_FFT_NOCORE
   fft8_core<LOGB, false, R>(v, lds, T, tid);
-  if constexpr (!kEager) load_ws();
+#endif
+  RVC_STAMP(0, 2);
+#if defined(RVC_ABLATE_FWD_STOP) && RVC_ABLATE_FWD_STOP == 2
+  if (a.rows > 0) { if (v[0].x == (R)12345.678) a.dst[0] = make_float2((float)v[1].x + (float)ws[0].x, (float)v[P::E - 1].y); return; }
+#endif
 
+  constexpr bool kLin = P::kLin;
+  const int lt = lpad(tid), ln = lpad_neg(tid);
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < P::E; ++e)
-    if (!P::out_is_low(e)) lds[lpad(P::out_idx(tid, e))] = v[e];   // only the high half is ever fetched by a partner
+    if (!P::out_is_low(e)) {   // only the high half is ever fetched by a partner
+      if constexpr (kLin) lds[lt + lpad_c(P::out_c(e))] = v[e];
+      else lds[lpad(P::out_idx(tid, e))] = v[e];
+    }
   __syncthreads();
   float2 *dst = a.dst + (long long)c * a.dst_chan_stride +
                 (long long)(((unsigned long long)(a.row0 + r_)) & a.row_mask) * B;
   const R half = (R)0.5;
+  RVC_STAMP(0, 3);
+#if defined(RVC_ABLATE_FWD_STOP) && RVC_ABLATE_FWD_STOP == 3
+  if (a.rows > 0) { if (v[0].x == (R)12345.678) a.dst[0] = make_float2((float)v[1].x + (float)ws[0].x, (float)v[P::E - 1].y); return; }
+#endif
   if (!live) return;                                   // (after the last barrier)
+  // all partner reads first (back to back, one wait), then the arithmetic. k == 0 exists only for
+  // (tid, e) = (0, 0); its partner slot is redirected to a valid address and its result replaced below.
+  C Zp[P::E / 2];
+  {
+    int q = 0;
+#pragma unroll
+    for (int e = 0; e < P::E; ++e)
+      if (P::out_is_low(e)) {
+        int idx;
+        if constexpr (kLin) idx = ln + lpad_c(B - P::out_c(e));
+        else idx = lpad(B - P::out_idx(tid, e));
+        if (e == 0) idx = tid == 0 ? lpad(B / 2) : idx;
+        Zp[q++] = lds[idx];
+      }
+  }
   int q = 0;
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
-    const int k = P::out_idx(tid, e);
+    const unsigned k = (unsigned)P::out_idx(tid, e);
     const C A = v[e];
+#ifdef RVC_ABLATE_FFT_NOSTORE
+    if (A.x != (R)12345.678) continue;
+#endif
     if (P::out_is_low(e)) {
-      const C w = ws[q++];
-      if (k == 0) {
-        dst[0] = make_float2((float)(A.x + A.y), (float)(A.x - A.y));   // packed (DC, Nyquist)
-      } else {
-        const C Bc = cconj(lds[lpad(B - k)]);
-        const C Ev = mk<R>(half * (A.x + Bc.x), half * (A.y + Bc.y));
-        const C D = mk<R>(half * (A.x - Bc.x), half * (A.y - Bc.y));
-        const C wO = cmul(w, mk<R>(D.y, -D.x));        // w^k * (-i D)
-        dst[k] = make_float2((float)(Ev.x + wO.x), (float)(Ev.y + wO.y));
-        dst[B - k] = make_float2((float)(Ev.x - wO.x), (float)(wO.y - Ev.y));   // conj(E - w^k O)
-      }
-    } else if (k == B / 2) {
+      const C w = ws[q];
+      const C Bc = cconj(Zp[q]);                       // conj Z[B - k]
+      ++q;
+      const C Ev = mk<R>(half * (A.x + Bc.x), half * (A.y + Bc.y));
+      const C D = mk<R>(half * (A.x - Bc.x), half * (A.y - Bc.y));
+      const C wO = cmul(w, mk<R>(D.y, -D.x));          // w^k * (-i D)
+      float2 x0 = make_float2((float)(Ev.x + wO.x), (float)(Ev.y + wO.y));
+      const float2 x1 = make_float2((float)(Ev.x - wO.x), (float)(wO.y - Ev.y));   // conj(E - w^k O)
+      const bool dc = (e == 0) && tid == 0;
+      if (dc) x0 = make_float2((float)(A.x + A.y), (float)(A.x - A.y));   // packed (DC, Nyquist)
+      dst[k] = x0;
+      if (!dc) dst[(unsigned)B - k] = x1;
+    } else if (k == (unsigned)B / 2) {
       dst[k] = make_float2((float)A.x, (float)-A.y);   // X[B/2] = conj(Z[B/2]) (its own partner)
     }
   }
+  RVC_STAMP(0, 4);
 }
 
 template <int LOGB, typename R>
@@ -494,45 +688,95 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   // thread's indices are "low" (k < B/2). For each low k it loads Y[k], Y[B-k] and one twiddle and
   // forms BOTH Z[k] = E + iO (kept) and Z[B-k] = conj(E) + i conj(O) (handed to its owner through
   // LDS). One exchange instead of loading every Y twice and every twiddle once per bin.
+  RVC_STAMP(2, 0);
   Tw8<LOGB, R> T;
   T.load(tw8, tw, tid);
   C v[P::E];
   const R sc = (R)0.5 / (R)B;
+  constexpr bool kLin = P::kLin;
+  const int lt = lpad(tid), ln = lpad_neg(tid);
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     if ((e & 7) < 4) {                                   // in_idx(tid, e) < B/2
-      const int k = P::in_idx(tid, e);
+      const unsigned k = (unsigned)P::in_idx(tid, e);
+#ifdef RVC_ABLATE_FFT_NOLOAD
+      const float2 yk = make_float2(1e-3f * (float)(k & 1023), (float)(k & 7) + (Y == nullptr ? 1.f : 0.f));
+#else
       const float2 yk = Y[k];
+#endif
       if (k == 0) {
         v[e] = mk<R>(sc * ((R)yk.x + (R)yk.y), sc * ((R)yk.x - (R)yk.y));
         const float2 yh = Y[B / 2];                      // and the self-paired bin B/2: Z = conj(Y) / B
         lds[lpad(B / 2)] = mk<R>((R)2 * sc * (R)yh.x, -(R)2 * sc * (R)yh.y);
       } else {
-        const float2 yc = Y[B - k];
+#ifdef RVC_ABLATE_FFT_NOLOAD
+        const float2 yc = make_float2(2e-3f * (float)(k & 511), (float)(k & 3));
+#else
+        const float2 yc = Y[(unsigned)B - k];
+#endif
         const C Yk = mk<R>((R)yk.x, (R)yk.y), Yc = mk<R>((R)yc.x, -(R)yc.y);
         const C Ev = mk<R>(sc * (Yk.x + Yc.x), sc * (Yk.y + Yc.y));
         const C D = mk<R>(sc * (Yk.x - Yc.x), sc * (Yk.y - Yc.y));
         const C O = cmul(cconj(wsplit[k]), D);
         v[e] = mk<R>(Ev.x - O.y, Ev.y + O.x);            // Z[k]   = E + iO
-        lds[lpad(B - k)] = mk<R>(Ev.x + O.y, O.x - Ev.y);   // Z[B-k] = conj(E) + i conj(O)
+        const C zc = mk<R>(Ev.x + O.y, O.x - Ev.y);      // Z[B-k] = conj(E) + i conj(O)
+        if constexpr (kLin) lds[ln + lpad_c(B - P::in_c(e))] = zc;
+        else lds[lpad(B - (int)k)] = zc;
       }
     }
   }
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < P::E; ++e)
-    if ((e & 7) >= 4) v[e] = lds[lpad(P::in_idx(tid, e))];
+    if ((e & 7) >= 4) {
+      if constexpr (kLin) v[e] = lds[lt + lpad_c(P::in_c(e))];
+      else v[e] = lds[lpad(P::in_idx(tid, e))];
+    }
   __syncthreads();                                       // the transform's first exchange overwrites the buffer
+  RVC_STAMP(2, 1);
+#ifndef RVC_ABLATE_FFT_NOCORE
   fft8_core<LOGB, true, R>(v, lds, T, tid);
+#endif
+  RVC_STAMP(2, 2);
 
   // z[m] = (s[2m], s[2m+1]); the overlap-save output is s[B..2B) = z[B/2..B): 8-byte stores
   float *dst = a.dst + (long long)c * a.dst_chan_stride;
   const float *add = a.add ? a.add + (long long)c * a.add_chan_stride : nullptr;
   const bool whole = nblk >= a.lo && nblk + B <= a.hi;      // every sample of the block is wanted
   if (!live) return;                                        // (after the last barrier)
+  // Common case: the whole block goes to one contiguous, 8-byte aligned run of dst (and of the add
+  // stream): wave-uniform base pointers + 32-bit lane offsets instead of 64-bit masked indices per value.
+  const unsigned long long o_dst = (unsigned long long)(nblk - a.dst_origin) & a.dst_mask;
+  const unsigned long long o_add = (unsigned long long)nblk & a.add_mask;
+  const bool add_all = add && nblk >= a.add_from;           // add_from is a multiple of the (even) block sizes
+  const bool flat = whole && (a.dst_mask == ~0ull || o_dst + B <= a.dst_mask + 1ull) && ((o_dst & 1ull) == 0ull) &&
+                    ((reinterpret_cast<uintptr_t>(dst) & 7u) == 0u) &&
+                    (!add || nblk + B <= a.add_from ||
+                     (add_all && (a.add_mask == ~0ull || o_add + B <= a.add_mask + 1ull)));
+  if (flat) {
+    float2 *ob = reinterpret_cast<float2 *>(dst + o_dst) - B / 2;          // ob[m] <-> samples nblk + 2m - B
+    const float2 *ab = add_all ? reinterpret_cast<const float2 *>(add + o_add) - B / 2 : nullptr;
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      if (!P::out_is_low(e)) {
+        const unsigned m = (unsigned)P::out_idx(tid, e);
+#ifdef RVC_ABLATE_FFT_NOSTORE
+        if (v[e].x != (R)12345.678) continue;
+#endif
+        float2 o = make_float2((float)v[e].x, (float)v[e].y);
+        if (ab) { const float2 t = ab[m]; o.x += t.x; o.y += t.y; }
+        ob[m] = o;
+      }
+    }
+    RVC_STAMP(2, 3);
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int m = P::out_idx(tid, e);
+#ifdef RVC_ABLATE_FFT_NOSTORE
+    if (v[e].x != (R)12345.678) continue;
+#endif
     if (m >= B / 2) {
       const int p0 = 2 * m - B;
       const long long n = nblk + p0;
@@ -550,16 +794,18 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
           dst[(unsigned long long)(n + 1 - a.dst_origin) & a.dst_mask] = o.y;
         }
       } else {
-        if (n >= a.lo && n < a.hi) {
-          float t = o.x;
-          if (add && n >= a.add_from) t += add[(unsigned long long)n & a.add_mask];
-          dst[(unsigned long long)(n - a.dst_origin) & a.dst_mask] = t;
+        // partially wanted block (first / last row of a call): the add-stream loads are unconditional
+        // (clamped to add_from, always inside the ring) so that they are issued together, not one by one
+        float t0 = o.x, t1 = o.y;
+        if (add) {
+          const bool a0 = n >= a.add_from, a1 = n + 1 >= a.add_from;
+          const float u0 = add[(unsigned long long)(a0 ? n : a.add_from) & a.add_mask];
+          const float u1 = add[(unsigned long long)(a1 ? n + 1 : a.add_from) & a.add_mask];
+          t0 += a0 ? u0 : 0.f;
+          t1 += a1 ? u1 : 0.f;
         }
-        if (n + 1 >= a.lo && n + 1 < a.hi) {
-          float t = o.y;
-          if (add && n + 1 >= a.add_from) t += add[(unsigned long long)(n + 1) & a.add_mask];
-          dst[(unsigned long long)(n + 1 - a.dst_origin) & a.dst_mask] = t;
-        }
+        if (n >= a.lo && n < a.hi) dst[(unsigned long long)(n - a.dst_origin) & a.dst_mask] = t0;
+        if (n + 1 >= a.lo && n + 1 < a.hi) dst[(unsigned long long)(n + 1 - a.dst_origin) & a.dst_mask] = t1;
       }
     }
   }
