@@ -98,8 +98,9 @@ struct rvc_set {
   long long keep = 0;            // input history (samples) a long call leaves in the time ring
   float *xring = nullptr, *tailring = nullptr;
   size_t ring_cap = 0;
-  float2 *ypre = nullptr;        // [nch][head block]: pre-multiplied accumulator of block ypre_block
-  long long ypre_block = -1;     // (fused single-block path); -1 = not valid
+  float2 *ypre = nullptr;        // [2][nch][head block]: pre-multiplied accumulator of block ypre_block in half
+  long long ypre_block = -1;     // (ypre_block & 1) (fused single-block path); -1 = not valid
+  bool fold = false;             // one launch per block: H_1 X_{k-1} folded into the fused kernel, ypre = sum_{i>=2}
   float *d_in = nullptr, *d_out = nullptr;     // staging for the host-pointer API [nch][max_len]
   float *h_in = nullptr, *h_out = nullptr;     // pinned
   long long n = 0;               // absolute sample clock
@@ -421,9 +422,10 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   s->ring_cap = next_pow2(s->max_len + (size_t)s->keep + 6 * std::max(span, pw > 0 ? wb : (size_t)0) + 4 * hb);
   RVC_CK(hipMalloc(&s->xring, sizeof(float) * (size_t)s->nch * s->ring_cap));
   if (pt > 0) RVC_CK(hipMalloc(&s->tailring, sizeof(float) * (size_t)s->nch * s->ring_cap));
-  RVC_CK(hipMalloc(&s->ypre, sizeof(float2) * (size_t)s->nch * A.B));
-  RVC_CK(hipMemset(s->ypre, 0, sizeof(float2) * (size_t)s->nch * A.B));
+  RVC_CK(hipMalloc(&s->ypre, sizeof(float2) * 2 * (size_t)s->nch * A.B));
+  RVC_CK(hipMemset(s->ypre, 0, sizeof(float2) * 2 * (size_t)s->nch * A.B));
   s->ypre_block = -1;
+  s->fold = rvc::fused_fold_supported(A.logB) && !want64;
   RVC_CK(hipMalloc(&s->d_in, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipMalloc(&s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipHostMalloc(&s->h_in, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
@@ -636,14 +638,22 @@ bool head_stage(rvc_set *s, long long n0, long long na, long long nb, const floa
 
 // Ypre_kb = sum_{i>=1} H_i X_{kb-i}: everything of block kb's spectrum that does not depend on
 // block kb's own input (FFTConvolver.cpp:176-185)
-bool run_premultiply(rvc_set *s, long long kb) {
+// (with s->fold the H_1 X_{kb-1} term moves into block kb's fused kernel and this is sum_{i>=2})
+rvc::FirArgs premultiply_args(rvc_set *s, long long kb) {
   Stage &A = s->A;
-  if (A.P > 1) {
-    rvc::FirArgs r{};
-    r.H = A.H + A.B; r.h_chan_stride = (long long)A.P * (long long)A.B;
-    r.X = A.X; r.x_chan_stride = (long long)A.rows * (long long)A.B; r.x_row_mask = A.rows - 1;
-    r.Y = s->ypre; r.y_chan_stride = (long long)A.B;
-    r.k0 = kb; r.M = 1; r.P = A.P - 1; r.delay = 1; r.B = (int)A.B;
+  const int d = s->fold ? 2 : 1;
+  rvc::FirArgs r{};
+  r.H = A.H + (size_t)d * A.B; r.h_chan_stride = (long long)A.P * (long long)A.B;
+  r.X = A.X; r.x_chan_stride = (long long)A.rows * (long long)A.B; r.x_row_mask = A.rows - 1;
+  r.Y = s->ypre + (size_t)(kb & 1) * (size_t)s->nch * A.B; r.y_chan_stride = (long long)A.B;
+  r.k0 = kb; r.M = 1; r.P = A.P - d; r.delay = d; r.B = (int)A.B;
+  if (r.P < 0) r.P = 0;
+  return r;
+}
+
+bool run_premultiply(rvc_set *s, long long kb) {
+  const rvc::FirArgs r = premultiply_args(s, kb);
+  if (r.P > 0) {      // (no partitions beyond the folded ones: the accumulator stays zero, as allocated)
     Timer t(s, 8, s->st_main);
     RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
   }
@@ -692,22 +702,36 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     g.n0 = n0; g.n1 = n1; g.k = k0;
     g.tw = A.tw; g.wsplit = A.wsplit; g.tw8 = A.tw8;
     g.H0 = A.H; g.h_chan_stride = (long long)A.P * hb;
-    g.Ypre = s->ypre; g.ypre_chan_stride = hb;
+    g.H1 = (s->fold && A.P > 1) ? A.H + hb : nullptr;
+    g.Ypre = s->ypre + (size_t)(k0 & 1) * (size_t)s->nch * (size_t)hb; g.ypre_chan_stride = hb;
     g.Xrow = A.X; g.x_chan_stride = (long long)A.rows * hb; g.x_row_mask = A.rows - 1;
     g.out = d_out; g.out_chan_stride = (long long)out_stride;
     g.add = has_tail ? s->tailring : nullptr;
     g.add_chan_stride = (long long)s->ring_cap; g.add_mask = s->ring_cap - 1;
     g.add_from = has_tail ? 2 * (long long)T.B : 0;
-    {
-      Timer t(s, 7, s->st_main);
-      RVC_CK(rvc::launch_fused(A.logB, g, s->nch, s->st_main));
+    const bool block_done = n1 % hb == 0;
+    if (s->fold) {
+      // the workgroups appended to this launch prepare block k0+1's accumulator (other half of ypre)
+      rvc::FirArgs f = premultiply_args(s, k0 + 1);
+      if (!block_done) f.P = 0;
+      {
+        Timer t(s, 7, s->st_main);
+        RVC_CK(rvc::launch_fused2(A.logB, g, f, s->nch, s->st_main));
+      }
+      if (!emit_output_copy(s)) return false;
+      if (block_done) s->ypre_block = k0 + 1;
+    } else {
+      {
+        Timer t(s, 7, s->st_main);
+        RVC_CK(rvc::launch_fused(A.logB, g, s->nch, s->st_main));
+      }
+      if (!emit_output_copy(s)) return false;
     }
-    if (!emit_output_copy(s)) return false;
-    s->xa_next = (n1 % hb == 0) ? k0 + 1 : k0;
-    // off the latency path: the tail job if a tail block just completed, and the pre-multiplied
-    // accumulator of the next block if this one is complete
+    s->xa_next = block_done ? k0 + 1 : k0;
+    // off the latency path: the tail job if a tail block just completed, and (two-launch scheme) the
+    // pre-multiplied accumulator of the next block if this one is complete
     if (has_tail && !run_tail_job(s, n0, n1, nullptr, in_stride, bg)) return false;
-    if (n1 % hb == 0 && !run_premultiply(s, k0 + 1)) return false;
+    if (!s->fold && block_done && !run_premultiply(s, k0 + 1)) return false;
     s->n = n1;
     return true;
   }

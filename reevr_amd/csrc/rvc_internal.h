@@ -93,8 +93,9 @@ struct FusedArgs {
   long long k;              // block index
   const void *tw, *wsplit, *tw8;
   const float2 *H0;         // [channel][B] partition 0 of the IR spectra
+  const float2 *H1;         // partition 1 (k_fused_block2 only; nullptr when the stage has one partition)
   long long h_chan_stride;
-  const float2 *Ypre;       // [channel][B]
+  const float2 *Ypre;       // [channel][B]: sum_{i>=1} H_i X_{k-i} (k_fused_block) / sum_{i>=2} (k_fused_block2)
   long long ypre_chan_stride;
   float2 *Xrow;             // [channel][rows][B]: where X_k is stored for later blocks
   long long x_chan_stride;
@@ -128,6 +129,10 @@ bool fwd_appends_ring(int logB);
 // fused single-block step; supported for 6 <= logB <= 13 (float transforms only)
 bool fused_supported(int logB, bool f64);
 hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t st);
+// One launch per block: the audio path with H_1 X_{k-1} folded in (a.Ypre = sum_{i>=2}) plus, when
+// f.P > 0, the workgroups that compute the next block's sum_{i>=2} (f: M = 1 row, any delay).
+bool fused_fold_supported(int logB);
+hipError_t launch_fused2(int logB, const FusedArgs &a, const FirArgs &f, int channels, hipStream_t st);
 hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st);
 // arm (a, b) / disarm (nullptr, nullptr) kernel-exact timing events for the next launch on this thread
 void set_launch_events(hipEvent_t a, hipEvent_t b);

@@ -813,17 +813,21 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
 
 // ----------------------------------------------------------------------------------------
 // fused streaming step: everything the plugin's per-block process() needs in ONE launch
-// (TwoStageFFTConvolver.cpp:151-233 for len <= head block). One workgroup per channel.
+// (TwoStageFFTConvolver.cpp:151-233 for len <= head block). One workgroup per channel
+// (several channels per workgroup for B < 512).
+//   FOLD = false: Y_k = H_0 X_k + Ypre,  Ypre = sum_{i>=1} H_i X_{k-i}  (made by a k_fir_row launch)
+//   FOLD = true : Y_k = H_0 X_k + H_1 X_{k-1} + Ypre,  Ypre = sum_{i>=2} H_i X_{k-i}. That sum needs
+//                 nothing of block k-1's launch, so the workgroups appended to the launch of block
+//                 k-1 (k_fused_block2) compute it: ONE launch per block instead of two dependent ones.
 // ----------------------------------------------------------------------------------------
-template <int LOGB>
-__global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fused_block(const FusedArgs a) {
+template <int LOGB, bool FOLD>
+__device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, const int wg) {
   typedef Plan8<LOGB> P;
   typedef cx<float> C;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int B = P::B;
   const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;
   C *lds = reinterpret_cast<C *>(smem_raw) + sub * P::LDS_ELEMS;
-  const int c_raw = blockIdx.x * P::TPW + sub;
+  const int c_raw = wg * P::TPW + sub;
   const bool live = c_raw < a.channels;     // a dead sub-transform shadows the last channel and stores nothing
   const int c = live ? c_raw : a.channels - 1;
   const float *in = a.in + (long long)c * a.in_chan_stride;
@@ -841,27 +845,40 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fused_block(const FusedArgs
   const float2 *Ypre = a.Ypre + (long long)c * a.ypre_chan_stride;
   C wso[P::E], wsi[P::E];
   float2 h0[P::E], ypre[P::E];
+  float2 h1[FOLD ? P::E : 1], xp[FOLD ? P::E : 1];
+  const bool fold = FOLD && a.H1 && a.k >= 1;     // partition 1 exists and block k-1 is not before time 0
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     wso[e] = wsplit[P::out_idx(tid, e)];
     wsi[e] = wsplit[P::in_idx(tid, e)];
     h0[e] = H0[P::out_idx(tid, e)];
     ypre[e] = Ypre[P::out_idx(tid, e)];
+    if constexpr (FOLD) {
+      // (clamped to row k when there is no block k-1: any resident row, the product is dropped below)
+      const float2 *H1 = (fold ? a.H1 : a.H0) + (long long)c * a.h_chan_stride;
+      const float2 *Xp = a.Xrow + (long long)c * a.x_chan_stride +
+                         (long long)((unsigned long long)(fold ? a.k - 1 : a.k) & a.x_row_mask) * B;
+      h1[e] = H1[P::out_idx(tid, e)];
+      xp[e] = Xp[P::out_idx(tid, e)];
+    }
   }
   // 1. load the segment: history from the ring, this call's samples from `in` (and append them
   //    to the ring), zero for the not-yet-played rest of block k and for time < 0
   C v[P::E];
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
+    // unconditional loads from an always legal address, then selects: loads under a branch would be
+    // issued one memory round trip at a time
     const long long n = seg + 2 * P::in_idx(tid, e);
-    float s0 = 0.f, s1 = 0.f;
-    if (n >= a.n0) {
-      if (n < a.n1) { s0 = in[n - a.n0]; if (live) ring[(unsigned long long)n & a.ring_mask] = s0; }
-    } else if (n >= 0) s0 = ring[(unsigned long long)n & a.ring_mask];
     const long long m = n + 1;
-    if (m >= a.n0) {
-      if (m < a.n1) { s1 = in[m - a.n0]; if (live) ring[(unsigned long long)m & a.ring_mask] = s1; }
-    } else if (m >= 0) s1 = ring[(unsigned long long)m & a.ring_mask];
+    const bool n_in = n >= a.n0 && n < a.n1, m_in = m >= a.n0 && m < a.n1;      // this call's samples
+    const bool n_hist = n < a.n0 && n >= 0, m_hist = m < a.n0 && m >= 0;       // history (else: zero)
+    const float *pn = n_in ? in + (n - a.n0) : ring + ((unsigned long long)(n_hist ? n : 0) & a.ring_mask);
+    const float *pm = m_in ? in + (m - a.n0) : ring + ((unsigned long long)(m_hist ? m : 0) & a.ring_mask);
+    const float ln = *pn, lm = *pm;
+    const float s0 = (n_in || n_hist) ? ln : 0.f, s1 = (m_in || m_hist) ? lm : 0.f;
+    if (live && n_in) ring[(unsigned long long)n & a.ring_mask] = s0;
+    if (live && m_in) ring[(unsigned long long)m & a.ring_mask] = s1;
     v[e] = mk<float>(s0, s1);
   }
   // 2. forward transform, real split; X_k goes to the delay line and, times H0 plus the
@@ -877,7 +894,15 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fused_block(const FusedArgs
   for (int e = 0; e < P::E; ++e) {
     const int k = P::out_idx(tid, e);
     const C A = v[e];
-    const float2 h = h0[e], yp = ypre[e];
+    const float2 h = h0[e];
+    float2 yp = ypre[e];
+    if constexpr (FOLD) {
+      if (fold) {                                                     // + H_1 X_{k-1}
+        const float2 g = h1[e], x = xp[e];
+        if (k == 0) yp = make_float2(fmaf(g.x, x.x, yp.x), fmaf(g.y, x.y, yp.y));
+        else yp = make_float2(fmaf(g.x, x.x, fmaf(-g.y, x.y, yp.x)), fmaf(g.x, x.y, fmaf(g.y, x.x, yp.y)));
+      }
+    }
     if (k == 0) {
       const float2 X = make_float2(A.x + A.y, A.x - A.y);             // packed (DC, Nyquist)
       if (live) Xrow[0] = X;
@@ -924,18 +949,24 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fused_block(const FusedArgs
     const int m = P::out_idx(tid, e);
     if (m >= B / 2) {
       const long long n = nblk + 2 * m - B;
-      if (n >= a.n0 && n < a.n1) {
-        float t = v[e].x;
-        if (add && n >= a.add_from) t += add[(unsigned long long)n & a.add_mask];
-        out[n - a.n0] = t;
+      float t0 = v[e].x, t1 = v[e].y;
+      if (add) {                         // unconditional (clamped) loads of the tail stream, then selects
+        const bool a0 = n >= a.add_from, a1 = n + 1 >= a.add_from;
+        const float u0 = add[(unsigned long long)(a0 ? n : a.add_from) & a.add_mask];
+        const float u1 = add[(unsigned long long)(a1 ? n + 1 : a.add_from) & a.add_mask];
+        t0 += a0 ? u0 : 0.f;
+        t1 += a1 ? u1 : 0.f;
       }
-      if (n + 1 >= a.n0 && n + 1 < a.n1) {
-        float t = v[e].y;
-        if (add && n + 1 >= a.add_from) t += add[(unsigned long long)(n + 1) & a.add_mask];
-        out[n + 1 - a.n0] = t;
-      }
+      if (n >= a.n0 && n < a.n1) out[n - a.n0] = t0;
+      if (n + 1 >= a.n0 && n + 1 < a.n1) out[n + 1 - a.n0] = t1;
     }
   }
+}
+
+template <int LOGB>
+__global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fused_block(const FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  fused_audio<LOGB, false>(a, smem_raw, blockIdx.x);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1204,13 +1235,10 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
 // each keeps 8 independent row pairs in flight, and the partial sums meet in LDS.
 // grid (ceil(B/64), channels), block 256.
 // ----------------------------------------------------------------------------------------
-template <int STAGE>
-__global__ void __launch_bounds__(256) k_fir_row(const FirArgs a) {
-  __shared__ float2 part[4][64];
+__device__ __forceinline__ void fir_row_body(const FirArgs &a, float2 (*part)[64], const int bx, const int c) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bin = blockIdx.x * 64 + lane;
-  const int c = blockIdx.y;
+  const int bin = bx * 64 + lane;
   const bool active = bin < a.B;
   const int b = active ? bin : 0;
   const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride + b;
@@ -1248,6 +1276,31 @@ __global__ void __launch_bounds__(256) k_fir_row(const FirArgs a) {
   if (wave == 0 && active) {
     const float2 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
     a.Y[(long long)c * a.y_chan_stride + bin] = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+  }
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(256) k_fir_row(const FirArgs a) {
+  __shared__ float2 part[4][64];
+  fir_row_body(a, part, blockIdx.x, blockIdx.y);
+}
+
+// One launch per block of the streaming path: workgroups [0, n_audio) run block k's audio path
+// (fused_audio<FOLD = true>), the rest compute sum_{i>=2} H_i X_{k+1-i} for block k+1 (fir_row_body;
+// FirArgs f, one workgroup per 64 bins and channel). The two parts are independent inside the launch.
+// Launched with max(Plan8::WG, 256) threads: the surplus waves of either part retire at once (a
+// terminated wave no longer counts at s_barrier).
+template <int LOGB>
+__global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256))
+k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int fir_bx) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if ((int)blockIdx.x < n_audio) {
+    if ((int)threadIdx.x >= Plan8<LOGB>::WG) return;
+    fused_audio<LOGB, true>(a, smem_raw, blockIdx.x);
+  } else {
+    if (threadIdx.x >= 256) return;
+    const int idx = (int)blockIdx.x - n_audio;
+    fir_row_body(f, reinterpret_cast<float2 (*)[64]>(smem_raw), idx % fir_bx, idx / fir_bx);
   }
 }
 
@@ -1361,6 +1414,37 @@ static hipError_t launch_fused_t(const FusedArgs &a, int channels, hipStream_t s
   b.channels = channels;
   RVC_LAUNCH((k_fused_block<LOGB>), dim3((channels + P::TPW - 1) / P::TPW), dim3(P::WG), lds, st, b);
   return hipGetLastError();
+}
+
+// audio path of block k with H_1 X_{k-1} folded in + (f.P > 0) the partial accumulator of block k+1
+template <int LOGB>
+static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int channels, hipStream_t st) {
+  typedef Plan8<LOGB> P;
+  size_t lds = sizeof(cx<float>) * P::LDS_ELEMS * P::TPW;
+  if (lds < sizeof(float2) * 4 * 64) lds = sizeof(float2) * 4 * 64;
+  FusedArgs b = a;
+  b.channels = channels;
+  const int n_audio = (channels + P::TPW - 1) / P::TPW;
+  const int fir_bx = (P::B + 63) / 64;
+  const int n_fir = f.P > 0 ? fir_bx * channels : 0;
+  constexpr int kThreads = P::WG > 256 ? P::WG : 256;
+  RVC_LAUNCH((k_fused_block2<LOGB>), dim3(n_audio + n_fir), dim3(kThreads), lds, st, b, f, n_audio, fir_bx);
+  return hipGetLastError();
+}
+
+bool fused_fold_supported(int logB) { return logB >= 6 && logB <= 12; }   // B = 8192: no registers left for the fold
+
+hipError_t launch_fused2(int logB, const FusedArgs &a, const FirArgs &f, int channels, hipStream_t st) {
+  switch (logB) {
+    case 6: return launch_fused2_t<6>(a, f, channels, st);
+    case 7: return launch_fused2_t<7>(a, f, channels, st);
+    case 8: return launch_fused2_t<8>(a, f, channels, st);
+    case 9: return launch_fused2_t<9>(a, f, channels, st);
+    case 10: return launch_fused2_t<10>(a, f, channels, st);
+    case 11: return launch_fused2_t<11>(a, f, channels, st);
+    case 12: return launch_fused2_t<12>(a, f, channels, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t st) {
