@@ -183,7 +183,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        conv.process_device(d_in, d_out, sync=False)
+        conv.process_device(d_in, d_out, sync=False, order=False)   # buffers resident and complete; synced below
         if do_gather:                      # one RCCL all_gather per batch of 3750 blocks
             conv.sync()
             shard.gather_batches(d_out, dist)
@@ -282,11 +282,11 @@ def main():
         fconv = reevr_amd.ConvolverSet(nch, device=local_rank, fixed_partitions=True)
         assert fconv.init(HOST_BLOCK, 8192, list(irs), max_len=frames)
         for _ in range(max(args.warmup, 2)):
-            fconv.process_device(d_in, d_out, sync=False)
+            fconv.process_device(d_in, d_out, sync=False, order=False)
         fconv.sync()
         tf = time.perf_counter()
         for _ in range(args.steps):
-            fconv.process_device(d_in, d_out, sync=False)
+            fconv.process_device(d_in, d_out, sync=False, order=False)
         fconv.sync()
         tf = time.perf_counter() - tf
         two_stage = {"value": round(nch * frames * args.steps / tf / 1e6, 3), "unit": "Msamples/s",

@@ -111,8 +111,9 @@ void rvc_set_process_end(rvc_set *s, float *const *out);
 
 /* Same, with DEVICE-resident buffers: channel c reads d_in + c*in_stride and writes
  * d_out + c*out_stride (strides in floats). Asynchronous on the set's stream
- * (rvc_set_stream); call rvc_set_sync or synchronise that stream before reading d_out
- * from another stream. */
+ * (rvc_set_stream, a non-blocking stream: it does not synchronise with the null stream): d_in must
+ * be complete, or its producer ordered before that stream (event / hipStreamWaitEvent), when this is
+ * called; call rvc_set_sync or synchronise that stream before reading d_out from another stream. */
 void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride,
                             float *d_out, size_t out_stride, size_t len);
 

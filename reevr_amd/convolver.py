@@ -116,20 +116,44 @@ class ConvolverSet:
         self._pending = None
         return out
 
-    def process_device(self, d_in, d_out=None, sync: bool = True):
+    def _order_after_torch(self):
+        """The engine runs on its own (non-blocking) HIP stream: make it wait for whatever torch's
+        current stream has queued (the kernels still producing d_in). Returns the wrapped stream."""
+        import torch
+        ptr = self._lib.rvc_set_stream(self._h, 0)
+        if not ptr:
+            return None
+        if getattr(self, "_ext_ptr", None) != ptr:
+            self._ext = torch.cuda.ExternalStream(ptr, device=torch.device("cuda", self.device))
+            self._ext_ptr = ptr
+        self._ext.wait_stream(torch.cuda.current_stream(self.device))
+        return self._ext
+
+    def _order_torch_after(self, ext):
+        import torch
+        if ext is not None:
+            torch.cuda.current_stream(self.device).wait_stream(ext)
+
+    def process_device(self, d_in, d_out=None, sync: bool = True, order: bool = True):
         """d_in / d_out: torch float32 CUDA tensors (n_channels, len), last dim contiguous.
-        Runs on the set's own HIP stream; with sync=True waits for completion."""
+        Runs on the set's own HIP stream, ordered after torch's current stream (d_in may still be
+        in production there); with sync=True waits for completion, else torch's current stream is
+        made to wait for the result. order=False skips both stream dependencies: for callers whose
+        buffers are already complete and who synchronise themselves (bench.py's timed loop)."""
         import torch
         assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
         assert d_in.shape[0] == self.n_channels
         if d_out is None:
             d_out = torch.empty_like(d_in)
         assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.shape == d_in.shape and d_out.stride(1) == 1
+        ext = self._order_after_torch() if order else None
         self._lib.rvc_set_process_device(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(),
                                          d_out.stride(0), d_in.shape[1])
         if sync:
             self.sync()
             self.check()
+        else:
+            self._order_torch_after(ext)
         return d_out
 
     def process_device_blocks(self, d_in, block: int, d_out=None, sync: bool = True):
@@ -139,11 +163,14 @@ class ConvolverSet:
         assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
         if d_out is None:
             d_out = torch.empty_like(d_in)
+        ext = self._order_after_torch()
         self._lib.rvc_set_process_device_blocks(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(),
                                                 d_out.stride(0), d_in.shape[1], block)
         if sync:
             self.sync()
             self.check()
+        else:
+            self._order_torch_after(ext)
         return d_out
 
     # -- state --------------------------------------------------------------------------

@@ -28,6 +28,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -100,6 +102,9 @@ struct rvc_set {
   size_t ring_cap = 0;
   float2 *ypre = nullptr;        // [2][nch][head block]: pre-multiplied accumulator of block ypre_block in half
   long long ypre_block = -1;     // (ypre_block & 1) (fused single-block path); -1 = not valid
+  unsigned *h_flags = nullptr;   // pinned, device-visible: completion flags of the audio workgroups (host-pointer calls)
+  unsigned flag_seq = 0;         // value the next flagged launch publishes
+  int flag_count = 0;            // flags the pending call waits for (0: wait for ev_out instead)
   bool fold = false;             // one launch per block: H_1 X_{k-1} folded into the fused kernel, ypre = sum_{i>=2}
   float *d_in = nullptr, *d_out = nullptr;     // staging for the host-pointer API [nch][max_len]
   float *h_in = nullptr, *h_out = nullptr;     // pinned
@@ -197,6 +202,8 @@ void free_device_state(rvc_set *s) {
   s->ypre_block = -1;
   if (s->h_in) hipHostFree(s->h_in);
   if (s->h_out) hipHostFree(s->h_out);
+  if (s->h_flags) hipHostFree(s->h_flags);
+  s->h_flags = nullptr;
   s->xring = s->tailring = s->d_in = s->d_out = s->h_in = s->h_out = nullptr;
   s->ring_cap = 0;
   s->live = false;
@@ -430,6 +437,9 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   RVC_CK(hipMalloc(&s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipHostMalloc(&s->h_in, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
   RVC_CK(hipHostMalloc(&s->h_out, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
+  RVC_CK(hipHostMalloc(&s->h_flags, sizeof(unsigned) * (size_t)s->nch, hipHostMallocDefault));
+  std::memset(s->h_flags, 0, sizeof(unsigned) * (size_t)s->nch);
+  s->flag_seq = 0; s->flag_count = 0;
   RVC_CK(hipDeviceSynchronize());
   s->n = 0;
   s->tail_fft_done = 0;
@@ -710,6 +720,15 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     g.add_chan_stride = (long long)s->ring_cap; g.add_mask = s->ring_cap - 1;
     g.add_from = has_tail ? 2 * (long long)T.B : 0;
     const bool block_done = n1 % hb == 0;
+    // host-pointer call through the pinned buffers: the audio workgroups publish completion flags and
+    // process_end polls them -- no event behind the kernel, no wait for the kernel's tail
+    const bool flagged = s->out_copy_len != 0 && s->zero_copy && !s->timing;
+    if (flagged) {
+      g.done_flag = s->h_flags;
+      g.seq = ++s->flag_seq;
+      s->flag_count = rvc::fused_audio_workgroups(A.logB, s->nch);
+      s->out_copy_len = 0;             // nothing to copy back, no event to record
+    }
     if (s->fold) {
       // the workgroups appended to this launch prepare block k0+1's accumulator (other half of ypre)
       rvc::FirArgs f = premultiply_args(s, k0 + 1);
@@ -1008,6 +1027,7 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   if (!s) return;
   s->pending_len = len;
   s->pending_ok = false;
+  s->flag_count = 0;
   if (len == 0 || !s->live || s->err != RVC_OK || !in) return;
   if (len > s->max_len) { fail(s, RVC_ERR_BAD_ARG, hipSuccess, "process_begin: len > max_len"); return; }
   if (!use_device(s)) return;
@@ -1035,7 +1055,27 @@ void rvc_set_process_end(rvc_set *s, float *const *out) {
   s->pending_len = 0;
   if (len == 0) return;
   bool ok = s->pending_ok;
-  if (ok) {
+  if (ok && s->flag_count > 0) {
+    // poll the completion flags the audio workgroups write behind their output stores
+    const unsigned want = s->flag_seq;
+    const int nf = s->flag_count;
+    s->flag_count = 0;
+    volatile unsigned *f = s->h_flags;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < nf; ++i) {
+      unsigned spins = 0;
+      while (f[i] != want) {
+        if ((++spins & 0x3ffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+          hipSetDevice(s->device);               // lost kernel? fall back to the stream and report what it says
+          ok = hipStreamSynchronize(s->st_main) == hipSuccess && f[i] == want;
+          if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_end (completion flag)");
+          break;
+        }
+      }
+      if (!ok) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else if (ok) {
     hipSetDevice(s->device);
     ok = hipEventSynchronize(s->ev_out) == hipSuccess;   // output copied back; later stream work may still run
     if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_end");

@@ -107,6 +107,11 @@ struct FusedArgs {
   unsigned long long add_mask;
   long long add_from;
   int channels;             // set by the launcher
+  // Host-pointer calls: when set, every audio workgroup publishes `seq` to done_flag[workgroup]
+  // (pinned host memory, system scope) right behind its output stores, and the host polls that
+  // instead of waiting for an event behind the whole kernel.
+  unsigned *done_flag;
+  unsigned seq;
 };
 
 struct IngestArgs {
@@ -132,6 +137,7 @@ hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t 
 // One launch per block: the audio path with H_1 X_{k-1} folded in (a.Ypre = sum_{i>=2}) plus, when
 // f.P > 0, the workgroups that compute the next block's sum_{i>=2} (f: M = 1 row, any delay).
 bool fused_fold_supported(int logB);
+int fused_audio_workgroups(int logB, int channels);
 hipError_t launch_fused2(int logB, const FusedArgs &a, const FirArgs &f, int channels, hipStream_t st);
 hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st);
 // arm (a, b) / disarm (nullptr, nullptr) kernel-exact timing events for the next launch on this thread

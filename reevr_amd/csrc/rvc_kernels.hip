@@ -961,6 +961,11 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       if (n + 1 >= a.n0 && n + 1 < a.n1) out[n + 1 - a.n0] = t1;
     }
   }
+  if (a.done_flag) {   // output is in (host-visible) memory: tell the polling host, do not make it wait for kernel end
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(a.done_flag + wg, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 template <int LOGB>
@@ -1430,6 +1435,15 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
   constexpr int kThreads = P::WG > 256 ? P::WG : 256;
   RVC_LAUNCH((k_fused_block2<LOGB>), dim3(n_audio + n_fir), dim3(kThreads), lds, st, b, f, n_audio, fir_bx);
   return hipGetLastError();
+}
+
+int fused_audio_workgroups(int logB, int channels) {   // workgroups of the audio part = entries of done_flag
+  switch (logB) {
+    case 6: return (channels + Plan8<6>::TPW - 1) / Plan8<6>::TPW;
+    case 7: return (channels + Plan8<7>::TPW - 1) / Plan8<7>::TPW;
+    case 8: return (channels + Plan8<8>::TPW - 1) / Plan8<8>::TPW;
+    default: return channels;
+  }
 }
 
 bool fused_fold_supported(int logB) { return logB >= 6 && logB <= 12; }   // B = 8192: no registers left for the fold

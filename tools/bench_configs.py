@@ -36,7 +36,7 @@ def main():
         for _ in range(2): s.process_device(x, y)
         t0 = time.perf_counter()
         reps = 5
-        for _ in range(reps): s.process_device(x, y, sync=False)
+        for _ in range(reps): s.process_device(x, y, sync=False, order=False)
         s.sync(); dt = (time.perf_counter() - t0) / reps
         batched = nch * frames / dt / 1e6
         # block-synchronous

@@ -12,7 +12,7 @@ s = reevr_amd.ConvolverSet(nch)
 assert s.init(512, 8192, list(irs), max_len=frames)
 for _ in range(2): s.process_device(x, y)
 t0 = time.perf_counter()
-for _ in range(5): s.process_device(x, y, sync=False)
+for _ in range(5): s.process_device(x, y, sync=False, order=False)
 s.sync(); dt = (time.perf_counter() - t0) / 5
 s.set_timing(True); s.kernel_time_reset()
 for _ in range(5): s.process_device(x, y)

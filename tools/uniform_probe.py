@@ -13,7 +13,7 @@ for B in (4096, 8192, 16384):
     assert s.init_uniform(B, list(irs), max_len=frames), s.last_error_string
     for _ in range(3): s.process_device(x, y)
     t0 = time.perf_counter()
-    for _ in range(20): s.process_device(x, y, sync=False)
+    for _ in range(20): s.process_device(x, y, sync=False, order=False)
     s.sync(); dt = (time.perf_counter() - t0) / 20
     s.set_timing(True); s.kernel_time_reset()
     for _ in range(5): s.process_device(x, y)
