@@ -10,7 +10,7 @@ LIB   := $(CSRC)/libreevr_amd.so
 all: $(LIB) oracle
 
 $(LIB): $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_impulse.hip $(CSRC)/rvc_engine.cpp $(CSRC)/rvc_internal.h $(CSRC)/rvc_fft_lds.hpp include/reevr_amd/rvc.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip -ffp-contract=fast \
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip -ffp-contract=fast-honor-pragmas \
 	  -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -o $@ $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_impulse.hip $(CSRC)/rvc_engine.cpp
 
 oracle:

@@ -231,6 +231,28 @@ const char *rvc_impulse_last_error_string(const rvc_impulse *m);
 int rvc_set_init_impulse(rvc_set *s, size_t head_block, size_t tail_block, rvc_impulse *m,
                          const int *channels, size_t max_len);
 
+/* ---- wet bus on the device ------------------------------ */
+
+/* What processBlock does with the convolvers' output buffers (src/PluginProcessor.cpp:1800-1876),
+ * for pipelines whose blocks stay on the device (rvc_set_process_device): crossfade of the
+ * fading-in convolver with the reference's per-sample alpha (:1808-1821; xfade = the counter's
+ * value at sample 0), true-stereo sum LL + RL / RR + LR (:1833-1838), reverb envelope and mid/side
+ * width (:1840-1857), dry/wet mix (:1860-1876), one pass, same float operations in the same order.
+ * All pointers are DEVICE pointers to n floats. Asynchronous on `stream` (a hipStream_t, e.g.
+ * rvc_set_stream(set, 0); NULL = the null stream). 1 = enqueued. */
+typedef struct rvc_wet_params {
+  const float *cur[4];     /* current convolver: LL, RR, LR, RL; LR = RL = NULL when not quad / true stereo off */
+  const float *load[2];    /* fading-in convolver: LL, RR; both NULL when no crossfade is running */
+  long long xfade;         /* crossfade countdown at sample 0 (REEVRAudioProcessor::xfade) */
+  long long xfadelen;      /* its start value, ceil(srate * CONV_XFADE / 1000), src/Globals.h:7 */
+  const float *yrev;       /* reverb envelope per sample, NULL = 1 */
+  float width, drygain, wetgain;
+  const float *dry[2];     /* dry signal L, R; both NULL = wet only */
+  float *out[2];
+  size_t n;
+} rvc_wet_params;
+int rvc_wet_mix_device(int device, void *stream, const rvc_wet_params *p);
+
 /* ---- library ----------------------------------------------------------------------- */
 
 /* Number of visible HIP devices (0 when there is none or the runtime cannot start). */

@@ -72,6 +72,7 @@ SIGNATURES = {
     "rvc_impulse_last_error": (C.c_int, [C.c_void_p]),
     "rvc_impulse_last_error_string": (C.c_char_p, [C.c_void_p]),
     "rvc_set_init_impulse": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(C.c_int), C.c_size_t]),
+    "rvc_wet_mix_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "rvc_device_count": (C.c_int, []),
     "rvc_version": (C.c_char_p, []),
 }
@@ -84,6 +85,12 @@ class ImpulseParams(C.Structure):       # struct rvc_impulse_params
     _fields_ = [("reverse", C.c_int), ("trim_left", C.c_float), ("trim_right", C.c_float), ("gain", C.c_float),
                 ("attack", C.c_float), ("decay", C.c_float), ("srate", C.c_double),
                 ("decay_lut", C.POINTER(C.c_double))]
+
+
+class WetParams(C.Structure):           # struct rvc_wet_params
+    _fields_ = [("cur", C.c_void_p * 4), ("load", C.c_void_p * 2), ("xfade", C.c_longlong), ("xfadelen", C.c_longlong),
+                ("yrev", C.c_void_p), ("width", C.c_float), ("drygain", C.c_float), ("wetgain", C.c_float),
+                ("dry", C.c_void_p * 2), ("out", C.c_void_p * 2), ("n", C.c_size_t)]
 
 
 _lib = None

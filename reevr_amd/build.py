@@ -38,7 +38,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-x", "hip", "-ffp-contract=fast", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+           "-x", "hip", "-ffp-contract=fast-honor-pragmas", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
            "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

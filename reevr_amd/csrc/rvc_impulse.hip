@@ -561,3 +561,79 @@ int rvc_impulse_last_error(const rvc_impulse *m) { return m ? m->err : RVC_ERR_B
 const char *rvc_impulse_last_error_string(const rvc_impulse *m) { return m ? m->errstr.c_str() : "null handle"; }
 
 }  // extern "C"
+
+// ================================================================================================
+// Wet-bus epilogue on the device: what processBlock does with the
+// convolvers' output buffers, src/PluginProcessor.cpp:1800-1876, in one pass over device-resident
+// blocks: crossfade of the fading-in convolver (per-sample alpha, :1808-1821), true-stereo sum
+// LL + RL / RR + LR (:1828-1838), reverb envelope and mid/side width (:1840-1857), dry/wet mix
+// (:1860-1876). Same float operations in the same order as the reference loop.
+// ================================================================================================
+namespace rvc {
+
+struct WetArgs {
+  const float *cur[4];    // LL, RR, LR, RL of the current convolver (LR / RL nullptr: not quad or true stereo off)
+  const float *load[2];   // LL, RR of the fading-in convolver (nullptr: not fading)
+  long long xfade, xfadelen;
+  const float *yrev;      // reverb envelope per sample, nullptr = 1
+  float width, drygain, wetgain;
+  const float *dry[2];    // nullptr: wet only
+  float *out[2];
+  size_t n;
+};
+
+__global__ void __launch_bounds__(256) k_wet_mix(const WetArgs a) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  float ll = a.cur[0][i], rr = a.cur[1][i];
+  float lr = a.cur[2] ? a.cur[2][i] : 0.f, rl = a.cur[3] ? a.cur[3][i] : 0.f;
+  float wl = 0.f, wr = 0.f;                                  // wetBuffer starts cleared
+  // (this file is compiled with fp contraction off -- #pragma at the top, -ffp-contract=fast-honor-pragmas --
+  //  so every product and sum rounds on its own like the reference's scalar loop)
+  if (a.load[0]) {
+    // alpha = clamp(1 - xfade / xfadelen, 0, 1) with xfade counting down one per sample (:1809, :1820)
+    float alpha = 1.f - (float)(a.xfade - (long long)i) / (float)a.xfadelen;
+    alpha = alpha < 0.f ? 0.f : (alpha > 1.f ? 1.f : alpha);
+    const float keep = 1.f - alpha;
+    ll *= keep; rr *= keep; lr *= keep; rl *= keep;
+    const float fl = a.load[0][i] * alpha, fr = a.load[1][i] * alpha;   // :1812-1813
+    wl += fl;                                                // :1829-1830
+    wr += fr;
+  }
+  wl += ll; wr += rr;                                        // :1834-1835
+  if (a.cur[2]) { wl += rl; wr += lr; }                      // :1836-1838 (L gets RL, R gets LR)
+  const float env = a.yrev ? a.yrev[i] : 1.f;
+  const float lin = wl * env, rin = wr * env;                // :1844-1845
+  const float mid = (lin + rin) * 0.5f, side = (lin - rin) * 0.5f;
+  const float normalization = 1.0f / (1.0f + a.width);
+  const float sw = side * a.width;
+  float lout = (mid + sw) * normalization;
+  float rout = (mid - sw) * normalization;
+  if (a.dry[0]) {                                            // :1860-1876
+    const float dl = a.dry[0][i] * a.drygain, dr = a.dry[1][i] * a.drygain;
+    const float gl = lout * a.wetgain, gr = rout * a.wetgain;
+    lout = dl + gl;
+    rout = dr + gr;
+  }
+  a.out[0][i] = lout;
+  a.out[1][i] = rout;
+}
+
+}  // namespace rvc
+
+extern "C" int rvc_wet_mix_device(int device, void *stream, const rvc_wet_params *p) {
+  if (!p || !p->cur[0] || !p->cur[1] || !p->out[0] || !p->out[1]) return 0;
+  if ((p->cur[2] == nullptr) != (p->cur[3] == nullptr)) return 0;
+  if ((p->load[0] == nullptr) != (p->load[1] == nullptr)) return 0;
+  if ((p->dry[0] == nullptr) != (p->dry[1] == nullptr)) return 0;
+  if (p->load[0] && p->xfadelen <= 0) return 0;
+  if (p->n == 0) return 1;
+  if (hipSetDevice(device < 0 ? 0 : device) != hipSuccess) return 0;
+  rvc::WetArgs a{};
+  for (int c = 0; c < 4; ++c) a.cur[c] = p->cur[c];
+  for (int c = 0; c < 2; ++c) { a.load[c] = p->load[c]; a.dry[c] = p->dry[c]; a.out[c] = p->out[c]; }
+  a.xfade = p->xfade; a.xfadelen = p->xfadelen; a.yrev = p->yrev;
+  a.width = p->width; a.drygain = p->drygain; a.wetgain = p->wetgain; a.n = p->n;
+  hipLaunchKernelGGL(rvc::k_wet_mix, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 1 : 0;
+}

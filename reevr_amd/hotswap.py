@@ -137,8 +137,37 @@ def wet_bus(wet, yrev, width: float, drygain: float, wetgain: float, dry):
     rin = wet[1] * yrev
     mid = (lin + rin) * np.float32(0.5)
     side = (lin - rin) * np.float32(0.5)
-    norm = np.float32(1.0 / (1.0 + width))
+    norm = np.float32(1.0) / (np.float32(1.0) + np.float32(width))    # float arithmetic, :1842
     lout = (mid + side * np.float32(width)) * norm
     rout = (mid - side * np.float32(width)) * norm
     return np.stack([dry[0] * np.float32(drygain) + lout * np.float32(wetgain),
                      dry[1] * np.float32(drygain) + rout * np.float32(wetgain)]).astype(np.float32)
+
+
+def wet_mix_device(cur, load=None, xfade: int = 0, xfadelen: int = 1, yrev=None, width: float = 1.0,
+                   drygain: float = 1.0, wetgain: float = 1.0, dry=None, out=None, stream: int = 0, device: int = 0):
+    """The same epilogue on the DEVICE for blocks that never leave it (rvc_wet_mix_device; kernel
+    k_wet_mix): crossfade (per-sample alpha) + true-stereo sum + envelope + width + dry/wet in one pass.
+    cur: 2 (LL, RR) or 4 (LL, RR, LR, RL) torch CUDA float32 vectors of the current convolver;
+    load: (LL, RR) of the fading-in convolver while a crossfade runs (xfade = countdown at sample 0);
+    dry: (L, R) or None for wet only. Returns the two output tensors. Asynchronous on `stream`
+    (a raw hipStream_t, 0 = null stream)."""
+    import torch
+    from . import _lib as L
+    n = cur[0].numel()
+    out = out or (torch.empty_like(cur[0]), torch.empty_like(cur[0]))
+    p = L.WetParams()
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    for i in range(4):
+        p.cur[i] = ptr(cur[i]) if i < len(cur) else None
+    for i in range(2):
+        p.load[i] = ptr(load[i]) if load is not None else None
+        p.dry[i] = ptr(dry[i]) if dry is not None else None
+        p.out[i] = ptr(out[i])
+    p.xfade, p.xfadelen = int(xfade), int(xfadelen)
+    p.yrev = ptr(yrev)
+    p.width, p.drygain, p.wetgain, p.n = width, drygain, wetgain, n
+    import ctypes as C
+    if not L.lib().rvc_wet_mix_device(device, stream, C.byref(p)):
+        raise RuntimeError("rvc_wet_mix_device failed")
+    return out

@@ -92,7 +92,7 @@ def test_wet_bus_matches_scalar_loop():
     yrev = rng.rand(64).astype(np.float32)
     width, dg, wg = 0.7, 0.5, 0.8
     out = wet_bus(wet, yrev, width, dg, wg, dry)
-    norm = np.float32(1.0 / (1.0 + width))
+    norm = np.float32(1.0) / (np.float32(1.0) + np.float32(width))
     for i in range(64):
         lin = wet[0, i] * yrev[i]; rin = wet[1, i] * yrev[i]
         mid = (lin + rin) * np.float32(0.5); side = (lin - rin) * np.float32(0.5)
