@@ -1,5 +1,5 @@
 """IR hot-swap cost, device path vs CPU restatement: recalcImpulse (all stages incl. decay EQ) and
-loadImpulse for the BASELINE impulse lengths. Run on the GPU box:  python tools/impulse_times.py"""
+loadImpulse for the BASELINE impulse lengths. Run on the GPU box:  python tests/measure_impulse_times.py"""
 import os
 import sys
 import time
