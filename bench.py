@@ -134,8 +134,8 @@ def cpu_baseline(irs: np.ndarray, x: np.ndarray, budget_s: float) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=40 * SR, help="frames per channel per step (one process() call)")
     ap.add_argument("--bg-stream", type=int, default=0, help="1: tail stage on the second HIP stream (overlaps the head stage)")
     ap.add_argument("--fixed-partitions", type=int, default=0,

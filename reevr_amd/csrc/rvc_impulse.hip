@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_imp_reduce(const ImpPtrs p, const int n
   const size_t base = (size_t)blockIdx.x * IMP_RED;
   double e = 0.0;
   float mx = 0.f;
-  for (int j = threadIdx.x; j < IMP_RED; j += 256) {
+  for (int j = (int)threadIdx.x; j < IMP_RED; j += 256) {
     const size_t i = base + j;
     if (i < n) {
       const double vl = (double)p.src[0][i], vr = (double)p.src[1][i];
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) k_imp_reduce(const ImpPtrs p, const int n
   sm[threadIdx.x] = mx;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
-    if (threadIdx.x < w) {
+    if ((int)threadIdx.x < w) {
       se[threadIdx.x] += se[threadIdx.x + w];
       sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + w]);
     }

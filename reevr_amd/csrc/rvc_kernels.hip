@@ -584,7 +584,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   // partner Z[B-k] (one LDS read) a thread produces BOTH X[k] = E + w^k O and X[B-k] = conj(E - w^k O):
   // one split twiddle, one partner read and one E/O evaluation per two output bins.
   C ws[P::E / 2];
-  constexpr bool kEager = Tw8<LOGB, R>::EAGER;   // twiddles requested before the transform when registers allow
   auto load_ws = [&]() {
     int q = 0;
 #pragma unroll
