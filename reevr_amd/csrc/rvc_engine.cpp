@@ -334,7 +334,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     longest = std::max(longest, l);
   }
   const size_t hb = next_pow2(head_block);
-  const size_t tb = two_stage ? next_pow2(tail_block) : 0;
+  size_t tb = two_stage ? next_pow2(tail_block) : 0;
   const bool want64 = (s->flags & RVC_FLAG_FFT_F64) != 0;
   const size_t max_block = want64 ? RVC_MAX_BLOCK / 2 : RVC_MAX_BLOCK;
   if (hb > max_block || tb > max_block) {
@@ -361,23 +361,32 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     pa = std::max(pa, (la + hb - 1) / hb);
     if (len[c] > split) pt = std::max(pt, (len[c] - split + tb - 1) / tb);
   }
+  // Long-call stage of a single-stage (FFTConvolver) set: the whole IR once more at block 8192, used
+  // only by calls that touch several such blocks (the adaptive path of step_device). It has no
+  // streaming role -- P stays 0: no tail jobs, no tail ring -- its delay line is rebuilt from the
+  // time ring whenever a long call needs it.
+  const bool no_resize = (s->flags & (RVC_FLAG_FIXED_PARTITIONS | RVC_FLAG_BG_STREAM)) != 0;
+  const size_t lb = 8192;
+  const bool uni_long = !two_stage && !no_resize && hb < lb && longest > 2 * lb && eff_max_len >= 4 * lb;
+  if (uni_long) tb = lb;                         // (tb is 0 for single-stage sets otherwise)
+  const size_t pf = (pt > 0 || uni_long) ? (longest + tb - 1) / tb : 0;   // rows of the whole-IR table at block tb
   // wide stage: only for float transforms (136 KiB of LDS), a tail block below 16384 and an IR of
   // several wide blocks; and only if calls can be long enough to use it
   const size_t wb = (size_t)RVC_MAX_BLOCK;
-  const bool wide = pt > 0 && !want64 && tb < wb && longest > 4 * wb && eff_max_len >= 4 * wb &&
-                    (s->flags & (RVC_FLAG_FIXED_PARTITIONS | RVC_FLAG_BG_STREAM)) == 0;
+  const bool wide = pf > 0 && !want64 && tb < wb && longest > 4 * wb && eff_max_len >= 4 * wb && !no_resize;
   const size_t pw = wide ? (longest + wb - 1) / wb : 0;
 
   // ---- IR swap with unchanged geometry: keep all device state, refresh the spectra ----
-  if (s->live && s->two_stage == two_stage && s->head == hb && s->tail == tb && s->max_len == eff_max_len &&
-      s->A.P == (int)pa && s->T.P == (int)pt && s->W.P == (int)pw) {
+  const size_t tail_pub = two_stage ? tb : 0;    // what rvc_set_tail_block reports: 0 for single-stage sets
+  if (s->live && s->two_stage == two_stage && s->head == hb && s->tail == tail_pub && s->max_len == eff_max_len &&
+      s->A.P == (int)pa && s->T.P == (int)pt && s->T.PF == (int)pf && s->W.P == (int)pw) {
     if (!use_device(s)) return false;
     hipStreamSynchronize(s->st_bg);
     hipStreamSynchronize(s->st_main);
     for (auto &j : s->jobs) s->ev_pool.push_back(j.ev);
     s->jobs.clear();
     if (!upload_ir_stage(s, s->A, irs, lenA, on_device)) { free_device_state(s); return false; }
-    if (pt > 0 && !upload_ir_stage(s, s->T, irs, len, on_device)) { free_device_state(s); return false; }
+    if (pf > 0 && !upload_ir_stage(s, s->T, irs, len, on_device)) { free_device_state(s); return false; }
     if (pw > 0 && !upload_ir_stage(s, s->W, irs, len, on_device)) { free_device_state(s); return false; }
     s->n = 0; s->tail_fft_done = 0; s->tail_out_done = 2; s->xa_next = 0; s->ypre_block = -1;
     s->w_next = 0; s->xt_valid_lo = 0;
@@ -389,7 +398,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   if (!use_device(s)) return false;
 
   s->head = hb;
-  s->tail = tb;
+  s->tail = tail_pub;
   s->two_stage = two_stage;
   s->max_len = eff_max_len;
   Stage &A = s->A, &T = s->T;
@@ -400,10 +409,10 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   if (!upload_ir_stage(s, A, irs, lenA, on_device)) return false;
   RVC_CK(hipMalloc(&A.X, sizeof(float2) * (size_t)s->nch * A.rows * A.B));
   RVC_CK(hipMalloc(&A.Y, sizeof(float2) * (size_t)s->nch * A.mcap * A.B));
-  if (pt > 0) {
-    T.B = tb; T.logB = ilog2(tb); T.P = (int)pt; T.PF = (int)pt + 2; T.delay = 2; T.f64 = want64;
+  if (pf > 0) {
+    T.B = tb; T.logB = ilog2(tb); T.P = (int)pt; T.PF = (int)pf; T.delay = 2; T.f64 = want64;
     T.mcap = s->max_len / tb + 3;
-    T.rows = next_pow2(pt + 2 + T.mcap + 2);
+    T.rows = next_pow2(pf + T.mcap + 2);
     if (!make_twiddles(s, T)) return false;
     if (!upload_ir_stage(s, T, irs, len, on_device)) return false;
     RVC_CK(hipMalloc(&T.X, sizeof(float2) * (size_t)s->nch * T.rows * T.B));
@@ -424,8 +433,8 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   // line of history (their rows are rebuilt from the ring when the call pattern changes)
   const size_t span = std::max(hb, tb);
   s->keep = 2 * (long long)span + ((long long)pa + 2) * (long long)hb;
-  if (pw > 0) s->keep = std::max<long long>(s->keep, std::max<long long>((long long)(pw + 2) * (long long)wb,
-                                                                        (long long)(pt + 4) * (long long)tb));
+  if (pw > 0) s->keep = std::max<long long>(s->keep, (long long)(pw + 2) * (long long)wb);
+  if (pf > 0 && (pw > 0 || uni_long)) s->keep = std::max<long long>(s->keep, (long long)(pf + 4) * (long long)tb);
   s->ring_cap = next_pow2(s->max_len + (size_t)s->keep + 6 * std::max(span, pw > 0 ? wb : (size_t)0) + 4 * hb);
   RVC_CK(hipMalloc(&s->xring, sizeof(float) * (size_t)s->nch * s->ring_cap));
   if (pt > 0) RVC_CK(hipMalloc(&s->tailring, sizeof(float) * (size_t)s->nch * s->ring_cap));
@@ -685,6 +694,17 @@ bool emit_output_copy(rvc_set *s) {
   return true;
 }
 
+// Single-stage sets with a long-call stage: no tail job keeps that stage's delay line current, so a
+// call that did not go through it leaves a hole -- everything up to the end of the call is marked
+// missing and the next long call rebuilds the rows it needs from the time ring (ensure_tail_spectra).
+void mark_long_stage_stale(rvc_set *s, long long n1) {
+  Stage &T = s->T;
+  if (T.PF > 0 && T.P == 0) {
+    s->tail_fft_done = n1 / (long long)T.B;
+    s->xt_valid_lo = s->tail_fft_done;
+  }
+}
+
 // one process() step of at most max_len samples, device buffers, asynchronous
 bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len) {
   Stage &A = s->A, &T = s->T;
@@ -751,6 +771,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     // pre-multiplied accumulator of the next block if this one is complete
     if (has_tail && !run_tail_job(s, n0, n1, nullptr, in_stride, bg)) return false;
     if (!s->fold && block_done && !run_premultiply(s, k0 + 1)) return false;
+    mark_long_stage_stale(s, n1);
     s->n = n1;
     return true;
   }
@@ -764,10 +785,11 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   const long long keep = s->keep;
   const bool fuse_in = !bg && (long long)len > keep;
   // (the adaptive long-call path below lets its forward transform append the history: no ingest launch)
-  const long long tbq = has_tail ? (long long)T.B : 1;
+  const bool has_long = T.PF > 0;                 // a whole-IR table at block T exists (two-stage sets; long-call stage of single-stage sets)
+  const long long tbq = has_long ? (long long)T.B : 1;
   const long long wbq = s->W.P > 0 ? (long long)s->W.B : 1;
   const bool wide = s->W.P > 0 && !bg && ((n1 - 1) / wbq - n0 / wbq) >= 3;
-  const bool adaptive = !wide && has_tail && !bg && (s->flags & RVC_FLAG_FIXED_PARTITIONS) == 0 &&
+  const bool adaptive = !wide && has_long && !bg && (s->flags & RVC_FLAG_FIXED_PARTITIONS) == 0 &&
                         ((n1 - 1) / tbq - n0 / tbq) >= 3;
   const bool fft_ingests = (wide && fuse_in) ||
                            (adaptive && fuse_in && rvc::fwd_appends_ring(T.logB) && (n0 / tbq) >= s->tail_fft_done);
@@ -910,6 +932,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   // 3. two-stage path: tail job one period ahead, then the zero-latency stage over the whole call
   if (has_tail && !run_tail_job(s, n0, n1, src2, in_stride, bg)) return false;
   if (!head_stage(s, n0, n0, n1, src2, in_stride, d_out, out_stride, bg, head_ingests ? n1 - keep : -1)) return false;
+  mark_long_stage_stale(s, n1);
   s->n = n1;
   return true;
 }

@@ -345,6 +345,48 @@ def test_mixed_long_and_short_calls_hand_state_over(fixed, ir_len):
             assert np.sqrt(np.mean((got[c, seg].astype(np.float64) - want[seg]) ** 2)) <= 5e-6
 
 
+@pytest.mark.parametrize("ir_len,block", [(48000, 512), (150000, 256), (20000, 64)])
+def test_single_stage_set_long_and_short_calls(ir_len, block):
+    """The same for a single-stage (FFTConvolver) set: calls touching several 8192-sample blocks go
+    through the long-call stage (whole IR at block 8192; the wide stage too for the 150000-sample IR),
+    whose delay line nobody keeps current between long calls -- it is rebuilt from the time ring.
+    (ir_len 20000 x block 64: IR too short for a long-call stage -- the plain path must be unchanged.)"""
+    ir = synth.synth_ir(ir_len, 2, 51)
+    sched = [block] * 3 + [70000] + [block] * 40 + [37, block - 37, block, 300] + [8192 * 5] + [100] + [block] * 20 + \
+            [8192 * 4 + 5] + [8187] + [block] * 33 + [90001] + [block - 1, 1] + [block] * 17 + [8192 * 6] + [66000] + [block] * 5
+    total = sum(sched)
+    x = np.stack([synth.synth_input(total, c) for c in range(2)])
+    s = reevr_amd.ConvolverSet(2)
+    assert s.init_uniform(block, list(ir), max_len=max(sched))
+    assert s.tail_block == 0 and s.partitions(1) == 0          # still reports a single-stage geometry
+    got = []
+    pos = 0
+    for n in sched:
+        got.append(s.process(x[:, pos:pos + n]))
+        pos += n
+    got = np.concatenate(got, axis=1)
+    assert s.last_error == 0, s.last_error_string
+    want = []
+    for c in range(2):
+        o = O.FFTConvolver("orc"); assert o.init(block, ir[c])
+        want.append(o.process(x[c]))
+        assert rel_rms(got[c], want[c]) <= TOL
+        for a in range(0, total - 4096, 4096):
+            seg = slice(a, a + 4096)
+            assert np.sqrt(np.mean((got[c, seg].astype(np.float64) - want[c][seg]) ** 2)) <= 5e-6
+    # clear() and a different interleaving on the same set: long call first, then blocks, then long again
+    s.clear()
+    sched2 = [8192 * 7 + 3] + [block] * 9 + [50000] + [block] * 4
+    got2 = []
+    pos = 0
+    for n in sched2:
+        got2.append(s.process(x[:, pos:pos + n]))
+        pos += n
+    got2 = np.concatenate(got2, axis=1)
+    for c in range(2):
+        assert rel_rms(got2[c], want[c][:pos]) <= TOL
+
+
 def test_device_entry_zeros_before_init_and_with_empty_ir():
     """process before init / with an all-zero IR writes zeros (FFTConvolver.cpp:157-161) -- also
     through the device-pointer entry, which has no stream yet at that point."""
