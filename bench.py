@@ -195,14 +195,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # untimed pre-roll: ~50 ms of the same step so that the GPU's clocks have settled whatever K / W are
+    # (a step is 60 us: with K = 50 the whole timed region would otherwise end before they have)
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.05:
+        for _ in range(20):
+            step()
+        conv.sync()
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    # closing bracket: synchronise this rank, stamp, barrier; the reported time is the MAX over ranks of
+    # the stamped spans (all ranks left the opening barrier together), so the collective's own latency
+    # (~0.2 ms for an RCCL barrier, 3 steps' worth) is not charged to the K steps
+    conv.sync()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    fence()
     conv.check()
     elapsed = shard.max_over_ranks(elapsed, dist, dev)    # slowest rank
     total_samples = world * nch * frames * args.steps
