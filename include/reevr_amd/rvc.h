@@ -36,12 +36,14 @@ enum {
   RVC_ERR_NO_DEVICE = 1,   /* no HIP device / hipSetDevice failed */
   RVC_ERR_HIP = 2,         /* a HIP call failed; rvc_last_error_string has the detail */
   RVC_ERR_BAD_ARG = 3,     /* zero block size, len > max_len, NULL pointer ... */
-  RVC_ERR_UNSUPPORTED = 4, /* block size above RVC_MAX_BLOCK */
+  RVC_ERR_UNSUPPORTED = 4, /* reserved (block sizes above RVC_MAX_BLOCK are clamped, not refused) */
   RVC_ERR_NOT_INIT = 5
 };
 
-/* Largest partition (block) size after rounding up to a power of two. The 2*block-point
- * real FFT of one partition lives in one CU's LDS (block * 8 bytes <= 128 KiB). */
+/* Largest partition (block) size used internally. The 2*block-point real FFT of one partition lives
+ * in one CU's LDS (block * 8 bytes <= 128 KiB). Larger requests are accepted and served with this
+ * size: partition sizes set the algorithm's latency, not its output, and here the latency is that of
+ * the call. rvc_set_head_block / rvc_set_tail_block report the sizes in use. */
 #define RVC_MAX_BLOCK 16384
 
 /* flags for rvc_set_create */
@@ -52,7 +54,7 @@ enum {
 #define RVC_FLAG_FFT_F64 4u     /* run the FFTs in double, spectra still stored as float -- the reference's
                                    precision (Ooura in double, AudioFFT.cpp:114-159). Default is float32
                                    transforms (~1e-7 relative, 100x inside the 1e-5 RMS parity bound and
-                                   faster). Limits the block size to RVC_MAX_BLOCK/2. IR spectra are computed
+                                   faster). Largest partition RVC_MAX_BLOCK/2. IR spectra are computed
                                    in double at init in either mode. */
 
 #define RVC_FLAG_FIXED_PARTITIONS 8u /* always use the reference's head/tail partition sizes. Default: a long

@@ -254,6 +254,14 @@ class _Mono:
     def last_error(self) -> int:
         return self._set.last_error
 
+    @property
+    def head_block(self) -> int:      # partition sizes in use (after rounding / clamping to RVC_MAX_BLOCK)
+        return self._set.head_block
+
+    @property
+    def tail_block(self) -> int:
+        return self._set.tail_block
+
 
 class FFTConvolver(_Mono):
     """fftconvolver::FFTConvolver (FFTConvolver.h:52-80)."""

@@ -333,23 +333,23 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     len[c] = l;
     longest = std::max(longest, l);
   }
-  const size_t hb = next_pow2(head_block);
-  size_t tb = two_stage ? next_pow2(tail_block) : 0;
+  // Requested partition sizes, rounded up to powers of two like the reference (:117-118). The sizes
+  // only set the latency of the partitioned algorithm, never its output, and this engine's latency
+  // is set by the call, not by the partition: requests above what one CU's LDS can transform are
+  // served with the largest supported partition instead (rvc_set_head_block / _tail_block report
+  // what is used). A host running 16384- or 32768-frame blocks gets the same samples.
+  const size_t hb_req = next_pow2(head_block);
   const bool want64 = (s->flags & RVC_FLAG_FFT_F64) != 0;
   const size_t max_block = want64 ? RVC_MAX_BLOCK / 2 : RVC_MAX_BLOCK;
-  if (hb > max_block || tb > max_block) {
-    drop();
-    s->err = RVC_ERR_UNSUPPORTED;
-    s->errstr = want64 ? "block size above RVC_MAX_BLOCK/2 (f64 FFT mode)" : "block size above RVC_MAX_BLOCK";
-    return false;
-  }
+  const size_t hb = std::min(hb_req, max_block);
+  size_t tb = two_stage ? std::min(next_pow2(tail_block), max_block) : 0;
   if (longest == 0) {   // empty IR: success, process() gives zeros (:112-115)
     drop();
     s->inited = true;
-    s->head = hb; s->tail = tb; s->max_len = max_len ? max_len : hb;
+    s->head = hb; s->tail = tb; s->max_len = max_len ? max_len : hb_req;
     return true;
   }
-  const size_t eff_max_len = max_len ? max_len : hb;
+  const size_t eff_max_len = max_len ? max_len : hb_req;
   const size_t split = two_stage ? 2 * tb : (size_t)-1;
 
   // partition counts (ceil(float/float) as FFTConvolver.cpp:115; exact below 2^24 samples)

@@ -61,7 +61,7 @@ def test_reference_error_conventions_without_gpu(lib):
     f = reevr_amd.FFTConvolver()
     assert np.all(f.process(np.ones(3, np.float32)) == 0)     # process before init
     assert f.init(0, ir) is False
-    assert f.init(1 << 20, ir) is False                        # above RVC_MAX_BLOCK
+    assert f.init(1 << 20, ir) is (lib.rvc_device_count() > 0)    # huge block: clamped, so it only fails for want of a device
 
 
 def test_cpp_shim_headers_compile():

@@ -179,11 +179,19 @@ def test_max_block_and_limits():
     o = O.TwoStageFFTConvolver("orc"); assert o.init(8192, 16384, ir)
     yo = np.concatenate([o.process(x[i:i + 8192]) for i in range(0, 57344, 8192)])
     assert rel_rms(y, yo) <= TOL
-    assert c.init(32768, ir) is False and c.last_error == 4   # RVC_ERR_UNSUPPORTED
+    # above the largest partition: accepted, served with 16384-sample partitions, same samples
+    assert c.init(32768, ir) is True and c.last_error == 0 and c.head_block == 16384
+    o = O.FFTConvolver("orc"); assert o.init(32768, ir)
+    yo = np.concatenate([o.process(x[:32768]), o.process(x[32768:])])
+    assert rel_rms(np.concatenate([c.process(x[:32768]), c.process(x[32768:])]), yo) <= TOL
+    t = reevr_amd.TwoStageFFTConvolver()
+    assert t.init(32768, 65536, ir) is True and (t.head_block, t.tail_block) == (16384, 16384)
+    o = O.TwoStageFFTConvolver("orc"); assert o.init(32768, 65536, ir)
+    assert rel_rms(np.concatenate([t.process(x[:32768]), t.process(x[32768:])]),
+                   np.concatenate([o.process(x[:32768]), o.process(x[32768:])])) <= TOL
     d = reevr_amd.FFTConvolver(fft_f64=True)
-    assert d.init(16384, ir) is False and d.last_error == 4   # f64 transforms: blocks up to 8192
-    assert d.init(8192, ir, max_len=60000)
-    o = O.FFTConvolver("orc"); assert o.init(8192, ir)
+    assert d.init(16384, ir, max_len=60000) is True and d.head_block == 8192   # f64 transforms: partitions up to 8192
+    o = O.FFTConvolver("orc"); assert o.init(16384, ir)
     assert rel_rms(d.process(x), o.process(x)) <= 1e-6
 
 
