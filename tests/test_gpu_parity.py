@@ -487,6 +487,52 @@ def test_fuzz_geometry_and_call_pattern(seed):
                                   f"bg {bg} fixed {fixed} clear {clear_at}: rel rms {err / ref:.3e}")
 
 
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_fuzz_single_stage_sets(seed):
+    """The same for single-stage (FFTConvolver) sets: block sizes 16..4096, IR lengths on either side of
+    the long-call stage's threshold (2 x 8192) and of the wide stage's (4 x 16384), call patterns
+    mixing per-block, ragged and very long calls, optional block-aligned clear."""
+    rng = np.random.RandomState(7000 + seed)
+    block = int(rng.choice([16, 100, 256, 512, 2048, 4096]))
+    hb = 1 << (block - 1).bit_length()
+    nch = int(rng.randint(1, 3))
+    base = int(rng.choice([900, 16384, 16385, 30000, 65536, 65537, 100000]))
+    irs = [synth.synth_ir(max(1, base - (c * 777)), 1, 160 + 3 * seed + c)[0] for c in range(nch)]
+    total = 260000
+    sched = []
+    left = total
+    while left > 0:
+        kind = rng.randint(0, 6)
+        n = hb if kind < 3 else (int(rng.randint(1, 3 * hb + 2)) if kind == 3 else int(rng.choice([8192 * 4 + 1, 8192 * 5, 70000, 16384 * 4 + 3])))
+        n = min(n, left)
+        sched.append(n)
+        left -= n
+    x = np.stack([synth.synth_input(total, 9 * seed + c) for c in range(nch)])
+    s = reevr_amd.ConvolverSet(nch, fixed_partitions=bool(rng.randint(0, 4) == 0))
+    assert s.init_uniform(block, irs, max_len=max(sched)), s.last_error_string
+    clear_at = int(rng.randint(0, len(sched))) if rng.randint(0, 2) == 0 else -1
+    got = np.empty_like(x)
+    pos = start = 0
+    for i, n in enumerate(sched):
+        if i == clear_at and pos % hb == 0:
+            s.clear()
+            start = pos
+        got[:, pos:pos + n] = s.process(x[:, pos:pos + n])
+        pos += n
+    assert s.last_error == 0, s.last_error_string
+    for c in range(nch):
+        o = O.FFTConvolver("orc")
+        assert o.init(block, irs[c])
+        want = np.empty(total, np.float32)
+        want[:start] = o.process(x[c, :start]) if start else want[:0]
+        if start:
+            o.clear()
+        want[start:] = o.process(x[c, start:])
+        err = np.sqrt(np.mean((got[c].astype(np.float64) - want) ** 2))
+        ref = max(np.sqrt(np.mean(want.astype(np.float64) ** 2)), 1e-12)
+        assert err / ref <= TOL, f"seed {seed}: block {block} nch {nch} ir {[len(i) for i in irs]} clear {clear_at}: {err / ref:.3e}"
+
+
 def test_ir_hot_swap_matches_reference_sequence():
     """load -> warm-up replay (one multi-block call here, a loop of block calls
     in the reference) -> 50 ms crossfade -> swap, for a quad impulse, against the oracle-side
