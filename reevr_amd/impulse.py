@@ -71,14 +71,29 @@ class Impulse:
     def prepare(self, srate: float):           # Impulse.cpp:73-76
         self.srate = float(srate)
 
-    def setRaw(self, *channels):
-        """The product of Impulse::load (Impulse.cpp:160-196): (LL, RR) or (LL, RR, LR, RL)."""
+    @staticmethod
+    def tail_start(channels) -> int:
+        """Impulse::load's silence trim (Impulse.cpp:151-156, getTailStart :696-703): one past the last
+        sample whose magnitude reaches 1e-3 in any channel (file-loading step, host side)."""
+        end = 0
+        for c in channels:
+            nz = np.flatnonzero(np.abs(_f32(c)) >= np.float32(1e-3))
+            if nz.size:
+                end = max(end, int(nz[-1]) + 1)
+        return end
+
+    def setRaw(self, *channels, trim_tail: bool = False):
+        """The product of Impulse::load (Impulse.cpp:160-196): (LL, RR) or (LL, RR, LR, RL).
+        trim_tail=True applies load's trailing-silence trim first (decoded file channels in)."""
         if len(channels) not in (2, 4):
             raise ValueError("2 (LL, RR) or 4 (LL, RR, LR, RL) channels")
         raw = [_f32(c) for c in channels]
         n = raw[0].size
         if any(r.size != n for r in raw):
             raise ValueError("channels differ in length")
+        if trim_tail:
+            n = self.tail_start(raw)
+            raw = [np.ascontiguousarray(r[:n]) for r in raw]
         self.isQuad = len(raw) == 4
         self.numChans = len(raw)
         ptrs = (L.F32P * len(raw))(*[r.ctypes.data_as(L.F32P) for r in raw])

@@ -45,7 +45,7 @@ def render(x: np.ndarray, sr: int, ir: np.ndarray, ir_sr: int, block: int = 512,
         raw = [ir[0], ir[0]]
     imp = Impulse(device)
     imp.prepare(float(sr))
-    imp.setRaw(*raw)
+    imp.setRaw(*raw, trim_tail=True)                # Impulse::load drops trailing silence below 1e-3
     for k, v in imp_params.items():
         setattr(imp, k, v)
     imp.recalcImpulse()

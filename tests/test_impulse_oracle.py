@@ -146,3 +146,11 @@ def test_impulse_handle_without_gpu():
     # null handles are inert, like the convolver entry points
     assert lib.rvc_impulse_size(None) == 0 and lib.rvc_impulse_recalc(None, None) == 0
     lib.rvc_impulse_destroy(None)
+
+
+def test_tail_start_rule():
+    import reevr_amd
+    a = np.zeros(100, np.float32); b = np.zeros(100, np.float32)
+    assert reevr_amd.Impulse.tail_start([a, b]) == 0
+    a[10] = 0.5; b[40] = -1e-3; b[60] = 9.9e-4           # 1e-3 counts, 9.9e-4 does not (Impulse.cpp:698)
+    assert reevr_amd.Impulse.tail_start([a, b]) == 41

@@ -55,6 +55,10 @@ def test_render_matches_oracle_chain(tmp_path, nir):
     assert osr == sr and y.shape[0] == 2
     # CPU chain: impulse restatement -> TwoStage oracle -> wet bus
     raw = [ir[0], ir[3], ir[1], ir[2]] if nir == 4 else ([ir[0], ir[1]] if nir == 2 else [ir[0], ir[0]])
+    from reevr_amd import Impulse
+    end = Impulse.tail_start(raw)                       # Impulse::load's trailing-silence trim (|x| < 1e-3)
+    assert 0 < end < m
+    raw = [r[:end] for r in raw]
     imp = O.impulse_recalc(raw, attack=0.02, decay=0.5, gain=1.5, srate=float(sr))["buffers"]
     assert y.shape[1] == n + imp[0].size
     xin = np.concatenate([x, np.zeros((2, imp[0].size), np.float32)], axis=1)
