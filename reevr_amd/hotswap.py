@@ -171,3 +171,119 @@ def wet_mix_device(cur, load=None, xfade: int = 0, xfadelen: int = 1, yrev=None,
     if not L.lib().rvc_wet_mix_device(device, stream, C.byref(p)):
         raise RuntimeError("rvc_wet_mix_device failed")
     return out
+
+
+class DeviceHotSwap:
+    """The same convolver section of processBlock (src/PluginProcessor.cpp:1655-1756, 1793-1876) for
+    blocks that live on the DEVICE: torch CUDA tensors in, torch CUDA tensors out, no host round trip.
+    Two device StereoConvolver pairs (current / loading), the 0.25 s warm-up ring in HBM, warm-up as ONE
+    multi-block rvc_set_process_device call per pair, and crossfade + true-stereo sum + envelope + width +
+    dry/wet in ONE pass (rvc_wet_mix_device). Impulses are reevr_amd.Impulse objects (device-resident,
+    rvc_set_init_impulse) or any object with bufferLL/RR[/LR/RL] + isQuad. Everything is enqueued on the
+    current pair's foreground stream and the streams are chained with torch stream dependencies."""
+
+    class _Pair:
+        def __init__(self, device):
+            from .convolver import ConvolverSet
+            self.main = ConvolverSet(2, device)        # LL, RR
+            self.cross = ConvolverSet(2, device)       # LR, RL
+            self.isQuad = False
+
+        def load(self, imp, head, tail, max_len):
+            if getattr(imp, "_h", None) and hasattr(imp, "device_ptr"):
+                assert self.main.init_impulse(head, tail, imp, [0, 1], max_len)
+                self.isQuad = bool(imp.isQuad)
+                if self.isQuad:
+                    assert self.cross.init_impulse(head, tail, imp, [2, 3], max_len)
+            else:
+                assert self.main.init(head, tail, [imp.bufferLL, imp.bufferRR], max_len)
+                self.isQuad = bool(imp.isQuad)
+                if self.isQuad:
+                    assert self.cross.init(head, tail, [imp.bufferLR, imp.bufferRL], max_len)
+
+        def run(self, x, force2=False):
+            """x: (2, n) device tensor. Returns [LL, RR] or [LL, RR, LR, RL] (device vectors); synchronous
+            with torch's current stream on return (ordering, not a host wait)."""
+            y = self.main.process_device(x, sync=False)
+            out = [y[0], y[1]]
+            if self.isQuad and not force2:
+                z = self.cross.process_device(x, sync=False)
+                out += [z[0], z[1]]
+            return out
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        self.cur = self._Pair(device)
+        self.nxt = self._Pair(device)
+        self.loadState = K_IDLE
+        self.xfade = self.xfadelen = 0
+        self._worker = None
+
+    def prepare(self, sampleRate: float, samplesPerBlock: int):
+        import torch
+        self.srate = float(sampleRate)
+        self.size = int(samplesPerBlock)
+        self.head = 1
+        while self.head < self.size:
+            self.head *= 2
+        self.tail = max(8192, 2 * self.head)
+        self.W = int(math.ceil(sampleRate)) // 4                     # 0.25 s warm-up ring, :610
+        self.warmer = torch.zeros(2, self.W, device=f"cuda:{self.device}")
+        self.warmwritepos = 0
+        self.max_len = max(self.size, (self.W // self.size) * self.size)
+
+    def loadImpulse(self, imp):
+        self.cur.load(imp, self.head, self.tail, self.max_len)
+
+    def request_impulse(self, imp, threaded: bool = False) -> bool:
+        if self.loadState != K_IDLE:
+            return False
+        self.loadState = K_LOADING
+
+        def job():
+            self.nxt.load(imp, self.head, self.tail, self.max_len)
+            self.loadState = K_READY
+        if threaded:
+            self._worker = threading.Thread(target=job)
+            self._worker.start()
+        else:
+            job()
+        return True
+
+    def wait_loaded(self):
+        if self._worker is not None:
+            self._worker.join()
+            self._worker = None
+
+    def process(self, send, delayed, yrev=None, width: float = 1.0, drygain: float = 0.0, wetgain: float = 1.0,
+                dry=None, tsenabled: bool = True):
+        """send / delayed: (2, n) device tensors (send feeds the warm-up ring and the fading-in
+        convolver, delayed the current one). Returns (outL, outR) device tensors."""
+        import torch
+        n = send.shape[1]
+        # warm-up ring write (:1655-1668)
+        idx = (self.warmwritepos + torch.arange(n, device=send.device)) % self.W
+        self.warmer[:, idx] = send
+        self.warmwritepos = (self.warmwritepos + n) % self.W
+        if self.loadState == K_READY:                                # warm-up replay, :1695-1755
+            numBlocks = self.W // self.size
+            start = (self.warmwritepos + 1) % self.W
+            ridx = (start + torch.arange(numBlocks * self.size, device=send.device)) % self.W
+            self.nxt.run(self.warmer[:, ridx].contiguous(), force2=True)     # one multi-block call, output discarded
+            self.loadState = K_FADING
+            self.xfade = int(math.ceil(self.srate * CONV_XFADE_MS / 1000.0))
+            self.xfadelen = self.xfade
+        cur = self.cur.run(delayed.contiguous())                     # :1793-1797
+        if not (self.cur.isQuad and tsenabled):
+            cur = cur[:2]
+        load = None
+        xf = self.xfade
+        if self.loadState == K_FADING:                               # :1800-1830
+            load = self.nxt.run(send.contiguous(), force2=True)[:2]
+            self.xfade -= self.size                                   # the reference's loop runs over the whole buffer
+        out = wet_mix_device(cur, load=load, xfade=xf, xfadelen=max(self.xfadelen, 1), yrev=yrev, width=width,
+                             drygain=drygain, wetgain=wetgain, dry=dry, device=self.device)
+        if self.loadState == K_FADING and self.xfade <= 0:
+            self.loadState = K_IDLE
+            self.cur, self.nxt = self.nxt, self.cur
+        return out

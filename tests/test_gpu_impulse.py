@@ -253,3 +253,62 @@ def test_wet_mix_argument_checks():
     p = _lib.WetParams()
     assert _lib.lib().rvc_wet_mix_device(0, None, None) == 0
     assert _lib.lib().rvc_wet_mix_device(0, None, __import__("ctypes").byref(p)) == 0     # no buffers
+
+
+@pytest.mark.parametrize("quad", [False, True])
+def test_device_hot_swap_pipeline(quad):
+    """DeviceHotSwap (blocks stay on the GPU: device convolvers, warm-up ring in HBM, one multi-block warm-up
+    call, crossfade + wet bus in one kernel) against the host-side HotSwapStereoConvolver + wet_bus, which is
+    itself checked against the oracle restatement of src/PluginProcessor.cpp:1655-1876
+    (test_ir_hot_swap_matches_reference_sequence)."""
+    import torch
+    import reevr_amd
+    from reevr_amd import synth
+    from reevr_amd.hotswap import DeviceHotSwap, HotSwapStereoConvolver, wet_bus
+
+    class Imp:
+        pass
+
+    def imp(inst, n):
+        irs = synth.synth_ir(n, 4, inst)
+        m = Imp()
+        m.bufferLL, m.bufferRR, m.bufferLR, m.bufferRL = irs
+        m.isQuad = quad
+        return m
+
+    sr, blk, nblocks = 48000, 480, 64
+    a, b = imp(90, 26000), imp(91, 19000)
+    L = synth.synth_input(blk * nblocks, 0)
+    R = synth.synth_input(blk * nblocks, 1)
+    yrev = (0.5 + 0.5 * synth.white_noise(blk * nblocks, 99)).astype(np.float32)
+    width, dg, wg = 0.8, 0.3, 0.9
+    host = HotSwapStereoConvolver(lambda: reevr_amd.StereoConvolver(), threaded=False)
+    dev = DeviceHotSwap()
+    for h in (host, dev):
+        h.prepare(sr, blk)
+        h.loadImpulse(a)
+    dL, dR, dY = (torch.from_numpy(v).cuda() for v in (L, R, yrev))
+    got, want = [], []
+    swap_block = None
+    for i in range(nblocks):
+        s = slice(i * blk, (i + 1) * blk)
+        if i == 25:
+            assert host.request_impulse(b) and dev.request_impulse(b)
+        x = torch.stack([dL[s], dR[s]])
+        was_fading = host.loadState == 3 or host.loadState == 2
+        wet = host.process(L[s], R[s], L[s], R[s], blk)
+        if was_fading and host.loadState == 0 and swap_block is None:
+            swap_block = i
+        want.append(wet_bus(wet, yrev[s], width, dg, wg, np.stack([L[s], R[s]])))
+        o = dev.process(x, x, yrev=dY[s].contiguous(), width=width, drygain=dg, wetgain=wg, dry=[dL[s].contiguous(), dR[s].contiguous()])
+        got.append(torch.stack(o).cpu().numpy())
+    assert host.loadState == 0 and dev.loadState == 0 and swap_block is not None
+    got = np.concatenate(got, axis=1)
+    want = np.concatenate(want, axis=1)
+    keep = np.ones(blk * nblocks, bool)
+    if quad:   # the block of the swap: the reference adds the new convolver's stale LR/RL buffers there (DESIGN.md)
+        keep[swap_block * blk:(swap_block + 1) * blk] = False
+    for c in range(2):
+        err = np.sqrt(np.mean((got[c, keep].astype(np.float64) - want[c, keep]) ** 2))
+        ref = np.sqrt(np.mean(want[c, keep].astype(np.float64) ** 2))
+        assert err / ref <= 1e-5, (c, err / ref)
