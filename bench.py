@@ -285,6 +285,16 @@ def main():
     roof_all = {k: {"avg_launch_ms": round(v["avg_ms"], 5),
                     "achieved_GBs": round(alg[k] / (v["avg_ms"] * 1e-3) / 1e9, 1),
                     "frac": round(alg[k] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in kern.items()}
+    # and the PHYSICAL rate: measured HBM bytes per launch (PMC passes, profiles/traffic.json) / launch time
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and frames == 40 * SR:
+        tk = json.load(open(tpath)).get("kernels", {})
+        for k, v in kern.items():
+            if k in tk:
+                gbs = tk[k]["traffic_bytes"] / (v["avg_ms"] * 1e-3) / 1e9
+                roof_all[k]["traffic"] = tk[k]["traffic_bytes"]
+                roof_all[k]["physical_GBs"] = round(gbs, 1)
+                roof_all[k]["physical_frac"] = round(gbs / HBM_PEAK_GBS, 4)
     bps = alg_bytes_per_sample(head, tail, IR_LEN)
     path_gbs = value / world * 1e6 * bps / 1e9
 
