@@ -40,14 +40,14 @@ def gather_batches(local, dist=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local.unsqueeze(0)
     world = dist.get_world_size()
-    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    if local.is_cuda:
-        dist.all_gather_into_tensor(out, local.contiguous())
-    else:
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(parts, local.contiguous())
-        out = torch.stack(parts)
-    return out
+    local = local.contiguous()
+    if local.is_cuda and dist.get_backend() == "nccl":      # RCCL: one collective straight into the stacked tensor
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out.view(world * local.shape[0], *local.shape[1:]), local)
+        return out
+    parts = [torch.empty_like(local) for _ in range(world)]  # gloo (CPU tensors, or CUDA tensors staged by gloo)
+    dist.all_gather(parts, local)
+    return torch.stack(parts)
 
 
 def reassemble(gathered, n_units: int, world: int):
