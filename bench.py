@@ -1,36 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the partitioned-convolution hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): stereo, 10 s IR @ 48 kHz, host block 512
-(-> head 512 / tail 8192, StereoConvolver.cpp:11-15), synthetic white-noise input,
-decaying-noise IR with the reference's auto-gain (reevr_amd/synth.py).
+Headline workload (BASELINE.json configs[1], measured the way SURVEY.md 8d defines it): stereo
+instances with a 10 s IR @ 48 kHz at host block 512 (-> head 512 / tail 8192,
+StereoConvolver.cpp:11-15), driven STRICTLY BLOCK-SYNCHRONOUSLY -- one process() call per
+512-frame host block, exactly the plug-in's calling pattern (src/PluginProcessor.cpp:1793-1797)
+-- for `--channels` lock-step channels of ONE convolver set (default 512 = 256 stereo instances,
+each with its own IR). A single stereo pair moves 1.5 MB per block and cannot fill a 256-CU GPU;
+256 instances keep 4 GB of IR spectra + delay lines in HBM (>> the 256 MiB Infinity Cache), which
+is the regime the per-block delay-line sweep (FFTConvolver.cpp:176-187) is HBM-bound in.
 
-A "step" is one pass of the hot path over one batch of input: ONE process() call of
-`--frames` frames per channel (default 40 s = 1 920 000 frames = 3750 blocks of 512) with
-input and output resident in HBM. process() takes any length, and its result does not
-depend on how the stream is cut into calls (tests/test_gpu_parity.py), so this is the same
-function the plugin calls per 512-sample block -- batched in time because a single
-512-frame block (2 KB per channel) cannot fill a 256-CU GPU. Two more numbers are reported
-beside `value` so nothing hides behind the batching:
-  * "two_stage": the same call with RVC_FLAG_FIXED_PARTITIONS, i.e. forced through the
-    reference's head-512 / tail-8192 partition structure (the engine's default instead gives a
-    call that spans >= 4 tail blocks to one uniform delay line at the tail block size -- same
-    output, no 512-sample work where no 512-sample latency is asked for);
-  * "streaming": strictly one call per 512-frame block (the plugin's real-time pattern).
+A "step" is `--blocks-per-step` consecutive host blocks (default 256 = 16 tail periods = 131072
+frames = 2.7 s of audio per channel): 256 per-block launches + 16 tail jobs, so every step does the
+same work. Inputs / outputs are resident in HBM (two batches, rotated).
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-N > 1: every rank owns one independent stereo instance (its own IR, `inst = rank`), no
-data-path collective (weak scaling; `--gather` adds the optional RCCL all_gather of the
-output batch). One JSON line on rank 0.
+N > 1: instances are dealt to ranks (unit mod world), every rank runs the same
+number of channels (weak scaling), no data-path collective; the output batch of every step is
+gathered with ONE RCCL all_gather per step (`--gather 0` turns it off). One JSON line on rank 0.
+
+Other BASELINE configurations: `--config 4` (8 stereo instances sharded over the ranks, block-synchronous,
+strong scaling) and `--config 5` (64 mono channels, 5 s IR, block 4096, offline render = one long
+call per step, sharded 64/N per rank, strong scaling).
+
+Side numbers on the same line (rank 0, N = 1): one stereo pair block-synchronously (the plug-in's own
+case: latency per block), the offline long-call rate of a stereo pair (adaptive partitioning), the
+same forced through the reference's partition sizes, and the CPU baseline.
 """
 from __future__ import annotations
 
 import argparse
+import concurrent.futures
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,23 +44,8 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 SR = 48000
-IR_LEN = 10 * SR
-HOST_BLOCK = 512
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-
-
-ROOF_NOTES = {
-    "fir": "achieved = ALGORITHMIC bytes of the reference structure this launch replaces (16 B per partition x bin of "
-           "the head, tail0 and tail delay lines, SURVEY.md 8d) / measured launch time. The kernel tiles 64 blocks of "
-           "time per workgroup and, for long calls, uses one delay line at a larger block for the whole IR, so physical "
-           "HBM traffic (`traffic`) is ~50x below the algorithmic figure: frac > 1 is expected, the kernel is fp32-FMA "
-           "bound (DESIGN.md 7).",
-    "fft": "achieved = ALGORITHMIC bytes of the reference transforms this launch replaces (4 B per input sample + 8 B "
-           "per spectrum bin, for every head AND tail block of the call, SURVEY.md 8d) / measured launch time; `traffic` "
-           "is what the kernel physically moved (overlap-save reads 2B samples per B-sample block, one transform per "
-           "16384-sample block on the long-call path). The FIR kernel takes about the same time per step "
-           "(kernels_ms / roofline_all); which of the two is 'dominant' can flip run to run.",
-}
+FP32_PEAK_TFLOPS = 157.3  # vector fp32 (same guide)
 
 
 def alg_bytes_block(B: int, P: int) -> int:
@@ -64,86 +53,81 @@ def alg_bytes_block(B: int, P: int) -> int:
     return 16 * P * (B + 1) + 8 * (B + 1) + 16 * B
 
 
-def alg_bytes_per_sample(head: int, tail: int, ir_len: int) -> float:
-    """Per channel-sample, reference structure head / tail0 / tail (TwoStageFFTConvolver.cpp:117-138)."""
+def ref_partitions(head: int, tail: int, ir_len: int):
+    """Partition counts of the reference's head / tail0 / tail sub-convolvers (TwoStageFFTConvolver.cpp:117-138)."""
     p_head = -(-min(ir_len, tail) // head)
     p_t0 = -(-min(max(ir_len - tail, 0), tail) // head)
     p_t = -(-max(ir_len - 2 * tail, 0) // tail)
+    return p_head, p_t0, p_t
+
+
+def alg_bytes_per_sample(head: int, tail: int, ir_len: int) -> float:
+    """Per channel-sample, reference structure head / tail0 / tail."""
+    p_head, p_t0, p_t = ref_partitions(head, tail, ir_len)
     per_tail_block = (tail // head) * (alg_bytes_block(head, p_head) + (alg_bytes_block(head, p_t0) if p_t0 else 0))
     per_tail_block += alg_bytes_block(tail, p_t) if p_t else 0
     return per_tail_block / tail
 
 
-def cpu_baseline(irs: np.ndarray, x: np.ndarray, budget_s: float) -> dict:
-    """The reference itself (oracle/_ref, kind "reference") or the C restatement (kind "port")
-    on this host's cores, 512-frame process() calls, tail inline, bounded to ~budget_s."""
+def flops_per_sample(head: int, tail: int, ir_len: int) -> float:
+    """SURVEY.md 8d flop model: 2 * 2.5 N log2 N + 8 P (B+1) per block of each sub-convolver."""
+    def blk(B, P):
+        N = 2 * B
+        return 2 * 2.5 * N * np.log2(N) + 8 * P * (B + 1)
+    p_head, p_t0, p_t = ref_partitions(head, tail, ir_len)
+    per = (tail // head) * (blk(head, p_head) + (blk(head, p_t0) if p_t0 else 0)) + (blk(tail, p_t) if p_t else 0)
+    return float(per / tail)
+
+
+def make_irs(ir_len: int, instances):
+    """One synthetic stereo IR per instance (reevr_amd.synth), generated in parallel."""
+    from reevr_amd import synth
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        sets = list(ex.map(lambda i: synth.synth_ir(ir_len, 2, inst=i), instances))
+    return [s[c] for s in sets for c in range(2)]
+
+
+def cpu_baseline(irs, x, head_block: int, budget_s: float) -> dict:
+    """The reference itself (oracle/_ref, kind "reference") or the C restatement (kind "port") on this
+    host's cores: 512-frame process() calls back to back, tail inline, one instance per thread, driven
+    by a pthread loop in C (oracle/cpu_bench.c -- no Python in the loop). Bounded to ~budget_s."""
     from oracle import oracle_py as O
     which = "ref" if O.have_ref() else "orc"
-    nch, frames = x.shape
-    frames -= frames % HOST_BLOCK
-
-    def run_channel(c: int, stop_at: float, counter: list):
-        conv = O.TwoStageFFTConvolver(which)
-        assert conv.init(HOST_BLOCK, 8192, irs[c % irs.shape[0]])
-        fn = conv._b.fn("twostage_process")
-        xin = np.ascontiguousarray(x[c % nch])
-        out = np.empty(HOST_BLOCK, np.float32)
-        import ctypes as C
-        fp = C.POINTER(C.c_float)
-        outp = out.ctypes.data_as(fp)
-        base = xin.ctypes.data
-        done = 0
-        while True:
-            for i in range(0, frames, HOST_BLOCK):
-                fn(conv._h, C.cast(base + 4 * i, fp), outp, HOST_BLOCK)
-            done += frames
-            if time.perf_counter() >= stop_at:
-                break
-        counter[c] = done
-
-    # (i) one thread, channels one after the other -- comparable with BASELINE.md section 2
-    t0 = time.perf_counter()
-    cnt = [0] * nch
-    per = budget_s / (2 * nch)
-    for c in range(nch):
-        run_channel(c, time.perf_counter() + per, cnt)
-    t1 = time.perf_counter()
-    single = sum(cnt) / (t1 - t0) / 1e6
-    # (ii) all host cores, one convolver instance per thread (ctypes releases the GIL)
     cores = os.cpu_count() or 1
-    cntm = [0] * cores
-    t2 = time.perf_counter()
-    stop = t2 + budget_s / 2
-    th = [threading.Thread(target=run_channel, args=(c, stop, cntm)) for c in range(cores)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    t3 = time.perf_counter()
-    multi = sum(cntm) / (t3 - t2) / 1e6
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    n1, w1, _ = O.cpu_bench(which, 1, head_block, 8192, head_block, irs[:2], x[:2], budget_s * 0.4)
+    nm, wm, per = O.cpu_bench(which, cores, head_block, 8192, head_block, irs, x, budget_s * 0.6)
     return {
-        "value": round(single, 3), "unit": "Msamples/s", "cores": 1,
+        "value": round(n1 / w1 / 1e6, 3), "unit": "Msamples/s", "cores": 1,
         "kind": "reference" if which == "ref" else "port",
-        "sample": f"stereo 10 s IR, head 512 / tail 8192, {HOST_BLOCK}-frame process() calls, tail inline, "
-                  f"{sum(cnt)} channel-samples in {t1 - t0:.1f} s on 1 thread",
-        "all_cores": {"value": round(multi, 3), "cores": cores,
-                      "sample": f"{cores} independent mono instances, one per thread, {t3 - t2:.1f} s"},
+        "sample": f"mono instance, 10 s IR, head {head_block} / tail 8192, {head_block}-frame process() calls back to back, "
+                  f"tail inline: {n1} samples in {w1:.1f} s on 1 thread (C loop, oracle/cpu_bench.c)",
+        "cpu_model": model, "flags": "g++ -O3 (SSE2 MAC as shipped, Utilities.cpp:62-111)",
+        "all_cores": {"value": round(nm / wm / 1e6, 3), "cores": cores,
+                      "sample": f"{cores} independent mono instances ({len(irs)} distinct IRs), one pthread each, "
+                                f"{nm} samples in {wm:.1f} s; slowest / fastest thread {min(per)} / {max(per)} samples"},
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=40 * SR, help="frames per channel per step (one process() call)")
-    ap.add_argument("--bg-stream", type=int, default=0, help="1: tail stage on the second HIP stream (overlaps the head stage)")
-    ap.add_argument("--fixed-partitions", type=int, default=0,
-                    help="1: force the reference's head/tail partition sizes even for long calls")
-    ap.add_argument("--gather", action="store_true", help="RCCL all_gather of the output batch each step")
-    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--side", type=int, default=1, help="0: skip the two_stage side measurement")
-    ap.add_argument("--stream-calls", type=int, default=3000, help="512-frame calls of the streaming side measurement")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5), help="BASELINE.json configuration (1-based index)")
+    ap.add_argument("--channels", type=int, default=512, help="config 2: lock-step channels per GPU (2 per stereo instance)")
+    ap.add_argument("--blocks-per-step", type=int, default=256, help="block-synchronous configs: host blocks per step")
+    ap.add_argument("--bg-stream", type=int, default=0, help="1: tail stage on the second HIP stream")
+    ap.add_argument("--gather", type=int, default=1, help="N > 1: RCCL all_gather of every step's output batch (0: off)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--side", type=int, default=1, help="0: skip the side measurements")
     args = ap.parse_args()
 
     import torch
@@ -153,8 +137,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     # development switch: all ranks on GPU 0 over gloo, to exercise the N > 1 control flow on a 1-GPU box
     same_device = os.environ.get("REEVR_BENCH_SAME_DEVICE") == "1"
     if same_device:
@@ -172,28 +157,69 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    frames = int(args.frames)
-    nch = 2
-    irs = synth.synth_ir(IR_LEN, nch, inst=rank)                 # this rank's stereo instance
-    x = np.stack([synth.synth_input(frames, c + 2 * rank) for c in range(nch)])
-    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream),
-                                  fixed_partitions=bool(args.fixed_partitions))
+    # ---- workload ----------------------------------------------------------------------------
+    if args.config == 2:
+        ir_len, host_block, long_call = 10 * SR, 512, False
+        if args.channels < 2 or args.channels % 2:
+            raise SystemExit("--channels must be a positive even number (stereo instances)")
+        n_inst = args.channels // 2
+        instances = shard.units_for_rank(n_inst * world, world, rank)  # rank = unit mod world, equal shards
+        scaling = "weak"
+        workload = (f"stereo, 10 s IR @ 48 kHz, block=512 (head 512 / tail 8192), TwoStage convolver: {n_inst} stereo "
+                    f"instances per GPU in lock-step, one process() per 512-frame block")
+    elif args.config == 4:
+        ir_len, host_block, long_call = 10 * SR, 512, False
+        if 8 % world:
+            raise SystemExit("--config 4 shards 8 stereo instances: --gpus must divide 8")
+        instances = shard.units_for_rank(8, world, rank)
+        scaling = "strong"
+        workload = "8 independent stereo instances, 10 s IR @ 48 kHz, block=512, sharded over the GPUs (unit mod world)"
+    else:
+        ir_len, host_block, long_call = 5 * SR, 4096, True
+        if 32 % world:
+            raise SystemExit("--config 5 shards 64 mono channels (32 pairs): --gpus must divide 32")
+        instances = shard.units_for_rank(32, world, rank)
+        scaling = "strong"
+        workload = "batched offline render: 64 mono channels, 5 s IR @ 48 kHz, block=4096, 64/N channels per GPU, one long call per step"
+    nch = 2 * len(instances)
+    head = 1
+    while head < host_block:
+        head *= 2
+    tail = max(8192, 2 * head)                                        # StereoConvolver.cpp:11-15
+    if not long_call and (args.blocks_per_step < 1 or (args.blocks_per_step * host_block) % tail):
+        raise SystemExit("--blocks-per-step must cover whole tail periods (a multiple of %d)" % (tail // host_block))
+    frames_step = 20 * SR if long_call else args.blocks_per_step * host_block   # frames per channel per step
+    frames_step -= frames_step % host_block
+    nbuf = 1 if long_call else 2                                      # input / output batches rotated through
+
+    t_gen = time.perf_counter()
+    irs = make_irs(ir_len, instances)
+    x = np.stack([synth.synth_input(frames_step * nbuf, 2 * u + c) for u in instances for c in range(2)])
+    gen_s = time.perf_counter() - t_gen
+    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream))
     t_init = time.perf_counter()
-    if not conv.init(HOST_BLOCK, 8192, list(irs), max_len=frames):
+    if not conv.init(host_block, tail, irs, max_len=frames_step if long_call else host_block):
         raise SystemExit(f"init failed: {conv.last_error_string}")
     conv.sync()
     init_ms = (time.perf_counter() - t_init) * 1e3
-    head, tail = conv.head_block, conv.tail_block
     d_in = torch.from_numpy(x).to(dev)
     d_out = torch.empty_like(d_in)
     do_gather = bool(args.gather and world > 1)
     torch.cuda.synchronize()
+    state = {"i": 0}
 
     def step():
-        conv.process_device(d_in, d_out, sync=False, order=False)   # buffers resident and complete; synced below
-        if do_gather:                      # one RCCL all_gather per batch of 3750 blocks
+        b = state["i"] % nbuf
+        state["i"] += 1
+        xi = d_in[:, b * frames_step:(b + 1) * frames_step]
+        yo = d_out[:, b * frames_step:(b + 1) * frames_step]
+        if long_call:
+            conv.process_device(xi, yo, sync=False, order=False)
+        else:                                  # the host's per-block loop (in C): one call per 512-frame block
+            conv.process_device_blocks(xi, host_block, yo, sync=False, order=False)
+        if do_gather:                          # one RCCL all_gather per step (batch of blocks), never per block
             conv.sync()
-            shard.gather_batches(d_out, dist)
+            shard.gather_batches(yo, dist)
 
     def fence():
         conv.sync()
@@ -202,13 +228,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # untimed pre-roll: ~50 ms of the same step so that the GPU's clocks have settled whatever K / W are
-    # (a step is 60 us: with K = 50 the whole timed region would otherwise end before they have)
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.05:
-        for _ in range(20):
+    # untimed pre-roll to the steady state: the tail delay line holds P_T tail blocks of history and
+    # rows before time 0 are never fetched, so the first P_T + 2 tail periods move fewer bytes
+    pre = 0
+    if not long_call:
+        pre = -(-(conv.partitions(1) + 4) * tail // frames_step)
+        for _ in range(pre):
             step()
         conv.sync()
+    else:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.05:
+            step()
+            conv.sync()
     for _ in range(args.warmup):
         step()
     fence()
@@ -216,15 +248,15 @@ def main():
     for _ in range(args.steps):
         step()
     # closing bracket: synchronise this rank, stamp, barrier; the reported time is the MAX over ranks of
-    # the stamped spans (all ranks left the opening barrier together), so the collective's own latency
-    # (~0.2 ms for an RCCL barrier, 3 steps' worth) is not charged to the K steps
+    # the stamped spans (all ranks left the opening barrier together)
     conv.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
     conv.check()
     elapsed = shard.max_over_ranks(elapsed, dist, dev)    # slowest rank
-    total_samples = world * nch * frames * args.steps
+    total_ch = nch * world if args.config == 2 else (16 if args.config == 4 else 64)
+    total_samples = total_ch * frames_step * args.steps
     value = total_samples / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
 
@@ -237,148 +269,156 @@ def main():
     # ---- per-kernel durations, live, with HIP events on the stream the kernels run on ----
     conv.set_timing(True)
     conv.kernel_time_reset()
-    ksteps = min(args.steps, 10)
+    ksteps = 1
     for _ in range(ksteps):
-        conv.process_device(d_in, d_out, sync=True)
+        step()
+    conv.sync()
     kern = {}
     for kid, name in enumerate(KERNEL_NAMES):
         n, ms = conv.kernel_time(kid)
         if n:
-            kern[name] = {"launches": n, "avg_ms": ms / n}
+            kern[name] = {"launches_per_step": n / ksteps, "avg_ms": ms / n}
     conv.set_timing(False)
     conv.kernel_time_reset()
     PA, PT = conv.partitions(0), conv.partitions(1)
-    rows_A = -(-frames // head) + (1 if frames % head else 0)
-    # algorithmic bytes per launch of each kernel family:
-    #   FIR:  16 B per (partition, bin) pair  = read one IR bin + one delay-line bin (8 B each)
-    blocksA, blocksT = frames / head, frames / tail
+    p_head, p_t0, p_t = ref_partitions(head, tail, ir_len)
+    # Algorithmic bytes per LAUNCH of each kernel family in the block-synchronous regime (SURVEY.md 8d
+    # per-unit figures x the units one launch processes = `nch` channels x one block):
     alg = {
-        "fir_head": 16.0 * PA * (head + 1) * blocksA * nch,
-        "fir_tail": 16.0 * PT * (tail + 1) * blocksT * nch,
-        "fft_fwd_head": (4.0 * head + 8.0 * (head + 1)) * blocksA * nch,
-        "fft_inv_head": (8.0 * (head + 1) + 12.0 * head) * blocksA * nch,
-        "fft_fwd_tail": (4.0 * tail + 8.0 * (tail + 1)) * blocksT * nch,
-        "fft_inv_tail": (8.0 * (tail + 1) + 12.0 * tail) * blocksT * nch,
-        "ingest": 8.0 * frames * nch,
+        # the per-block launch does one head block of the reference's head AND tail0 sub-convolvers
+        "fused_block": float(nch * (alg_bytes_block(head, p_head) + (alg_bytes_block(head, p_t0) if p_t0 else 0))),
+        "premultiply": float(nch * 16 * PA * (head + 1)),
+        "fir_head": float(nch * 16 * PA * (head + 1)),
+        "fir_tail": float(nch * 16 * p_t * (tail + 1)),
+        "fft_fwd_head": float(nch * (4 * head + 8 * (head + 1))),
+        "fft_inv_head": float(nch * (8 * (head + 1) + 12 * head)),
+        "fft_fwd_tail": float(nch * (4 * tail + 8 * (tail + 1))),
+        "fft_inv_tail": float(nch * (8 * (tail + 1) + 12 * tail)),
+        "ingest": float(nch * 8 * host_block),
     }
-    adaptive = not args.fixed_partitions and not args.bg_stream and "fir_head" not in kern
-    if adaptive:
-        # the long-call path runs ONE delay line (P_T + 2 partitions at the tail block size) that does
-        # the work of the reference's head, tail0 and tail delay lines: it inherits all their
-        # algorithmic bytes; likewise the transforms
-        alg["fir_tail"] += alg["fir_head"]
-        alg["fft_fwd_tail"] += alg["fft_fwd_head"]
-        alg["fft_inv_tail"] += alg["fft_inv_head"]
-    dominant = max(kern, key=lambda k: kern[k]["avg_ms"]) if kern else None
+    traffic_all, tsrc = {}, None
+    tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
+    if os.path.exists(tpath) and not long_call:
+        tj = json.load(open(tpath))
+        if tj.get("channels") == nch and tj.get("config") == args.config:
+            traffic_all = {k: v["traffic_bytes"] for k, v in tj.get("kernels", {}).items()}
+            tsrc = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)"
+    roof_all = {}
+    for k, v in kern.items():
+        if long_call or k not in alg:
+            continue
+        gbs = alg[k] / (v["avg_ms"] * 1e-3) / 1e9
+        roof_all[k] = {"launches_per_step": v["launches_per_step"], "avg_launch_ms": round(v["avg_ms"], 5),
+                       "ms_per_step": round(v["avg_ms"] * v["launches_per_step"], 5),
+                       "alg_bytes_per_launch": alg[k], "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                       "traffic": traffic_all.get(k)}
     roof = None
-    if dominant:
-        ach = alg[dominant] / (kern[dominant]["avg_ms"] * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters cannot be read from inside this process:
-        # they come from the committed rocprofv3 --pmc passes of this same command
-        # (profiles/traffic.json, made by tools/pmc_summarize.py; valid for the default --frames only).
-        traffic, tsrc = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and frames == 40 * SR:
-            tj = json.load(open(tpath))
-            if dominant in tj.get("kernels", {}):
-                traffic = tj["kernels"][dominant]["traffic_bytes"]
-                tsrc = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)"
-        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "alg_bytes_per_launch": alg[dominant], "avg_launch_ms": round(kern[dominant]["avg_ms"], 5),
-                "traffic_source": tsrc,
-                "note": ROOF_NOTES["fir" if dominant.startswith("fir") else "fft"]}
-    # every timed kernel family against the HBM roofline (algorithmic numerator), for the record
-    roof_all = {k: {"avg_launch_ms": round(v["avg_ms"], 5),
-                    "achieved_GBs": round(alg[k] / (v["avg_ms"] * 1e-3) / 1e9, 1),
-                    "frac": round(alg[k] / (v["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)} for k, v in kern.items()}
-    # and the PHYSICAL rate: measured HBM bytes per launch (PMC passes, profiles/traffic.json) / launch time
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and frames == 40 * SR:
-        tk = json.load(open(tpath)).get("kernels", {})
-        for k, v in kern.items():
-            if k in tk:
-                gbs = tk[k]["traffic_bytes"] / (v["avg_ms"] * 1e-3) / 1e9
-                roof_all[k]["traffic"] = tk[k]["traffic_bytes"]
-                roof_all[k]["physical_GBs"] = round(gbs, 1)
-                roof_all[k]["physical_frac"] = round(gbs / HBM_PEAK_GBS, 4)
-    bps = alg_bytes_per_sample(head, tail, IR_LEN)
+    if roof_all:
+        dominant = max(roof_all, key=lambda k: roof_all[k]["ms_per_step"])      # largest share of a step
+        r = roof_all[dominant]
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": r["frac"], "traffic": r["traffic"], "alg_bytes_per_launch": r["alg_bytes_per_launch"],
+                "avg_launch_ms": r["avg_launch_ms"], "traffic_source": tsrc,
+                "note": "block-synchronous regime: every launch re-reads the IR spectra and the delay line of its stage once "
+                        "(16 B per partition x bin, nothing reusable across blocks that have not arrived yet), so physical "
+                        "HBM bytes ~ algorithmic bytes and frac <= 1; 8 flop per 16 B = 0.5 flop/B, far below the fp32 ridge"}
+    bps = alg_bytes_per_sample(head, tail, ir_len)
+    fps = flops_per_sample(head, tail, ir_len)
     path_gbs = value / world * 1e6 * bps / 1e9
+    path = {"alg_bytes_per_sample": round(bps, 1), "achieved_GBs_per_gpu": round(path_gbs, 1),
+            "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4),
+            "flops_per_sample": round(fps, 1), "frac_of_fp32_peak": round(value / world * 1e6 * fps / 1e12 / FP32_PEAK_TFLOPS, 4),
+            "x_realtime_per_gpu": round(value / world * 1e6 / SR, 1),
+            "note": "whole path: SURVEY.md 8d algorithmic bytes per channel-sample x measured rate (per GPU) / 8 TB/s"}
 
-    # ---- side measurement: the same call forced through the reference's partition sizes ----
-    two_stage = None
-    if adaptive and args.side:
-        fconv = reevr_amd.ConvolverSet(nch, device=local_rank, fixed_partitions=True)
-        assert fconv.init(HOST_BLOCK, 8192, list(irs), max_len=frames)
-        for _ in range(max(args.warmup, 2)):
-            fconv.process_device(d_in, d_out, sync=False, order=False)
-        fconv.sync()
-        tf = time.perf_counter()
-        for _ in range(args.steps):
-            fconv.process_device(d_in, d_out, sync=False, order=False)
-        fconv.sync()
-        tf = time.perf_counter() - tf
-        two_stage = {"value": round(nch * frames * args.steps / tf / 1e6, 3), "unit": "Msamples/s",
-                     "ms_per_step": round(tf / args.steps * 1e3, 4),
-                     "note": "RVC_FLAG_FIXED_PARTITIONS: head 512 (32 partitions) + tail 8192 (57 partitions) for the whole call"}
-        fconv.close()
-
-    # ---- streaming side measurement: one process() call per 512-frame host block --------
-    streaming = None
-    if args.stream_calls > 0:
-        nblk = args.stream_calls
-        s_in = d_in[:, :HOST_BLOCK * nblk].contiguous()
-        s_out = torch.empty_like(s_in)
-        res = {}
-        for mode, bg in (("tail_on_second_stream", True), ("tail_inline", False)):
-            sconv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bg)
-            assert sconv.init(HOST_BLOCK, 8192, list(irs), max_len=HOST_BLOCK)
-            sconv.process_device_blocks(s_in[:, :HOST_BLOCK * 200].contiguous(), HOST_BLOCK)   # warm-up
-            ts = time.perf_counter()
-            sconv.process_device_blocks(s_in, HOST_BLOCK, s_out)      # the per-block host loop, in C
-            te = time.perf_counter() - ts
-            res[mode] = {"Msamples_s": round(nch * HOST_BLOCK * nblk / te / 1e6, 3),
-                         "us_per_block": round(te / nblk * 1e6, 2)}
-            sconv.close()
-        best = max(res.values(), key=lambda r: r["Msamples_s"])
-        streaming = {"value": best["Msamples_s"], "unit": "Msamples/s", "us_per_block": best["us_per_block"],
-                     "modes": res,
-                     "note": "one process_device() call per 512-frame block (host loop in C, "
-                             "rvc_set_process_device_blocks): ONE launch per block (fused latency kernel with the "
-                             "next block's partial accumulator appended); tail job every 16 blocks on the second "
-                             "stream (RVC_FLAG_BG_STREAM, lowest per-call latency) or inline (highest rate)"}
-
-    cpu = cpu_baseline(irs, x[:, :20 * SR], args.cpu_seconds) if (world == 1 and args.cpu_seconds > 0) else None
+    side = {}
+    if args.side and args.config == 2 and world == 1:
+        conv.close()
+        del d_in, d_out
+        torch.cuda.empty_cache()
+        side = side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail)
+    cpu = None
+    if world == 1 and args.cpu_seconds > 0 and args.config == 2:
+        cores = os.cpu_count() or 1
+        n_cpu_irs = min(len(irs), max(2, cores))
+        xin = [np.ascontiguousarray(x[c % nch, :frames_step * nbuf]) for c in range(min(n_cpu_irs, nch))]
+        cpu = cpu_baseline(irs[:n_cpu_irs], xin, host_block, args.cpu_seconds)
 
     line = {
         "metric": "Msamples/s convolved (stereo, 10s IR, block=512); % HBM roofline",
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "stereo, 10 s IR @ 48 kHz, block=512 (head 512 / tail 8192), TwoStage convolver",
-                   "frames_per_step": frames, "channels_per_gpu": nch, "instances": world,
-                   "partitions": {"head+tail0": PA, "tail": PT},
-                   "call": "one process() per step, device-resident I/O", "gather": do_gather,
-                   "partitioning": "fixed head/tail" if not adaptive else
-                                   ("adaptive: long call -> one uniform delay line at block 16384 (P = %d)" % conv.partitions(2)
-                                    if conv.partitions(2) > 0 and frames >= 4 * 16384 else
-                                    "adaptive: long call -> one uniform delay line at the tail block size (P = %d)" % (PT + 2)),
-                   "sharding": "one independent stereo instance per rank (unit mod world), no data-path collective"},
+        "config": {"workload": workload, "baseline_config": args.config,
+                   "channels_per_gpu": nch, "stereo_instances_per_gpu": nch // 2, "instances_total": total_ch // 2,
+                   "frames_per_channel_per_step": frames_step, "host_block": host_block,
+                   "calls_per_step": 1 if long_call else frames_step // host_block,
+                   "partitions": {"head+tail0 (block %d)" % head: PA, "tail (block %d)" % tail: PT},
+                   "resident_GB": round(nch * 8.0 * (PA * head + (PT + 2) * tail) * 2 / 1e9, 2),
+                   "call": ("one process() per step" if long_call else
+                            "one process_device() per 512-frame host block for all channels (rvc_set_process_device_blocks), "
+                            "device-resident I/O, %d input/output batches rotated" % nbuf),
+                   "pre_roll_steps": pre, "gather": do_gather,
+                   "sharding": "instances dealt to ranks, equal shards, no data-path collective"
+                               + ("; one RCCL all_gather of the output batch per step" if do_gather else "")},
         "roofline": roof,
         "roofline_all": roof_all,
-        "path_roofline": {"alg_bytes_per_sample": round(bps, 1), "achieved_GBs_per_gpu": round(path_gbs, 1),
-                          "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4),
-                          "x_realtime_per_gpu": round(value / world * 1e6 / (SR * nch), 1)},
+        "path_roofline": path,
         "kernels_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()},
-        "two_stage": two_stage,
-        "streaming": streaming,
+        **side,
         "cpu_baseline": cpu,
-        "init_ms": round(init_ms, 2),
+        "init_ms": round(init_ms, 2), "synth_s": round(gen_s, 2),
     }
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def side_measurements(torch, reevr_amd, synth, irs2, local_rank, dev, host_block, tail):
+    """ONE stereo pair (the plug-in's own case), three ways. Not the headline."""
+    out = {}
+    # (a) block-synchronous: latency per 512-frame block
+    nblk = 3000
+    xs = torch.from_numpy(np.stack([synth.synth_input(host_block * nblk, c) for c in range(2)])).to(dev)
+    ys = torch.empty_like(xs)
+    res = {}
+    for mode, bg in (("tail_on_second_stream", True), ("tail_inline", False)):
+        s = reevr_amd.ConvolverSet(2, device=local_rank, bg_stream=bg)
+        assert s.init(host_block, tail, irs2, max_len=host_block)
+        s.process_device_blocks(xs[:, :host_block * 200].contiguous(), host_block)
+        ts = time.perf_counter()
+        s.process_device_blocks(xs, host_block, ys)
+        te = time.perf_counter() - ts
+        res[mode] = {"Msamples_s": round(2 * host_block * nblk / te / 1e6, 3), "us_per_block": round(te / nblk * 1e6, 2)}
+        s.close()
+    best = max(res.values(), key=lambda r: r["Msamples_s"])
+    out["stereo_block_sync"] = {"value": best["Msamples_s"], "unit": "Msamples/s", "us_per_block": best["us_per_block"],
+                                "modes": res, "note": "ONE stereo pair, one process_device() call per 512-frame block (host loop in C)"}
+    # (b) offline: one 40 s call per step (adaptive partitioning) and (c) the same through the fixed head/tail sizes
+    frames = 40 * SR
+    xl = torch.from_numpy(np.stack([synth.synth_input(frames, c) for c in range(2)])).to(dev)
+    yl = torch.empty_like(xl)
+    for key, fixed in (("stereo_offline_long_call", False), ("stereo_offline_fixed_partitions", True)):
+        s = reevr_amd.ConvolverSet(2, device=local_rank, fixed_partitions=fixed)
+        assert s.init(host_block, tail, irs2, max_len=frames)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.05:
+            s.process_device(xl, yl, sync=False, order=False)
+            s.sync()
+        reps = 200
+        ts = time.perf_counter()
+        for _ in range(reps):
+            s.process_device(xl, yl, sync=False, order=False)
+        s.sync()
+        te = time.perf_counter() - ts
+        out[key] = {"value": round(2 * frames * reps / te / 1e6, 1), "unit": "Msamples/s", "ms_per_call": round(te / reps * 1e3, 4),
+                    "note": ("one process() call over 40 s of stereo audio, device-resident; " +
+                             ("RVC_FLAG_FIXED_PARTITIONS: head 512 + tail 8192 for the whole call" if fixed else
+                              "adaptive partitioning: one uniform delay line at block 16384 (P = %d), head / tail stages skipped"
+                              % s.partitions(2)))}
+        s.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -163,6 +163,33 @@ def direct_convolve(x: np.ndarray, ir: np.ndarray) -> np.ndarray:
     return out
 
 
+def cpu_bench(which: str, n_threads: int, head: int, tail: int, block: int, irs, ins, seconds: float):
+    """bench.py's CPU baseline (cpu_bench.c): n_threads independent TwoStageFFTConvolver instances of
+    back-end `which` ("ref" = the untouched reference, "orc" = the restatement), one per thread,
+    `block`-frame process() calls back to back for ~`seconds`, no Python in the loop.
+    Returns (channel-samples convolved, wall seconds, per-thread samples)."""
+    b = backend(which)
+    lib = backend("orc").lib
+    lib.orc_cpu_bench.restype = C.c_double
+    lib.orc_cpu_bench.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(_F32P), C.c_int,
+                                                     C.c_size_t, C.POINTER(_F32P), C.c_int, C.c_size_t, C.c_double,
+                                                     C.POINTER(C.c_ulonglong)]
+    irs = [np.ascontiguousarray(a, np.float32) for a in irs]
+    ins = [np.ascontiguousarray(a, np.float32) for a in ins]
+    assert len({a.size for a in irs}) == 1 and len({a.size for a in ins}) == 1
+    irp = (_F32P * len(irs))(*[_fp(a) for a in irs])
+    inp = (_F32P * len(ins))(*[_fp(a) for a in ins])
+    cnt = (C.c_ulonglong * n_threads)()
+    addr = lambda name: C.cast(b.fn(name), C.c_void_p)
+    wall = lib.orc_cpu_bench(addr("twostage_create"), addr("twostage_destroy"), addr("twostage_init"),
+                             addr("twostage_process"), n_threads, head, tail, block, irp, len(irs), irs[0].size,
+                             inp, len(ins), ins[0].size, float(seconds), cnt)
+    if wall <= 0.0:
+        raise RuntimeError("orc_cpu_bench failed")
+    per = [int(v) for v in cnt]
+    return sum(per), float(wall), per
+
+
 def run_schedule(conv, x: np.ndarray, schedule) -> np.ndarray:
     """Feed x to conv.process in calls of the given sizes (sum(schedule) == len(x))."""
     out = np.empty(len(x), np.float32)

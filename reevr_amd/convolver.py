@@ -156,14 +156,17 @@ class ConvolverSet:
             self._order_torch_after(ext)
         return d_out
 
-    def process_device_blocks(self, d_in, block: int, d_out=None, sync: bool = True):
+    def process_device_blocks(self, d_in, block: int, d_out=None, sync: bool = True, order: bool = True):
         """The host's per-block loop in C: d_in (n_channels, len) is fed in consecutive calls of
-        `block` frames (strict streaming; every call takes the latency path)."""
+        `block` frames (strict streaming; every call takes the latency path). order=False: see
+        process_device."""
         import torch
         assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
+        assert d_in.shape[0] == self.n_channels
         if d_out is None:
             d_out = torch.empty_like(d_in)
-        ext = self._order_after_torch()
+        assert d_out.is_cuda and d_out.dtype == torch.float32 and d_out.shape == d_in.shape and d_out.stride(1) == 1
+        ext = self._order_after_torch() if order else None
         self._lib.rvc_set_process_device_blocks(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(),
                                                 d_out.stride(0), d_in.shape[1], block)
         if sync:
