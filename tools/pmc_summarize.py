@@ -3,11 +3,13 @@
 passes of `python bench.py`, as MI355X_MICROARCH.md section HBM prescribes) into per-launch HBM
 traffic per kernel family:
 
-    bytes = 2 * FETCH_SIZE[KiB] * 1024   (gfx950: FETCH_SIZE counts half of a streaming read --
-                                          confirmed here with a 1 GiB copy, profiles/*/calib_*)
-          + WRITE_SIZE[KiB] * 1024       (exact on the same calibration)
+    bytes = f_fetch * FETCH_SIZE[KiB] * 1024 + f_write * WRITE_SIZE[KiB] * 1024
 
-usage: pmc_summarize.py FETCH.csv WRITE.csv --head-log 9 --tail-log 13 -o profiles/rNN_traffic.json
+The correction factors come from a calibration pass over a 1 GiB device copy (tools/pmc_calib.py,
+--calib-fetch / --calib-write): on gfx950 FETCH_SIZE counts half of a streamed read (f_fetch = 2),
+WRITE_SIZE is exact (f_write = 1). Without calibration files those two values are assumed.
+
+usage: pmc_summarize.py FETCH.csv WRITE.csv [--calib-fetch C.csv --calib-write C.csv] -o out.json
 """
 import argparse
 import collections
@@ -15,15 +17,25 @@ import csv
 import json
 import re
 
+CALIB_BYTES = 4 * (1 << 28)      # tools/pmc_calib.py copies 1 GiB per dispatch: this many bytes read AND as many written
+
 
 def family(name: str, head_log: int, tail_log: int):
-    m = re.search(r"k_fir(?:_lds|_row)?<(?:\d+, )?(\d)>", name)
+    if "k_fused_block" in name or "k_block_step" in name:
+        return "fused_block"
+    m = re.search(r"k_fir_row<(\d)>", name)
+    if m:
+        return "premultiply" if m.group(1) == "0" else "fir_tail"
+    m = re.search(r"k_fdl_sweep<[^>]*?(\d)>", name)
+    if m:
+        return "fir_head" if m.group(1) == "0" else "fir_tail"
+    m = re.search(r"k_fir(?:_lds)?<(?:\d+, )?(\d)>", name)
     if m:
         return "fir_head" if m.group(1) == "0" else "fir_tail"   # <1> tail stage, <2> whole-IR line (timed as fir_tail)
     m = re.search(r"k_fft8?_(fwd|inv)<(\d+), float>", name)
     if m:
         lg = int(m.group(2))
-        st = "head" if lg == head_log else ("tail" if lg == tail_log else None)
+        st = "head" if lg == head_log else ("tail" if lg >= tail_log else None)
         return f"fft_{m.group(1)}_{st}" if st else None
     if "k_ingest" in name:
         return "ingest"
@@ -36,30 +48,51 @@ def per_family(path, head_log, tail_log):
         f = family(r["Kernel_Name"], head_log, tail_log)
         if f:
             acc[f].append(float(r["Counter_Value"]))
-    # drop the first (warm-up / cold cache) launch of each family when there are several
-    return {k: sum(v[1:]) / len(v[1:]) if len(v) > 1 else v[0] for k, v in acc.items()}
+    # steady state: the second half of the dispatches of each family (the first ones run on a delay line
+    # that is still filling: rows before time 0 are not fetched)
+    return {k: (sum(v[len(v) // 2:]) / len(v[len(v) // 2:]), len(v)) for k, v in acc.items()}
+
+
+def calib_factor(path, default):
+    if not path:
+        return default, None
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if "copyBuffer" in r["Kernel_Name"]]
+    vals = [v for v in vals if v > 1024.0]
+    if not vals:
+        return default, None
+    kib = sum(vals) / len(vals)
+    return CALIB_BYTES / (kib * 1024.0), kib
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("fetch_csv")
     ap.add_argument("write_csv")
+    ap.add_argument("--calib-fetch")
+    ap.add_argument("--calib-write")
     ap.add_argument("--head-log", type=int, default=9)
     ap.add_argument("--tail-log", type=int, default=13)
-    ap.add_argument("--command", default="python bench.py --steps 5 --warmup 2 --cpu-seconds 0 --stream-calls 0")
+    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--command", default="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --side 0")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
     fe = per_family(a.fetch_csv, a.head_log, a.tail_log)
     wr = per_family(a.write_csv, a.head_log, a.tail_log)
-    out = {"command": a.command, "unit": "bytes per launch",
-           "correction": "2*FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950 FETCH_SIZE = 1/2 of streamed bytes; calibrated)",
+    ff, fk = calib_factor(a.calib_fetch, 2.0)
+    fw, wk = calib_factor(a.calib_write, 1.0)
+    out = {"command": a.command, "channels": a.channels, "config": a.config, "unit": "bytes per launch (steady state)",
+           "correction": {"fetch_factor": round(ff, 4), "write_factor": round(fw, 4),
+                          "calibration": "1 GiB device copy (tools/pmc_calib.py): FETCH_SIZE %s KiB, WRITE_SIZE %s KiB per dispatch "
+                                         "for 1048576 KiB read + 1048576 KiB written" % (fk, wk)},
            "kernels": {}}
     for k in sorted(set(fe) | set(wr)):
-        f = 2.0 * fe.get(k, 0.0) * 1024.0
-        w = wr.get(k, 0.0) * 1024.0
-        out["kernels"][k] = {"fetch_bytes": f, "write_bytes": w, "traffic_bytes": f + w}
+        f = ff * fe.get(k, (0.0, 0))[0] * 1024.0
+        w = fw * wr.get(k, (0.0, 0))[0] * 1024.0
+        out["kernels"][k] = {"fetch_bytes": f, "write_bytes": w, "traffic_bytes": f + w,
+                             "dispatches_seen": max(fe.get(k, (0, 0))[1], wr.get(k, (0, 0))[1])}
     json.dump(out, open(a.out, "w"), indent=1)
-    print(json.dumps(out["kernels"], indent=1))
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
