@@ -12,6 +12,21 @@
 
 #include "rvc.h"
 
+#ifndef REEVR_AMD_HAVE_SVF
+// Stand-in for the one nested type of the reference's SVF (src/dsp/SVF.h:8-33) that StereoConvolver's
+// public surface names; define REEVR_AMD_HAVE_SVF when the real class is in scope.
+class SVF {
+ public:
+  enum Mode { LP, BP, HP, LS, HS, PK, BS, HP6, LP6, Off };
+  struct EQBand {
+    Mode mode;
+    float freq;
+    float q;
+    float gain;
+  };
+};
+#endif
+
 #ifndef REEVR_AMD_HAVE_IMPULSE
 // Minimal stand-in for the fields of the reference's Impulse (src/dsp/Impulse.h) that
 // loadImpulse reads; define REEVR_AMD_HAVE_IMPULSE when the real class is in scope.
@@ -117,6 +132,7 @@ class StereoConvolver {
   std::vector<float> bufferRL = {};
   int size = 0;
   bool isQuad = false;
+  std::vector<SVF::EQBand> decayEQ;   // StereoConvolver.h:33 -- carried for the caller (PluginProcessor.cpp:631), unused here
 
  protected:
   size_t headBlockSize = 0;

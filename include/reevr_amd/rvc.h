@@ -249,11 +249,33 @@ typedef struct rvc_wet_params {
   long long xfadelen;      /* its start value, ceil(srate * CONV_XFADE / 1000), src/Globals.h:7 */
   const float *yrev;       /* reverb envelope per sample, NULL = 1 */
   float width, drygain, wetgain;
-  const float *dry[2];     /* dry signal L, R; both NULL = wet only */
+  const float *dry[2];     /* dry signal L, R; both NULL = stop after the width stage (:1840-1857): out = the
+                            * wet bus as wetBuffer holds it there, neither drygain nor wetgain applied */
   float *out[2];
   size_t n;
 } rvc_wet_params;
 int rvc_wet_mix_device(int device, void *stream, const rvc_wet_params *p);
+
+/* The send pre-stage in front of the convolvers, for blocks that stay on the
+ * device: send envelope multiply (src/PluginProcessor.cpp:1640-1653), warm-up ring write (:1655-1668),
+ * pre-delay ring write and delayed read (:1766-1790), one pass. The IIR send filters (irLowcut /
+ * irHighcut, :1643-1650) are serial recurrences and stay on the host: a caller that has them enabled
+ * applies envelope + filters itself and passes the result as `in` with ysend = NULL.
+ * All pointers are DEVICE pointers. The caller owns the ring positions and advances them after the call:
+ * delaypos = (delaypos + n) % delay_size, warmwritepos = (warmwritepos + n) % warm_size. Requires
+ * 0 <= delaypos < delay_size, 0 <= predelay, 0 <= warmwritepos < warm_size. Asynchronous on `stream`. 1 = enqueued. */
+typedef struct rvc_send_params {
+  const float *in[2];      /* input L, R, n floats */
+  const float *ysend;      /* send envelope per sample (ysendBuffer), NULL = 1 */
+  float *send[2];          /* out: sendBuffer L, R (feeds the fading-in convolver), both NULL = not wanted */
+  float *delay_ring[2];    /* delayBuffer L, R, delay_size floats each, updated in place */
+  long long delay_size, delaypos, predelay;
+  float *delayed[2];       /* out: delayedBuffer L, R -- what convolver->process reads (:1793-1797) */
+  float *warm_ring[2];     /* warmer L, R, warm_size floats each, updated in place; both NULL = none */
+  long long warm_size, warmwritepos;
+  size_t n;
+} rvc_send_params;
+int rvc_send_pre_device(int device, void *stream, const rvc_send_params *p);
 
 /* ---- library ----------------------------------------------------------------------- */
 

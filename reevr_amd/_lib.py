@@ -73,6 +73,7 @@ SIGNATURES = {
     "rvc_impulse_last_error_string": (C.c_char_p, [C.c_void_p]),
     "rvc_set_init_impulse": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(C.c_int), C.c_size_t]),
     "rvc_wet_mix_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "rvc_send_pre_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "rvc_device_count": (C.c_int, []),
     "rvc_version": (C.c_char_p, []),
 }
@@ -91,6 +92,13 @@ class WetParams(C.Structure):           # struct rvc_wet_params
     _fields_ = [("cur", C.c_void_p * 4), ("load", C.c_void_p * 2), ("xfade", C.c_longlong), ("xfadelen", C.c_longlong),
                 ("yrev", C.c_void_p), ("width", C.c_float), ("drygain", C.c_float), ("wetgain", C.c_float),
                 ("dry", C.c_void_p * 2), ("out", C.c_void_p * 2), ("n", C.c_size_t)]
+
+
+class SendParams(C.Structure):          # struct rvc_send_params
+    _fields_ = [("in_", C.c_void_p * 2), ("ysend", C.c_void_p), ("send", C.c_void_p * 2), ("delay_ring", C.c_void_p * 2),
+                ("delay_size", C.c_longlong), ("delaypos", C.c_longlong), ("predelay", C.c_longlong),
+                ("delayed", C.c_void_p * 2), ("warm_ring", C.c_void_p * 2), ("warm_size", C.c_longlong),
+                ("warmwritepos", C.c_longlong), ("n", C.c_size_t)]
 
 
 _lib = None

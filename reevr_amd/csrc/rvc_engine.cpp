@@ -31,7 +31,6 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
-#include <deque>
 #include <string>
 #include <vector>
 
@@ -118,9 +117,16 @@ struct rvc_set {
   hipStream_t st_main = nullptr, st_bg = nullptr;
   bool streams_ok = false;
   hipEvent_t ev_ingest = nullptr;
+  // Tail jobs enqueued on st_bg, oldest first. Fixed capacity and a pre-created event pool: nothing on the
+  // process() / clear() path allocates (the reference's real-time rule, FFTConvolver.h:44-47).
   struct Job { long long m_hi; hipEvent_t ev; };
-  std::deque<Job> jobs;          // tail jobs enqueued on st_bg, oldest first
-  std::vector<hipEvent_t> ev_pool;
+  static constexpr int kMaxJobs = 32;
+  Job jobs[kMaxJobs];
+  int job_head = 0, job_count = 0;
+  hipEvent_t ev_pool[kMaxJobs];
+  int ev_free = 0;
+  std::vector<const float *> in_ptrs;    // scratch of rvc_set_process (sized at create)
+  std::vector<float *> out_ptrs;
 
   size_t pending_len = 0;        // rvc_set_process_begin without its _end yet
   bool pending_ok = false;
@@ -129,7 +135,9 @@ struct rvc_set {
   hipEvent_t ev_out = nullptr;   // kernel is enqueued (before the off-critical-path work) and mark it here
 
   bool timing = false;
-  std::vector<TimedLaunch> timed[kNumKernelIds];
+  std::vector<TimedLaunch> timed[kNumKernelIds];   // event pairs not yet read (folded into the totals every 1024 launches)
+  double timed_ms[kNumKernelIds] = {};
+  long timed_n[kNumKernelIds] = {};
 };
 
 namespace {
@@ -168,6 +176,8 @@ bool ensure_streams(rvc_set *s) {
   RVC_CK(hipStreamCreateWithFlags(&s->st_bg, hipStreamNonBlocking));
   RVC_CK(hipEventCreateWithFlags(&s->ev_ingest, hipEventDisableTiming));
   RVC_CK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
+  for (s->ev_free = 0; s->ev_free < rvc_set::kMaxJobs; ++s->ev_free)
+    RVC_CK(hipEventCreateWithFlags(&s->ev_pool[s->ev_free], hipEventDisableTiming));
   s->streams_ok = true;
   return true;
 }
@@ -178,10 +188,33 @@ void free_stage(Stage &g) {
   g = Stage();
 }
 
+void drop_jobs(rvc_set *s) {   // return the events of all queued tail jobs to the pool
+  for (; s->job_count > 0; --s->job_count) {
+    s->ev_pool[s->ev_free++] = s->jobs[s->job_head].ev;
+    s->job_head = (s->job_head + 1) % rvc_set::kMaxJobs;
+  }
+  s->job_head = 0;
+}
+
+// read the pending event pairs of one kernel family into its running totals and release the events
+void fold_timing(rvc_set *s, int id) {
+  auto &v = s->timed[id];
+  if (v.empty()) return;
+  hipEventSynchronize(v.back().b);
+  for (auto &t : v) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { s->timed_ms[id] += ms; ++s->timed_n[id]; }
+    hipEventDestroy(t.a); hipEventDestroy(t.b);
+  }
+  v.clear();
+}
+
 void drop_timing(rvc_set *s) {
-  for (auto &v : s->timed) {
-    for (auto &t : v) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
-    v.clear();
+  for (int id = 0; id < kNumKernelIds; ++id) {
+    for (auto &t : s->timed[id]) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    s->timed[id].clear();
+    s->timed_ms[id] = 0.0;
+    s->timed_n[id] = 0;
   }
 }
 
@@ -191,8 +224,7 @@ void free_device_state(rvc_set *s) {
     hipStreamSynchronize(s->st_bg);
     hipStreamSynchronize(s->st_main);
   }
-  for (auto &j : s->jobs) s->ev_pool.push_back(j.ev);
-  s->jobs.clear();
+  drop_jobs(s);
   drop_timing(s);
   free_stage(s->A);
   free_stage(s->T);
@@ -383,8 +415,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     if (!use_device(s)) return false;
     hipStreamSynchronize(s->st_bg);
     hipStreamSynchronize(s->st_main);
-    for (auto &j : s->jobs) s->ev_pool.push_back(j.ev);
-    s->jobs.clear();
+    drop_jobs(s);
     if (!upload_ir_stage(s, s->A, irs, lenA, on_device)) { free_device_state(s); return false; }
     if (pf > 0 && !upload_ir_stage(s, s->T, irs, len, on_device)) { free_device_state(s); return false; }
     if (pw > 0 && !upload_ir_stage(s, s->W, irs, len, on_device)) { free_device_state(s); return false; }
@@ -461,15 +492,22 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   return true;
 }
 
-hipEvent_t get_event(rvc_set *s) {
-  if (!s->ev_pool.empty()) {
-    hipEvent_t e = s->ev_pool.back();
-    s->ev_pool.pop_back();
-    return e;
+// Queue a tail job's completion event. The queue holds at most kMaxJobs entries; a caller that never
+// reads the tail blocks it produced (kMaxJobs tail periods without a wait) makes the oldest job's event
+// be waited for here, which frees its slot.
+bool push_job(rvc_set *s, long long m_hi, hipStream_t st) {
+  if (s->job_count == rvc_set::kMaxJobs) {
+    rvc_set::Job &o = s->jobs[s->job_head];
+    RVC_CK(hipStreamWaitEvent(s->st_main, o.ev, 0));
+    s->ev_pool[s->ev_free++] = o.ev;
+    s->job_head = (s->job_head + 1) % rvc_set::kMaxJobs;
+    --s->job_count;
   }
-  hipEvent_t e = nullptr;
-  hipEventCreateWithFlags(&e, hipEventDisableTiming);
-  return e;
+  rvc_set::Job j{m_hi, s->ev_pool[--s->ev_free]};
+  RVC_CK(hipEventRecord(j.ev, st));
+  s->jobs[(s->job_head + s->job_count) % rvc_set::kMaxJobs] = j;
+  ++s->job_count;
+  return true;
 }
 
 struct Timer {   // brackets one launch with events when timing is on
@@ -478,7 +516,10 @@ struct Timer {   // brackets one launch with events when timing is on
     if (on) { hipEventCreate(&t.a); hipEventCreate(&t.b); rvc::set_launch_events(t.a, t.b); }
   }
   ~Timer() {
-    if (on) { rvc::set_launch_events(nullptr, nullptr); s->timed[id].push_back(t); }
+    if (!on) return;
+    rvc::set_launch_events(nullptr, nullptr);
+    s->timed[id].push_back(t);
+    if (s->timed[id].size() >= 1024) fold_timing(s, id);   // bounded: streaming use with RVC_FLAG_TIMING does not grow
   }
 };
 
@@ -566,11 +607,7 @@ bool run_tail_job(rvc_set *s, long long n0, long long n1, const float *src2, siz
   }
   if (!tail_spectra(s, n0, n1, src2, in_stride, st)) return false;
   if (!tail_rows(s, mb1 + 2, st)) return false;
-  if (bg) {
-    rvc_set::Job j{mb1 + 2, get_event(s)};
-    RVC_CK(hipEventRecord(j.ev, st));
-    s->jobs.push_back(j);
-  }
+  if (bg && !push_job(s, mb1 + 2, st)) return false;
   return true;
 }
 
@@ -578,11 +615,12 @@ bool run_tail_job(rvc_set *s, long long n0, long long n1, const float *src2, siz
 // tail blocks a call ending at n1 reads
 bool wait_tail_jobs(rvc_set *s, long long n1) {
   const long long m_need = (n1 - 1) / (long long)s->T.B;
-  while (!s->jobs.empty() && m_need >= 2) {
-    rvc_set::Job j = s->jobs.front();
+  while (s->job_count > 0 && m_need >= 2) {
+    const rvc_set::Job j = s->jobs[s->job_head];
     RVC_CK(hipStreamWaitEvent(s->st_main, j.ev, 0));   // jobs are ordered: all up to the first one covering m_need
-    s->jobs.pop_front();
-    s->ev_pool.push_back(j.ev);
+    s->job_head = (s->job_head + 1) % rvc_set::kMaxJobs;
+    --s->job_count;
+    s->ev_pool[s->ev_free++] = j.ev;
     if (j.m_hi > m_need) break;
   }
   return true;
@@ -937,6 +975,16 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   return true;
 }
 
+// A failed init must not keep the stages it had already allocated (the sticky error stays readable)
+void release_after_failed_init(rvc_set *s) {
+  if (!s->streams_ok && !s->live) return;
+  const int err = s->err;
+  const std::string msg = s->errstr;
+  free_device_state(s);
+  s->err = err;
+  s->errstr = msg;
+}
+
 bool zero_device_out(rvc_set *s, float *d_out, size_t out_stride, size_t len) {
   if (len == 0 || !d_out) return true;
   if (s->streams_ok) {
@@ -962,6 +1010,8 @@ rvc_set *rvc_set_create(int n_channels, int device, unsigned flags) {
   s->device = device;
   s->flags = flags;
   s->timing = (flags & RVC_FLAG_TIMING) != 0;
+  s->in_ptrs.assign((size_t)n_channels, nullptr);
+  s->out_ptrs.assign((size_t)n_channels, nullptr);
   return s;
 }
 
@@ -969,7 +1019,7 @@ void rvc_set_destroy(rvc_set *s) {
   if (!s) return;
   free_device_state(s);
   if (s->streams_ok) {
-    for (auto e : s->ev_pool) hipEventDestroy(e);
+    for (int i = 0; i < s->ev_free; ++i) hipEventDestroy(s->ev_pool[i]);
     hipEventDestroy(s->ev_ingest);
     hipEventDestroy(s->ev_out);
     hipStreamDestroy(s->st_bg);
@@ -982,7 +1032,7 @@ int rvc_set_init(rvc_set *s, size_t head_block, size_t tail_block, const float *
                  const size_t *ir_lens, size_t max_len) {
   if (!s) return 0;
   const bool ok = do_init(s, head_block, tail_block, true, irs, ir_lens, max_len);
-  if (!ok && s->live) free_device_state(s);
+  if (!ok) release_after_failed_init(s);
   return ok ? 1 : 0;
 }
 
@@ -990,7 +1040,7 @@ int rvc_set_init_uniform(rvc_set *s, size_t block, const float *const *irs, cons
                          size_t max_len) {
   if (!s) return 0;
   const bool ok = do_init(s, block, 0, false, irs, ir_lens, max_len);
-  if (!ok && s->live) free_device_state(s);
+  if (!ok) release_after_failed_init(s);
   return ok ? 1 : 0;
 }
 
@@ -1016,7 +1066,7 @@ int rvc_set_init_impulse(rvc_set *s, size_t head_block, size_t tail_block, rvc_i
     lens[c] = v.trimmed[k];
   }
   const bool ok = do_init(s, head_block, tail_block, true, irs.data(), lens.data(), max_len, /*on_device=*/true);
-  if (!ok && s->live) free_device_state(s);
+  if (!ok) release_after_failed_init(s);
   return ok ? 1 : 0;
 }
 
@@ -1052,7 +1102,8 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   s->pending_ok = false;
   s->flag_count = 0;
   if (len == 0 || !s->live || s->err != RVC_OK || !in) return;
-  if (len > s->max_len) { fail(s, RVC_ERR_BAD_ARG, hipSuccess, "process_begin: len > max_len"); return; }
+  if (len > s->max_len) return;   // refused: process_end writes zeros for this call; the handle stays usable
+                                  // (rvc_set_process splits long calls itself)
   if (!use_device(s)) return;
   for (int c = 0; c < s->nch; ++c) std::memcpy(s->h_in + (size_t)c * len, in[c], len * sizeof(float));
   // Per-block calls (the latency path: one fused launch) skip both DMA copies: the pinned staging
@@ -1114,8 +1165,8 @@ void rvc_set_process_end(rvc_set *s, float *const *out) {
 void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size_t len) {
   if (!s || len == 0 || !out) return;
   size_t done = 0;
-  std::vector<const float *> ins(s->nch);
-  std::vector<float *> outs(s->nch);
+  std::vector<const float *> &ins = s->in_ptrs;      // sized at create: no allocation here (FFTConvolver.h:44-47)
+  std::vector<float *> &outs = s->out_ptrs;
   while (done < len) {   // calls longer than max_len are split; results are call-pattern independent
     const size_t chunk = std::min(len - done, s->max_len ? s->max_len : len);
     for (int c = 0; c < s->nch; ++c) {
@@ -1134,8 +1185,7 @@ void rvc_set_clear(rvc_set *s) {
   hipSetDevice(s->device);
   hipStreamSynchronize(s->st_bg);
   hipStreamSynchronize(s->st_main);
-  for (auto &j : s->jobs) s->ev_pool.push_back(j.ev);
-  s->jobs.clear();
+  drop_jobs(s);
   s->n = 0;
   s->tail_fft_done = 0;
   s->tail_out_done = 2;
@@ -1180,13 +1230,9 @@ long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms) {
   if (total_ms) *total_ms = 0.0;
   if (!s || kernel < 0 || kernel >= kNumKernelIds) return 0;
   rvc_set_sync(s);
-  double tot = 0.0;
-  for (auto &t : s->timed[kernel]) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) tot += ms;
-  }
-  if (total_ms) *total_ms = tot;
-  return (long)s->timed[kernel].size();
+  fold_timing(s, kernel);
+  if (total_ms) *total_ms = s->timed_ms[kernel];
+  return s->timed_n[kernel];
 }
 
 void rvc_set_kernel_time_reset(rvc_set *s) {

@@ -637,3 +637,77 @@ extern "C" int rvc_wet_mix_device(int device, void *stream, const rvc_wet_params
   hipLaunchKernelGGL(rvc::k_wet_mix, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return hipGetLastError() == hipSuccess ? 1 : 0;
 }
+
+// ================================================================================================
+// Send pre-stage on the device: what processBlock does in FRONT of the
+// convolvers for blocks that stay in HBM -- send envelope (src/PluginProcessor.cpp:1640-1653, without
+// the serial IIR send filters :1643-1650, which stay with the host), the warm-up ring write (:1655-1668)
+// and the pre-delay ring write + read (:1766-1790). One pass; the reference's "write the whole block,
+// then read it back predelay samples late" becomes: a sample whose read position was written by this
+// very block is taken from the block itself, every other one from the ring as it was.
+// ================================================================================================
+namespace rvc {
+
+struct SendArgs {
+  const float *in[2];
+  const float *ysend;
+  float *send[2];
+  float *delay_ring[2];
+  long long delay_size, delaypos, predelay;
+  float *delayed[2];
+  float *warm_ring[2];
+  long long warm_size, warmwritepos;
+  long long n;
+};
+
+__global__ void __launch_bounds__(256) k_send_pre(const SendArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  if (i >= a.n) return;
+  const float *in = a.in[c];
+  auto send_at = [&](long long j) -> float { return a.ysend ? in[j] * a.ysend[j] : in[j]; };   // :1641-1642
+  const float s = send_at(i);
+  if (a.send[c]) a.send[c][i] = s;
+  // rings: sample i lands on slot (pos + i) % size; when the block is longer than the ring the LAST writer wins
+  if (a.warm_ring[c] && i + a.warm_size >= a.n) a.warm_ring[c][(a.warmwritepos + i) % a.warm_size] = s;
+  if (a.delay_ring[c] && i + a.delay_size >= a.n) a.delay_ring[c][(a.delaypos + i) % a.delay_size] = s;
+  if (a.delayed[c]) {
+    // read position (delaypos + size - predelay + i) % size = the slot block sample j = i - predelay (mod size)
+    // was written to, if that sample exists in this block (the last such j, as above)
+    long long j = (i - a.predelay) % a.delay_size;
+    if (j < 0) j += a.delay_size;
+    float v;
+    if (j < a.n) {
+      j += ((a.n - 1 - j) / a.delay_size) * a.delay_size;
+      v = send_at(j);
+    } else {
+      v = a.delay_ring[c][(a.delaypos + a.delay_size - a.predelay % a.delay_size + i) % a.delay_size];
+    }
+    a.delayed[c][i] = v;
+  }
+}
+
+}  // namespace rvc
+
+extern "C" int rvc_send_pre_device(int device, void *stream, const rvc_send_params *p) {
+  if (!p || !p->in[0] || !p->in[1]) return 0;
+  if ((p->send[0] == nullptr) != (p->send[1] == nullptr)) return 0;
+  if ((p->delayed[0] == nullptr) != (p->delayed[1] == nullptr)) return 0;
+  if ((p->delay_ring[0] == nullptr) != (p->delay_ring[1] == nullptr)) return 0;
+  if ((p->warm_ring[0] == nullptr) != (p->warm_ring[1] == nullptr)) return 0;
+  if (p->delayed[0] && (!p->delay_ring[0] || p->delay_size <= 0 || p->predelay < 0 || p->delaypos < 0)) return 0;
+  if (p->delay_ring[0] && (p->delay_size <= 0 || p->delaypos < 0 || p->delaypos >= p->delay_size)) return 0;
+  if (p->warm_ring[0] && (p->warm_size <= 0 || p->warmwritepos < 0 || p->warmwritepos >= p->warm_size)) return 0;
+  if (p->n == 0) return 1;
+  if (hipSetDevice(device < 0 ? 0 : device) != hipSuccess) return 0;
+  rvc::SendArgs a{};
+  for (int c = 0; c < 2; ++c) {
+    a.in[c] = p->in[c]; a.send[c] = p->send[c]; a.delay_ring[c] = p->delay_ring[c];
+    a.delayed[c] = p->delayed[c]; a.warm_ring[c] = p->warm_ring[c];
+  }
+  a.ysend = p->ysend;
+  a.delay_size = p->delay_size; a.delaypos = p->delaypos; a.predelay = p->predelay;
+  a.warm_size = p->warm_size; a.warmwritepos = p->warmwritepos; a.n = (long long)p->n;
+  hipLaunchKernelGGL(rvc::k_send_pre, dim3((unsigned)((p->n + 255) / 256), 2), dim3(256), 0, (hipStream_t)stream, a);
+  return hipGetLastError() == hipSuccess ? 1 : 0;
+}

@@ -28,6 +28,15 @@
 #include "rvc_internal.h"
 #include "rvc_fft_lds.hpp"
 
+// The RVC_ABLATE_* / RVC_PHASE_TIMES measurement switches only exist in development builds
+// (-DRVC_DEV_BUILD, tools/abl_build.py): the shipped library cannot be built with one of them active.
+#if !defined(RVC_DEV_BUILD) && (defined(RVC_PHASE_TIMES) || defined(RVC_ABLATE_NOTW) || defined(RVC_ABLATE_NOBARRIER) || \
+    defined(RVC_ABLATE_CORE_NOLDS) || defined(RVC_ABLATE_FWD_STOP) || defined(RVC_ABLATE_FFT_NOLOAD) ||                   \
+    defined(RVC_ABLATE_FFT_NOCORE) || defined(RVC_ABLATE_FFT_NOSTORE) || defined(RVC_ABLATE_NOLOAD) ||                     \
+    defined(RVC_ABLATE_NOLDSREAD) || defined(RVC_ABLATE_NOSTORE))
+#error "measurement switches (RVC_ABLATE_*, RVC_PHASE_TIMES) need -DRVC_DEV_BUILD: they produce wrong results by design"
+#endif
+
 #ifdef RVC_PHASE_TIMES
 // Development instrumentation (tools/phase_times.py): thread 0 of a few workgroups stamps the shader clock
 // at phase boundaries of the big kernels. Waits are forced at the stamps, so the kernel is slower with it.

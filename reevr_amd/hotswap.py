@@ -145,15 +145,18 @@ def wet_bus(wet, yrev, width: float, drygain: float, wetgain: float, dry):
 
 
 def wet_mix_device(cur, load=None, xfade: int = 0, xfadelen: int = 1, yrev=None, width: float = 1.0,
-                   drygain: float = 1.0, wetgain: float = 1.0, dry=None, out=None, stream: int = 0, device: int = 0):
+                   drygain: float = 1.0, wetgain: float = 1.0, dry=None, out=None, stream=None, device: int = 0):
     """The same epilogue on the DEVICE for blocks that never leave it (rvc_wet_mix_device; kernel
     k_wet_mix): crossfade (per-sample alpha) + true-stereo sum + envelope + width + dry/wet in one pass.
     cur: 2 (LL, RR) or 4 (LL, RR, LR, RL) torch CUDA float32 vectors of the current convolver;
     load: (LL, RR) of the fading-in convolver while a crossfade runs (xfade = countdown at sample 0);
-    dry: (L, R) or None for wet only. Returns the two output tensors. Asynchronous on `stream`
-    (a raw hipStream_t, 0 = null stream)."""
+    dry: (L, R), or None to stop after the width stage (the wet bus itself: no gains applied). Returns the two
+    output tensors. Asynchronous on `stream` (a raw hipStream_t; default: torch's CURRENT stream on `device`,
+    the one _Pair.run has ordered behind the convolvers' streams)."""
     import torch
     from . import _lib as L
+    if stream is None:
+        stream = torch.cuda.current_stream(device).cuda_stream
     n = cur[0].numel()
     out = out or (torch.empty_like(cur[0]), torch.empty_like(cur[0]))
     p = L.WetParams()
@@ -171,6 +174,40 @@ def wet_mix_device(cur, load=None, xfade: int = 0, xfadelen: int = 1, yrev=None,
     if not L.lib().rvc_wet_mix_device(device, stream, C.byref(p)):
         raise RuntimeError("rvc_wet_mix_device failed")
     return out
+
+
+def send_pre_device(inp, ysend=None, delay_ring=None, delaypos: int = 0, predelay: int = 0, warm_ring=None,
+                    warmwritepos: int = 0, want_send: bool = True, stream=None, device: int = 0):
+    """The send pre-stage on the DEVICE (rvc_send_pre_device; kernel k_send_pre): send envelope multiply
+    (src/PluginProcessor.cpp:1640-1653, IIR send filters excluded), warm-up ring write (:1655-1668), pre-delay
+    ring write + delayed read (:1766-1790). inp: (2, n) torch CUDA float32; delay_ring / warm_ring: (2, size)
+    tensors updated in place. Returns (send, delayed) as (2, n) tensors (None where not requested); the caller
+    advances delaypos / warmwritepos by n modulo the ring sizes."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    if stream is None:
+        stream = torch.cuda.current_stream(device).cuda_stream
+    n = inp.shape[1]
+    assert inp.is_cuda and inp.dtype == torch.float32 and inp.shape[0] == 2 and inp.stride(1) == 1
+    send = torch.empty((2, n), device=inp.device) if want_send else None
+    delayed = torch.empty((2, n), device=inp.device) if delay_ring is not None else None
+    p = L.SendParams()
+    for c in range(2):
+        p.in_[c] = inp[c].data_ptr()
+        p.send[c] = send[c].data_ptr() if send is not None else None
+        p.delay_ring[c] = delay_ring[c].data_ptr() if delay_ring is not None else None
+        p.delayed[c] = delayed[c].data_ptr() if delayed is not None else None
+        p.warm_ring[c] = warm_ring[c].data_ptr() if warm_ring is not None else None
+    p.ysend = ysend.data_ptr() if ysend is not None else None
+    p.delay_size = delay_ring.shape[1] if delay_ring is not None else 0
+    p.delaypos, p.predelay = int(delaypos), int(predelay)
+    p.warm_size = warm_ring.shape[1] if warm_ring is not None else 0
+    p.warmwritepos = int(warmwritepos)
+    p.n = n
+    if not L.lib().rvc_send_pre_device(device, stream, C.byref(p)):
+        raise RuntimeError("rvc_send_pre_device failed")
+    return send, delayed
 
 
 class DeviceHotSwap:
@@ -230,6 +267,8 @@ class DeviceHotSwap:
         self.W = int(math.ceil(sampleRate)) // 4                     # 0.25 s warm-up ring, :610
         self.warmer = torch.zeros(2, self.W, device=f"cuda:{self.device}")
         self.warmwritepos = 0
+        self.delay_ring = torch.zeros(2, int(2.0 * sampleRate), device=f"cuda:{self.device}")   # delayBuffer, :640
+        self.delaypos = 0
         self.max_len = max(self.size, (self.W // self.size) * self.size)
 
     def loadImpulse(self, imp):
@@ -255,16 +294,28 @@ class DeviceHotSwap:
             self._worker.join()
             self._worker = None
 
+    def process_input(self, inp, ysend=None, predelay: int = 0, **kw):
+        """The whole convolver section from the plug-in's INPUT block (2, n), all on the device: send pre-stage
+        (rvc_send_pre_device: envelope, warm-up ring, pre-delay ring; src/PluginProcessor.cpp:1640-1668,
+        1766-1790) and then process(). The dry signal of the mix defaults to the input itself."""
+        n = inp.shape[1]
+        send, delayed = send_pre_device(inp, ysend, self.delay_ring, self.delaypos, predelay, self.warmer,
+                                        self.warmwritepos, device=self.device)
+        self.delaypos = (self.delaypos + n) % self.delay_ring.shape[1]
+        self.warmwritepos = (self.warmwritepos + n) % self.W
+        kw.setdefault("dry", (inp[0], inp[1]))
+        return self.process(send, delayed, _warm_written=True, **kw)
+
     def process(self, send, delayed, yrev=None, width: float = 1.0, drygain: float = 0.0, wetgain: float = 1.0,
-                dry=None, tsenabled: bool = True):
+                dry=None, tsenabled: bool = True, _warm_written: bool = False):
         """send / delayed: (2, n) device tensors (send feeds the warm-up ring and the fading-in
         convolver, delayed the current one). Returns (outL, outR) device tensors."""
         import torch
         n = send.shape[1]
-        # warm-up ring write (:1655-1668)
-        idx = (self.warmwritepos + torch.arange(n, device=send.device)) % self.W
-        self.warmer[:, idx] = send
-        self.warmwritepos = (self.warmwritepos + n) % self.W
+        if not _warm_written:                                        # warm-up ring write (:1655-1668)
+            idx = (self.warmwritepos + torch.arange(n, device=send.device)) % self.W
+            self.warmer[:, idx] = send
+            self.warmwritepos = (self.warmwritepos + n) % self.W
         if self.loadState == K_READY:                                # warm-up replay, :1695-1755
             numBlocks = self.W // self.size
             start = (self.warmwritepos + 1) % self.W

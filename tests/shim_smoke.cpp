@@ -26,6 +26,7 @@ int main() {
     (void)c.isFinished();
     StereoConvolver sc;
     sc.prepare(128);
+    sc.decayEQ.push_back(SVF::EQBand{SVF::PK, 1000.f, 0.707f, -3.f});   // StereoConvolver.h:33 member exists
     Impulse imp;
     imp.bufferLL = ir; imp.bufferRR = ir;
     sc.loadImpulse(imp);

@@ -206,7 +206,8 @@ def test_wet_mix_device_matches_host_epilogue(quad, fading, with_dry):
     """rvc_wet_mix_device (crossfade + true-stereo sum + envelope + width + dry/wet on the device, SURVEY 8f
     f-2 / f-3) against the host-side restatement of src/PluginProcessor.cpp:1800-1876 -- bit for bit."""
     import torch
-    from reevr_amd.hotswap import wet_bus, wet_mix_device
+    from reevr_amd.hotswap import wet_mix_device
+    from tests.ref_wetbus import ref_wet_bus as wet_bus     # oracle-side restatement of PluginProcessor.cpp:1840-1876
     rng = np.random.RandomState(11)
     n = 5000
     cur = [rng.randn(n).astype(np.float32) for _ in range(4 if quad else 2)]
@@ -233,7 +234,7 @@ def test_wet_mix_device_matches_host_epilogue(quad, fading, with_dry):
     if with_dry:
         want = wet_bus(wet, yrev, width, dg, wg, np.stack(dry))
     else:
-        want = wet_bus(wet, yrev, width, 0.0, 1.0, np.zeros((2, n), np.float32))
+        want = wet_bus(wet, yrev, width, 0.0, 1.0, None)                 # stop after the width stage
     dev = lambda a: torch.from_numpy(a).cuda()
     got = wet_mix_device([dev(x) for x in cur], load=[dev(x) for x in load] if fading else None, xfade=xfade,
                          xfadelen=xfadelen, yrev=dev(yrev), width=float(width), drygain=float(dg) if with_dry else 1.0,
@@ -243,7 +244,7 @@ def test_wet_mix_device_matches_host_epilogue(quad, fading, with_dry):
         g = got[ch].cpu().numpy()
         if with_dry:
             assert np.array_equal(g, want[ch])
-        else:   # wet only: the host helper multiplies by wetgain 1 and adds 0 * dry -- same values
+        else:   # dry = NULL: the wet bus after the width stage, no gains
             assert np.array_equal(g, want[ch])
 
 
@@ -264,7 +265,8 @@ def test_device_hot_swap_pipeline(quad):
     import torch
     import reevr_amd
     from reevr_amd import synth
-    from reevr_amd.hotswap import DeviceHotSwap, HotSwapStereoConvolver, wet_bus
+    from reevr_amd.hotswap import DeviceHotSwap, HotSwapStereoConvolver
+    from tests.ref_wetbus import ref_wet_bus as wet_bus
 
     class Imp:
         pass
@@ -312,3 +314,74 @@ def test_device_hot_swap_pipeline(quad):
         err = np.sqrt(np.mean((got[c, keep].astype(np.float64) - want[c, keep]) ** 2))
         ref = np.sqrt(np.mean(want[c, keep].astype(np.float64) ** 2))
         assert err / ref <= 1e-5, (c, err / ref)
+
+
+@pytest.mark.parametrize("predelay,nblk", [(0, 480), (100, 480), (3000, 512), (47999, 480), (5, 70000)])
+def test_send_pre_device_matches_reference_loops(predelay, nblk):
+    """rvc_send_pre_device (send envelope + warm-up ring + pre-delay ring on the device) against the
+    oracle-side restatement of src/PluginProcessor.cpp:1640-1668, 1766-1790 (tests/ref_wetbus.py) -- bit for bit,
+    over several blocks so that both rings wrap; the last case is a block longer than the warm-up ring."""
+    import torch
+    from reevr_amd.hotswap import send_pre_device
+    from tests.ref_wetbus import RefSendPre
+    rng = np.random.RandomState(5)
+    dsize, wsize = 48000, 12000
+    ref = RefSendPre(dsize, wsize)
+    dring = torch.zeros(2, dsize, device="cuda")
+    wring = torch.zeros(2, wsize, device="cuda")
+    dpos = wpos = 0
+    for b in range(4 if nblk > 10000 else 120):
+        x = rng.randn(2, nblk).astype(np.float32)
+        ys = rng.rand(nblk).astype(np.float32)
+        ws, wd = ref.process(x[0], x[1], ys, predelay)
+        send, delayed = send_pre_device(torch.from_numpy(x).cuda(), torch.from_numpy(ys).cuda(), dring, dpos, predelay,
+                                        wring, wpos)
+        dpos = (dpos + nblk) % dsize
+        wpos = (wpos + nblk) % wsize
+        torch.cuda.synchronize()
+        assert np.array_equal(send.cpu().numpy(), ws), b
+        assert np.array_equal(delayed.cpu().numpy(), wd), b
+    assert np.array_equal(dring.cpu().numpy(), ref.delayBuffer)
+    assert np.array_equal(wring.cpu().numpy(), ref.warmer)
+    assert dpos == ref.delaypos and wpos == ref.warmwritepos
+
+
+def test_device_pipeline_from_plugin_input():
+    """DeviceHotSwap.process_input: send pre-stage -> convolvers -> wet bus, all on the device, against the oracle-side
+    chain RefSendPre -> oracle convolvers -> ref_wet_bus."""
+    import torch
+    from reevr_amd.hotswap import DeviceHotSwap
+    from tests.ref_hotswap import OracleStereoConvolver
+    from tests.ref_wetbus import RefSendPre, ref_wet_bus
+    from reevr_amd import synth
+    sr, blk, nblocks, predelay = 8000.0, 64, 40, 150
+
+    class Imp:
+        pass
+    imp = Imp()
+    irs = synth.synth_ir(900, 2, 3)
+    imp.bufferLL, imp.bufferRR, imp.isQuad = irs[0], irs[1], False
+    dev = DeviceHotSwap()
+    dev.prepare(sr, blk)
+    dev.loadImpulse(imp)
+    oc = OracleStereoConvolver()
+    oc.prepare(blk)
+    oc.loadImpulse(imp)
+    pre = RefSendPre(int(2.0 * sr), int(np.ceil(sr)) // 4)
+    rng = np.random.RandomState(9)
+    got, want = [], []
+    for b in range(nblocks):
+        x = rng.randn(2, blk).astype(np.float32)
+        ys = (0.5 + 0.5 * rng.rand(blk)).astype(np.float32)
+        yr = (0.5 + 0.5 * rng.rand(blk)).astype(np.float32)
+        _, dl = pre.process(x[0], x[1], ys, predelay)
+        oc.process(dl[0], dl[1], blk)
+        wet = np.stack([oc.bufferLL[:blk], oc.bufferRR[:blk]])
+        want.append(ref_wet_bus(wet, yr, 0.8, 0.6, 0.9, x))
+        o = dev.process_input(torch.from_numpy(x).cuda(), ysend=torch.from_numpy(ys).cuda(), predelay=predelay,
+                              yrev=torch.from_numpy(yr).cuda(), width=0.8, drygain=0.6, wetgain=0.9)
+        got.append(torch.stack(o).cpu().numpy())
+    got = np.concatenate(got, axis=1)
+    want = np.concatenate(want, axis=1)
+    err = np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)) / np.sqrt(np.mean(want.astype(np.float64) ** 2))
+    assert err <= 1e-5, err

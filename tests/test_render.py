@@ -72,7 +72,7 @@ def test_render_matches_oracle_chain(tmp_path, nir):
     if nir == 4:
         wl += conv(imp[3], xin[1])                          # RL <- R goes to the left bus
         wr += conv(imp[2], xin[0])                          # LR <- L goes to the right bus
-    from reevr_amd.hotswap import wet_bus              # host restatement of PluginProcessor.cpp:1840-1876
+    from tests.ref_wetbus import ref_wet_bus as wet_bus   # oracle-side restatement of PluginProcessor.cpp:1840-1876
     want = wet_bus(np.stack([wl, wr]).astype(np.float32), np.ones(xin.shape[1], np.float32), 1.0, 0.2, 0.7, xin)
     err = np.sqrt(np.mean((y - want) ** 2))
     assert err <= 1e-5, err

@@ -17,7 +17,7 @@ def one(spec):
     os.makedirs(out, exist_ok=True)
     cmd = [build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
            "-ffp-contract=fast-honor-pragmas", "-w", "-o", os.path.join(out, "libreevr_amd.so")]
-    cmd += [f for f in flags.split(",") if f]
+    cmd += ["-DRVC_DEV_BUILD"] + [f for f in flags.split(",") if f]
     cmd += [os.path.join(build.CSRC, f) for f in build.SOURCES]
     subprocess.run(cmd, check=True, cwd=build.CSRC)
     return name
