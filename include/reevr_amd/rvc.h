@@ -279,6 +279,14 @@ int rvc_send_pre_device(int device, void *stream, const rvc_send_params *p);
 
 /* ---- library ----------------------------------------------------------------------- */
 
+/* Known-answer entries for the transforms alone: one n-point real transform (n = 2 * partition size, a power
+ * of two, 2 <= n <= 2 * RVC_MAX_BLOCK; half that with f64) through the SAME forward / inverse kernels and twiddle
+ * tables the convolver stages use, with the reference facade's conventions (AudioFFT::fft / ifft,
+ * libs/FFTConvolver/AudioFFT.cpp:114-159, :988-1016): split-complex re / im of n/2 + 1 bins, unscaled forward,
+ * 1/n total on the inverse. Host buffers; synchronous; for tests, not for the audio path. 1 = ok. */
+int rvc_debug_rfft(int device, size_t n, int f64, const float *data, float *re, float *im);
+int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re, const float *im);
+
 /* Number of visible HIP devices (0 when there is none or the runtime cannot start). */
 int rvc_device_count(void);
 const char *rvc_version(void);

@@ -74,6 +74,8 @@ SIGNATURES = {
     "rvc_set_init_impulse": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(C.c_int), C.c_size_t]),
     "rvc_wet_mix_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "rvc_send_pre_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
+    "rvc_debug_rfft": (C.c_int, [C.c_int, C.c_size_t, C.c_int, F32P, F32P, F32P]),
+    "rvc_debug_irfft": (C.c_int, [C.c_int, C.c_size_t, C.c_int, F32P, F32P, F32P]),
     "rvc_device_count": (C.c_int, []),
     "rvc_version": (C.c_char_p, []),
 }

@@ -1261,6 +1261,77 @@ void rvc_reset(rvc_set *h) { rvc_set_reset(h); }
 int rvc_is_finished(rvc_set *h) { return rvc_set_is_finished(h); }
 void rvc_destroy(rvc_set *h) { rvc_set_destroy(h); }
 
+// Known-answer entries for the transforms themselves (AudioFFT::fft / ifft, AudioFFT.cpp:114-159): one bare
+// 2B-point real transform through the SAME kernels the convolver stages launch (launch_fft_fwd / launch_fft_inv
+// with the stage's twiddle tables), host buffers in and out, split-complex like the reference's facade.
+static int debug_fft(int device, size_t n, int f64, bool inverse, const float *in_t, float *out_t, const float *re_in,
+                     const float *im_in, float *re_out, float *im_out) {
+  if (n < 2 || (n & (n - 1)) != 0) return 0;                       // power of two (AudioFFT.cpp:996)
+  const size_t B = n / 2;
+  const int logB = ilog2(B);
+  if (logB > (f64 ? 13 : 14)) return 0;
+  rvc_set *s = rvc_set_create(1, device, f64 ? RVC_FLAG_FFT_F64 : 0u);
+  if (!s) return 0;
+  bool ok = ensure_streams(s) && use_device(s);
+  Stage g;
+  g.B = B; g.logB = logB; g.f64 = f64 != 0;
+  float *d_t = nullptr;
+  float2 *d_f = nullptr;
+  ok = ok && make_twiddles(s, g);
+  ok = ok && hipMalloc(&d_t, sizeof(float) * 2 * n) == hipSuccess && hipMalloc(&d_f, sizeof(float2) * 2 * B) == hipSuccess;
+  if (ok && !inverse) {
+    ok = hipMemcpy(d_t, in_t, sizeof(float) * n, hipMemcpyHostToDevice) == hipSuccess;
+    rvc::FwdArgs a{};
+    a.src = d_t; a.src_chan_stride = (long long)n; a.src_mask = ~0ull;
+    a.seg0 = 0; a.valid_len = (int)n; a.lo = 0; a.hi = (long long)n;
+    a.tw = g.twp(); a.wsplit = g.wsp(); a.tw8 = g.t8p();
+    a.dst = d_f; a.dst_chan_stride = (long long)B; a.row0 = 0; a.row_mask = ~0ull;
+    ok = ok && rvc::launch_fft_fwd(logB, g.f64, a, 1, 1, s->st_main) == hipSuccess &&
+         hipStreamSynchronize(s->st_main) == hipSuccess;
+    std::vector<float2> X(B);
+    ok = ok && hipMemcpy(X.data(), d_f, sizeof(float2) * B, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok) {   // unpack: bin 0 carries (DC, Nyquist), both real (AudioFFT.cpp:130-136)
+      re_out[0] = X[0].x; im_out[0] = 0.f;
+      re_out[B] = X[0].y; im_out[B] = 0.f;
+      for (size_t k = 1; k < B; ++k) { re_out[k] = X[k].x; im_out[k] = X[k].y; }
+    }
+  } else if (ok) {
+    // the stage kernel delivers samples [B, 2B) of the inverse (overlap-save); the first half is the second half
+    // of the same spectrum shifted by B samples, i.e. with bins multiplied by (-1)^k
+    std::vector<float2> Y(2 * B);
+    for (int half = 0; half < 2; ++half) {
+      float2 *y = Y.data() + (size_t)half * B;
+      const float sN = (half == 0 && (B & 1)) ? -1.f : 1.f;          // Nyquist bin k = B
+      y[0] = make_float2(re_in[0], sN * re_in[B]);
+      for (size_t k = 1; k < B; ++k) {
+        const float sg = (half == 0 && (k & 1)) ? -1.f : 1.f;
+        y[k] = make_float2(sg * re_in[k], sg * im_in[k]);
+      }
+    }
+    ok = hipMemcpy(d_f, Y.data(), sizeof(float2) * 2 * B, hipMemcpyHostToDevice) == hipSuccess;
+    rvc::InvArgs v{};
+    v.Y = d_f; v.y_chan_stride = (long long)(2 * B); v.tw = g.twp(); v.wsplit = g.wsp(); v.tw8 = g.t8p();
+    v.blk0 = 0; v.dst = d_t; v.dst_chan_stride = (long long)n; v.dst_origin = 0; v.dst_mask = ~0ull;
+    v.lo = 0; v.hi = (long long)n; v.add = nullptr;
+    ok = ok && rvc::launch_fft_inv(logB, g.f64, v, 2, 1, s->st_main) == hipSuccess &&
+         hipStreamSynchronize(s->st_main) == hipSuccess;
+    ok = ok && hipMemcpy(out_t, d_t, sizeof(float) * n, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  hipFree(d_t); hipFree(d_f);
+  free_stage(g);
+  rvc_set_destroy(s);
+  return ok ? 1 : 0;
+}
+
+int rvc_debug_rfft(int device, size_t n, int f64, const float *data, float *re, float *im) {
+  if (!data || !re || !im) return 0;
+  return debug_fft(device, n, f64, false, data, nullptr, nullptr, nullptr, re, im);
+}
+int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re, const float *im) {
+  if (!data || !re || !im) return 0;
+  return debug_fft(device, n, f64, true, nullptr, data, re, im, nullptr, nullptr);
+}
+
 int rvc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -100,6 +100,10 @@ SYNTH_CASES = {
     # configs[2]: stereo, 30 s IR @ 96 kHz, block 256 -> head 256 / tail 8192
     "cfg3_stereo_30s96k_b256": dict(kind="twostage", head=256, tail=8192, ir=("synth", 2880000, 2, 0),
                                     frames=256 * 4608, calls=("fixed", 256)),
+    # configs[2] at full length: input = IR length + two wraps of the tail delay line's 512-row ring
+    # (352 + 1024 tail blocks), so all 350 tail partitions carry signal and every ring wraps
+    "cfg3_full_length": dict(kind="twostage", head=256, tail=8192, ir=("synth", 2880000, 2, 0),
+                             frames=8192 * 1376, calls=("fixed", 256)),
     # configs[3]: one of the 8 independent stereo instances (inst 3), 10 s IR @ 48 kHz
     "cfg4_inst3_10s_b512": dict(kind="twostage", head=512, tail=8192, ir=("synth", 480000, 2, 3),
                                 frames=512 * 400, calls=("fixed", 512)),

@@ -66,7 +66,9 @@ def test_kat_vs_golden_and_reference_rule(golden, kind, tup, mode):
     exact = O.direct_convolve(synth.ramp(tup[0]), synth.ramp(tup[1]))
     margin = cases.kat_margin(out, exact, tup[1])
     block = tup[4]
-    limit = 1.5 if (mode == "f32" and block >= 2048) else 1.0
+    # (bounded tightly: measured 0.71 ... 1.10 on MI355X for the four cases concerned; INTEGRATION.md lists this as
+    #  the one known divergence of the default precision, RVC_FLAG_FFT_F64 removes it)
+    limit = 1.15 if (mode == "f32" and block >= 2048) else 1.0
     assert margin < limit, f"margin {margin:.3f}"
     if limit == 1.0:
         assert cases.kat_tolerance_ok(out, exact, tup[1])
@@ -98,7 +100,7 @@ def test_background_stream_matches(golden, name):
 
 
 @pytest.mark.parametrize("name", ["cfg1_mono_1s_b512", "cfg2_stereo_10s_b512", "cfg3_stereo_30s96k_b256",
-                                  "cfg5_5s_b4096", "small_three_stage"])
+                                  "cfg3_full_length", "cfg5_5s_b4096", "small_three_stage"])
 def test_one_big_call_equals_block_calls(golden, name):
     """Multi-block fast path: the whole input in ONE process() call (time-tiled FIR, batched
     FFTs) must give the reference's block-by-block result (call-pattern independence)."""
@@ -163,6 +165,99 @@ def test_full_size_properties_cfg2():
         assert o.init(512, 8192, irs[c])
         yo = np.concatenate([o.process(a[c, i:i + 512]) for i in range(0, n, 512)])
         assert rel_rms(ya[c, :n], yo) <= TOL
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4", "cfg5"])
+def test_full_size_properties_other_configs(cfg):
+    """BASELINE configs[2], [3], [4] at full size -- config 3: stereo, 30 s IR @ 96 kHz, block 256 (350 tail
+    partitions); config 4: all 8 stereo instances = 16 channels in one set, 10 s IR, block 512; config 5: all
+    64 channels, 5 s IR, block 4096 -- through size-independent properties: impulse -> IR, linearity,
+    block-synchronous streaming == one big call, and the oracle on a prefix of two channels."""
+    import torch
+    nch, ir_len, block, n_inst = {"cfg3": (2, 2880000, 256, 1), "cfg4": (16, 480000, 512, 8),
+                                  "cfg5": (64, 240000, 4096, 32)}[cfg]
+    irs = np.concatenate([synth.synth_ir(ir_len, 2, inst=i) for i in range(n_inst)])
+    head = block
+    tail = max(8192, 2 * head)
+    frames = 2 * ir_len
+    frames -= frames % tail
+    s = reevr_amd.ConvolverSet(nch)
+    assert s.init(block, tail, list(irs), max_len=frames), s.last_error_string
+    assert s.partitions(0) == 2 * tail // head
+    assert s.partitions(1) == -(-(ir_len - 2 * tail) // tail)
+    dev = torch.device("cuda")
+    # impulse response identity (delta at sample 5 of every channel)
+    d = torch.zeros((nch, frames), device=dev)
+    d[:, 5] = 1.0
+    y = s.process_device(d).cpu().numpy()
+    for c in range(nch):
+        want = np.zeros(frames, np.float32)
+        want[5:5 + ir_len] = irs[c][:frames - 5]
+        assert np.sqrt(np.mean((y[c].astype(np.float64) - want) ** 2)) <= 1e-7, c
+    # linearity
+    a = torch.from_numpy(np.stack([synth.synth_input(frames, c) for c in range(nch)])).to(dev)
+    b = torch.from_numpy(np.stack([synth.synth_input(frames, 100 + c) for c in range(nch)])).to(dev)
+    s.clear(); ya = s.process_device(a).cpu().numpy()
+    s.clear(); yb = s.process_device(b).cpu().numpy()
+    s.clear(); yab = s.process_device(a + 2 * b).cpu().numpy()
+    for c in range(nch):
+        assert rel_rms(yab[c], ya[c].astype(np.float64) + 2.0 * yb[c]) <= TOL, c
+    # block-synchronous streaming (the host's per-block loop, all channels in lock-step) over the whole IR
+    # length and a few more tail blocks == the big call
+    n = min(frames, (ir_len // tail + 6) * tail)
+    for bg in (False, True):
+        t = reevr_amd.ConvolverSet(nch, bg_stream=bg)
+        assert t.init(block, tail, list(irs), max_len=block)
+        ys = t.process_device_blocks(a[:, :n].contiguous(), block).cpu().numpy()
+        for c in range(nch):
+            assert rel_rms(ys[c], ya[c, :n]) <= TOL, (bg, c)
+        t.close()
+    # and the oracle, block by block, on a prefix of the first and the last channel
+    m = min(n, 40 * tail)
+    for c in (0, nch - 1):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(block, tail, irs[c])
+        xin = a[c, :m].cpu().numpy()
+        yo = np.concatenate([o.process(xin[i:i + block]) for i in range(0, m, block)])
+        assert rel_rms(ya[c, :m], yo) <= TOL, c
+
+
+AUDIOFFT_SIZES = (2, 4, 8, 16, 64, 1024, 16384)
+
+
+@pytest.mark.parametrize("f64", [0, 1])
+@pytest.mark.parametrize("n", AUDIOFFT_SIZES)
+def test_bare_transforms_vs_audiofft_golden(golden, n, f64):
+    """The HIP forward / inverse transform kernels ALONE (rvc_debug_rfft / rvc_debug_irfft: one launch of the
+    stage kernels with the stage twiddle tables) against the reference's AudioFFT known answers
+    (tests/golden/audiofft.npz, generated from oracle/_ref: AudioFFT.cpp:988-1016 facade, Ooura back-end in
+    double). Tolerance, relative to the RMS of the expected vector: 2e-6 with float32 transforms (measured
+    ~3e-7), 3e-7 with RVC_FLAG_FFT_F64 (what remains is the float32 rounding of the stored bins)."""
+    import ctypes as C
+    from reevr_amd import _lib
+    L = _lib.lib()
+    g = golden["audiofft"]
+    x = synth.white_noise(n, 0xF00D + n)
+    re = np.empty(n // 2 + 1, np.float32)
+    im = np.empty(n // 2 + 1, np.float32)
+    fp = lambda a: a.ctypes.data_as(_lib.F32P)
+    assert L.rvc_debug_rfft(0, n, f64, fp(x), fp(re), fp(im)) == 1
+    tol = 3e-7 if f64 else 2e-6
+    want = np.concatenate([g[f"n{n}/re"], g[f"n{n}/im"]]).astype(np.float64)
+    got = np.concatenate([re, im]).astype(np.float64)
+    scale = np.sqrt(np.mean(want ** 2))
+    assert np.sqrt(np.mean((got - want) ** 2)) / scale <= tol
+    assert im[0] == 0.0 and im[n // 2] == 0.0                     # AudioFFT.cpp:134-135
+    # inverse of the REFERENCE's spectrum == the reference's round trip
+    rt = np.empty(n, np.float32)
+    wre = np.ascontiguousarray(g[f"n{n}/re"], np.float32)
+    wim = np.ascontiguousarray(g[f"n{n}/im"], np.float32)
+    assert L.rvc_debug_irfft(0, n, f64, fp(rt), fp(wre), fp(wim)) == 1
+    wrt = g[f"n{n}/rt"].astype(np.float64)
+    assert np.sqrt(np.mean((rt.astype(np.float64) - wrt) ** 2)) / np.sqrt(np.mean(wrt ** 2)) <= tol
+    # argument checks: not a power of two / too large -> 0, nothing written
+    assert L.rvc_debug_rfft(0, 24, 0, fp(x), fp(re), fp(im)) == 0 if n >= 24 else True
+    assert L.rvc_debug_rfft(0, 1 << 16, 0, fp(x), fp(re), fp(im)) == 0 if n >= (1 << 16) else True
 
 
 def test_max_block_and_limits():
