@@ -128,7 +128,12 @@ def main():
     ap.add_argument("--gather", type=int, default=1, help="N > 1: RCCL all_gather of every step's output batch (0: off)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--side", type=int, default=1, help="0: skip the side measurements")
+    ap.add_argument("--watchdog", type=float, default=1500.0,
+                    help="seconds after which a stuck run dumps every thread's stack and exits (0: off)")
     args = ap.parse_args()
+    if args.watchdog > 0:          # a hung collective or kernel must not hold the GPU box until the driver's limit
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     import torch
     import reevr_amd
@@ -208,7 +213,7 @@ def main():
     torch.cuda.synchronize()
     state = {"i": 0}
 
-    def step():
+    def step(gather=True):
         b = state["i"] % nbuf
         state["i"] += 1
         xi = d_in[:, b * frames_step:(b + 1) * frames_step]
@@ -217,7 +222,7 @@ def main():
             conv.process_device(xi, yo, sync=False, order=False)
         else:                                  # the host's per-block loop (in C): one call per 512-frame block
             conv.process_device_blocks(xi, host_block, yo, sync=False, order=False)
-        if do_gather:                          # one RCCL all_gather per step (batch of blocks), never per block
+        if do_gather and gather:               # one RCCL all_gather per step (batch of blocks), never per block
             conv.sync()
             shard.gather_batches(yo, dist)
 
@@ -271,7 +276,7 @@ def main():
     conv.kernel_time_reset()
     ksteps = 1
     for _ in range(ksteps):
-        step()
+        step(gather=False)                     # (rank 0 only: no collective here)
     conv.sync()
     kern = {}
     for kid, name in enumerate(KERNEL_NAMES):

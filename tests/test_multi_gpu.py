@@ -1,0 +1,127 @@
+"""Multi-GPU path on real devices. Two tests:
+
+* bench.py's N > 1 control flow (sharding of units, per-step all_gather, max-over-ranks timing, one JSON
+  line) for BASELINE configs 2, 4 and 5, run as two ranks under torch.distributed.run. On a 1-GPU box the
+  ranks share device 0 over gloo (REEVR_BENCH_SAME_DEVICE=1); with >= 2 devices they take one each over RCCL.
+* the RCCL branch of shard.gather_batches with real engines on two devices against the oracle; skipped when
+  fewer than two devices are visible.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ndev():
+    from reevr_amd import _lib
+    return _lib.lib().rvc_device_count()
+
+
+@pytest.mark.parametrize("extra", [["--config", "2", "--channels", "8", "--blocks-per-step", "32"],
+                                   ["--config", "4", "--blocks-per-step", "32"],
+                                   ["--config", "5"]], ids=["cfg2", "cfg4", "cfg5"])
+def test_bench_two_ranks(extra):
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if _ndev() < 2:
+        env["REEVR_BENCH_SAME_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--cpu-seconds", "0", "--side", "0", "--watchdog", "120"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["value"] > 0
+    assert rec["config"]["gather"] is True
+    want_scaling = "weak" if extra[1] == "2" else "strong"
+    assert rec["scaling"] == want_scaling
+    if extra[1] == "2":
+        assert rec["config"]["channels_per_gpu"] == 8 and rec["config"]["instances_total"] == 8
+    if extra[1] == "4":
+        assert rec["config"]["channels_per_gpu"] == 8          # 8 stereo instances over 2 ranks
+    if extra[1] == "5":
+        assert rec["config"]["channels_per_gpu"] == 32         # 64 mono channels over 2 ranks
+
+
+def test_bench_refuses_gpus_without_launcher():
+    """`python bench.py --gpus 8` outside torch.distributed.run must fail, not report a 1-GPU number."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "WORLD_SIZE" in (r.stdout + r.stderr)
+
+
+def _rccl_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import reevr_amd
+    from reevr_amd import shard, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        n_units, frames = 4, 4096
+        mine = shard.units_for_rank(n_units, world, rank)
+        irs = [synth.synth_ir(3000, 2, inst=u)[c] for u in mine for c in range(2)]
+        x = np.stack([synth.synth_input(frames, 2 * u + c) for u in mine for c in range(2)])
+        s = reevr_amd.ConvolverSet(2 * len(mine), device=rank)
+        assert s.init(64, 256, irs, max_len=64)
+        y = s.process_device_blocks(torch.from_numpy(x).cuda(rank), 64)
+        g = shard.gather_batches(y.view(len(mine), 2, frames), dist)          # RCCL all_gather_into_tensor
+        full = shard.reassemble(g, n_units, world)
+        slow = shard.max_over_ranks(1.0 + rank, dist, torch.device("cuda", rank))
+        q.put((rank, full.cpu().numpy(), slow))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_gather_two_devices():
+    if _ndev() < 2:
+        pytest.skip("needs two visible devices")
+    import torch.multiprocessing as mp
+    from oracle import oracle_py as O
+    from reevr_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    frames = 4096
+    for rank, full, slow in res:
+        assert slow == 2.0
+        assert full.shape == (4, 2, frames)
+        for u in range(4):
+            irs = synth.synth_ir(3000, 2, inst=u)
+            for c in range(2):
+                o = O.TwoStageFFTConvolver("orc")
+                assert o.init(64, 256, irs[c])
+                want = o.process(synth.synth_input(frames, 2 * u + c))
+                err = np.sqrt(np.mean((full[u, c].astype(np.float64) - want) ** 2)) / np.sqrt(np.mean(want.astype(np.float64) ** 2))
+                assert err <= 1e-5, (rank, u, c, err)
