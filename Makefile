@@ -9,9 +9,8 @@ LIB   := $(CSRC)/libreevr_amd.so
 
 all: $(LIB) oracle
 
-$(LIB): $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_impulse.hip $(CSRC)/rvc_engine.cpp $(CSRC)/rvc_internal.h $(CSRC)/rvc_fft_lds.hpp include/reevr_amd/rvc.h
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip -ffp-contract=fast-honor-pragmas \
-	  -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -o $@ $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_impulse.hip $(CSRC)/rvc_engine.cpp
+$(LIB): $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_sweep.hip $(CSRC)/rvc_impulse.hip $(CSRC)/rvc_engine.cpp $(CSRC)/rvc_internal.h $(CSRC)/rvc_fft_lds.hpp include/reevr_amd/rvc.h
+	python -m reevr_amd.build --force     # hipcc -c per source (rvc_sweep.hip with -fno-slp-vectorize), then link
 
 oracle:
 	$(MAKE) -C oracle

@@ -65,6 +65,16 @@ enum {
                                    >= 4 blocks of 16384 uses a delay line at THAT size when the IR is long
                                    enough (float transforms, max_len >= 65536). */
 
+#define RVC_FLAG_NO_TIME_TILING 16u /* block-synchronous calls: sweep every stage's IR spectra and delay line once per
+                                   block, in the reference's order (FFTConvolver.cpp:176-187). Default: causal time
+                                   tiling -- every 8th block a sweep reads them ONCE and leaves partial sums for the
+                                   next 8 blocks (only partitions whose input has already arrived), the blocks in
+                                   between add their few recent partitions: same sums, same zero latency, ~3.5x fewer
+                                   HBM bytes where the path is bandwidth-bound (many lock-step channels). */
+
+#define RVC_FLAG_FORCE_TIME_TILING 32u /* testing: time-tile every stage that has partitions to tile, however small
+                                   (by default only stages whose per-block sweep is long enough to be bandwidth-bound) */
+
 /* ---- lifetime ---------------------------------------------------------------------- */
 
 /* Replaces `new Convolver()` x n (StereoConvolver.h:12-17). `device` is the HIP ordinal.

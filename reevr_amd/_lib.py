@@ -18,6 +18,8 @@ RVC_FLAG_BG_STREAM = 1
 RVC_FLAG_TIMING = 2
 RVC_FLAG_FFT_F64 = 4
 RVC_FLAG_FIXED_PARTITIONS = 8
+RVC_FLAG_NO_TIME_TILING = 16
+RVC_FLAG_FORCE_TIME_TILING = 32
 RVC_MAX_BLOCK = 16384
 
 # name -> (restype, argtypes); must list every symbol declared in include/reevr_amd/rvc.h

@@ -15,7 +15,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libreevr_amd.so")
-SOURCES = ["rvc_kernels.hip", "rvc_impulse.hip", "rvc_engine.cpp"]
+SOURCES = ["rvc_kernels.hip", "rvc_sweep.hip", "rvc_impulse.hip", "rvc_engine.cpp"]
+# per-source extra flags (rvc_sweep.hip: see the comment at its top)
+EXTRA_FLAGS = {"rvc_sweep.hip": ["-fno-slp-vectorize"]}
 HEADERS = ["rvc_internal.h", "rvc_fft_lds.hpp", os.path.join("..", "..", "include", "reevr_amd", "rvc.h")]
 
 
@@ -34,15 +36,38 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-x", "hip", "-ffp-contract=fast-honor-pragmas", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
-           "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-ffp-contract=fast-honor-pragmas",
+                "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def compile_objects(out_dir: str, defines=(), verbose: bool = False):
+    """hipcc -c every source (in parallel) into out_dir; returns the object paths."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(out_dir, exist_ok=True)
+
+    def one(src):
+        obj = os.path.join(out_dir, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc()] + COMMON_FLAGS + list(defines) + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        return obj
+    with ThreadPoolExecutor(len(SOURCES)) as ex:
+        return list(ex.map(one, SOURCES))
+
+
+def link_lib(objs, lib: str, verbose: bool = False):
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True, cwd=CSRC)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    objs = compile_objects(os.path.join(CSRC, "build"), verbose=verbose)
+    link_lib(objs, LIB, verbose)
     return LIB
 
 

@@ -105,6 +105,14 @@ struct rvc_set {
   unsigned flag_seq = 0;         // value the next flagged launch publishes
   int flag_count = 0;            // flags the pending call waits for (0: wait for ev_out instead)
   bool fold = false;             // one launch per block: H_1 X_{k-1} folded into the fused kernel, ypre = sum_{i>=2}
+  // Causal time tiling of the block-synchronous delay lines (rvc_internal.h, kSweepRows): every kSweepRows-th
+  // block a sweep reads the stage's IR spectra and delay line ONCE and leaves partial sums for kSweepRows blocks;
+  // the blocks in between only add their few missing (recent) partitions.
+  bool tile_A = false, tile_T = false;
+  float2 *sA = nullptr, *sT = nullptr;     // sweep rows [nch][kSweepRows][B], slot = block & (kSweepRows - 1)
+  long long sa_t0 = -1, st_t0 = -1;        // blocks [t0, t0 + kSweepRows) have sweep rows; -1: none
+  const float2 *ypre_cur = nullptr;        // where the accumulator of block ypre_block lives: a ypre half or a sweep row
+  long long ypre_cur_stride = 0;
   float *d_in = nullptr, *d_out = nullptr;     // staging for the host-pointer API [nch][max_len]
   float *h_in = nullptr, *h_out = nullptr;     // pinned
   long long n = 0;               // absolute sample clock
@@ -230,7 +238,11 @@ void free_device_state(rvc_set *s) {
   free_stage(s->T);
   free_stage(s->W);
   hipFree(s->xring); hipFree(s->tailring); hipFree(s->d_in); hipFree(s->d_out); hipFree(s->ypre);
-  s->ypre = nullptr;
+  hipFree(s->sA); hipFree(s->sT);
+  s->ypre = nullptr; s->sA = nullptr; s->sT = nullptr;
+  s->tile_A = s->tile_T = false;
+  s->sa_t0 = s->st_t0 = -1;
+  s->ypre_cur = nullptr;
   s->ypre_block = -1;
   if (s->h_in) hipHostFree(s->h_in);
   if (s->h_out) hipHostFree(s->h_out);
@@ -420,7 +432,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     if (pf > 0 && !upload_ir_stage(s, s->T, irs, len, on_device)) { free_device_state(s); return false; }
     if (pw > 0 && !upload_ir_stage(s, s->W, irs, len, on_device)) { free_device_state(s); return false; }
     s->n = 0; s->tail_fft_done = 0; s->tail_out_done = 2; s->xa_next = 0; s->ypre_block = -1;
-    s->w_next = 0; s->xt_valid_lo = 0;
+    s->w_next = 0; s->xt_valid_lo = 0; s->sa_t0 = s->st_t0 = -1;
     return true;
   }
 
@@ -473,6 +485,18 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   RVC_CK(hipMemset(s->ypre, 0, sizeof(float2) * 2 * (size_t)s->nch * A.B));
   s->ypre_block = -1;
   s->fold = rvc::fused_fold_supported(A.logB) && !want64;
+  // time tiling: where a per-block sweep is long enough to be bandwidth- rather than latency-bound
+  {
+    const bool tiling = (s->flags & RVC_FLAG_NO_TIME_TILING) == 0;
+    const bool force = tiling && (s->flags & RVC_FLAG_FORCE_TIME_TILING) != 0;   // tests: tile whatever the size
+    const size_t K = (size_t)rvc::kSweepRows;
+    s->tile_A = tiling && s->fold && A.B >= 64 &&
+                (force ? pa >= 3 : (pa >= 16 && (size_t)s->nch * (pa - 2) * A.B * 16 >= ((size_t)4 << 20)));
+    s->tile_T = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
+    if (s->tile_A) RVC_CK(hipMalloc(&s->sA, sizeof(float2) * (size_t)s->nch * K * A.B));
+    if (s->tile_T) RVC_CK(hipMalloc(&s->sT, sizeof(float2) * (size_t)s->nch * K * T.B));
+    s->sa_t0 = s->st_t0 = -1;
+  }
   RVC_CK(hipMalloc(&s->d_in, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipMalloc(&s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipHostMalloc(&s->h_in, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
@@ -575,12 +599,36 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
   r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
   r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
   r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = 2; r.B = (int)tb; r.tag = 1;
-  {
+  const long long K = rvc::kSweepRows;
+  const float2 *yrows = T.Y;                      // where the inverse transforms read the spectra
+  if (s->tile_T && r.M == 1) {
+    // block-synchronous streaming, time-tiled: output block m_lo either lies in the current sweep tile -- then only
+    // the partitions whose input arrived after the sweep are added to the sweep's row -- or starts a new tile
+    const long long sTstride = K * tb;
+    if (s->st_t0 >= 0 && m_lo > s->st_t0 && m_lo < s->st_t0 + K) {
+      const long long t = m_lo - s->st_t0;         // input rows m_lo-2 .. m_lo-1-t came after the sweep
+      r.P = (int)std::min<long long>(t, T.P);
+      r.Yadd = s->sT + (size_t)((unsigned long long)m_lo & (unsigned long long)(K - 1)) * tb;
+      r.yadd_chan_stride = sTstride;
+      Timer tm(s, 5, st);
+      RVC_CK(rvc::launch_fir(r, s->nch, st));
+    } else {
+      r.M = (int)K; r.Y = s->sT; r.y_chan_stride = sTstride; r.y_row_mask = (unsigned)(K - 1);
+      r.x_hi = m_lo - 2;                           // newest delay-line row that exists
+      Timer tm(s, 5, st);
+      RVC_CK(rvc::launch_fdl_sweep(r, s->nch, st));
+      s->st_t0 = m_lo;
+      yrows = s->sT + (size_t)((unsigned long long)m_lo & (unsigned long long)(K - 1)) * tb;
+      r.y_chan_stride = sTstride;
+      r.M = 1;
+    }
+  } else {
+    s->st_t0 = -1;                                 // several rows at once: plain delay line, any tile is dropped
     Timer t(s, 5, st);
     RVC_CK(rvc::launch_fir(r, s->nch, st));
   }
   rvc::InvArgs v{};
-  v.Y = T.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp(); v.tw8 = T.t8p();
+  v.Y = yrows; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(); v.wsplit = T.wsp(); v.tw8 = T.t8p();
   v.blk0 = m_lo;
   v.dst = s->tailring; v.dst_chan_stride = (long long)s->ring_cap; v.dst_origin = 0; v.dst_mask = s->ring_cap - 1;
   v.lo = 0; v.hi = (long long)1 << 62;
@@ -708,13 +756,43 @@ rvc::FirArgs premultiply_args(rvc_set *s, long long kb) {
   return r;
 }
 
+// A sweep of the zero-latency stage for the tile of blocks starting at kb: partial sums of blocks kb .. kb+K-1
+// over the input rows that exist (<= kb - 2); row kb is complete (= sum_{i>=2} H_i X_{kb-i}).
+rvc::FirArgs head_sweep_args(rvc_set *s, long long kb) {
+  Stage &A = s->A;
+  const long long K = rvc::kSweepRows;
+  rvc::FirArgs r{};
+  r.H = A.H; r.h_chan_stride = (long long)A.P * (long long)A.B;
+  r.X = A.X; r.x_chan_stride = (long long)A.rows * (long long)A.B; r.x_row_mask = A.rows - 1;
+  r.Y = s->sA; r.y_chan_stride = K * (long long)A.B; r.y_row_mask = (unsigned)(K - 1);
+  r.k0 = kb; r.M = (int)K; r.P = A.P; r.delay = 0; r.B = (int)A.B; r.x_hi = kb - 2;
+  return r;
+}
+const float2 *head_sweep_row(const rvc_set *s, long long k) {
+  return s->sA + (size_t)((unsigned long long)k & (unsigned long long)(rvc::kSweepRows - 1)) * s->A.B;
+}
+
 bool run_premultiply(rvc_set *s, long long kb) {
+  if (s->tile_A) {    // (state was invalidated: a stand-alone sweep starts a new tile at kb)
+    const rvc::FirArgs r = head_sweep_args(s, kb);
+    {
+      Timer t(s, 8, s->st_main);
+      RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
+    }
+    s->sa_t0 = kb;
+    s->ypre_block = kb;
+    s->ypre_cur = head_sweep_row(s, kb);
+    s->ypre_cur_stride = r.y_chan_stride;
+    return true;
+  }
   const rvc::FirArgs r = premultiply_args(s, kb);
   if (r.P > 0) {      // (no partitions beyond the folded ones: the accumulator stays zero, as allocated)
     Timer t(s, 8, s->st_main);
     RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
   }
   s->ypre_block = kb;
+  s->ypre_cur = r.Y;
+  s->ypre_cur_stride = r.y_chan_stride;
   return true;
 }
 
@@ -740,6 +818,7 @@ void mark_long_stage_stale(rvc_set *s, long long n1) {
   if (T.PF > 0 && T.P == 0) {
     s->tail_fft_done = n1 / (long long)T.B;
     s->xt_valid_lo = s->tail_fft_done;
+    s->st_t0 = -1;
   }
 }
 
@@ -762,6 +841,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       if (!head_spectra(s, head_fft_from(s, k0), k0 - 1, n0, nullptr, 0, 0)) return false;
       s->xa_next = k0;
       s->ypre_block = -1;
+      s->sa_t0 = -1;
     }
     if (s->ypre_block != k0 && !run_premultiply(s, k0)) return false;
     rvc::FusedArgs g{};
@@ -771,7 +851,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     g.tw = A.tw; g.wsplit = A.wsplit; g.tw8 = A.tw8;
     g.H0 = A.H; g.h_chan_stride = (long long)A.P * hb;
     g.H1 = (s->fold && A.P > 1) ? A.H + hb : nullptr;
-    g.Ypre = s->ypre + (size_t)(k0 & 1) * (size_t)s->nch * (size_t)hb; g.ypre_chan_stride = hb;
+    g.Ypre = s->ypre_cur; g.ypre_chan_stride = s->ypre_cur_stride;
     g.Xrow = A.X; g.x_chan_stride = (long long)A.rows * hb; g.x_row_mask = A.rows - 1;
     g.out = d_out; g.out_chan_stride = (long long)out_stride;
     g.add = has_tail ? s->tailring : nullptr;
@@ -789,14 +869,37 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     }
     if (s->fold) {
       // the workgroups appended to this launch prepare block k0+1's accumulator (other half of ypre)
-      rvc::FirArgs f = premultiply_args(s, k0 + 1);
+      const long long kn = k0 + 1;
+      rvc::FirArgs f = premultiply_args(s, kn);
+      bool new_tile = false;
+      if (s->tile_A && block_done) {
+        const long long K = rvc::kSweepRows;
+        if (s->sa_t0 >= 0 && kn > s->sa_t0 && kn < s->sa_t0 + K) {
+          // inside the current tile: the sweep's row + the partitions whose input arrived after the sweep
+          f.P = (int)std::min<long long>(kn - s->sa_t0, (long long)A.P - 2);
+          f.Yadd = head_sweep_row(s, kn);
+          f.yadd_chan_stride = K * hb;
+          if (f.P <= 0) { f.P = 0; f.Y = const_cast<float2 *>(f.Yadd); f.y_chan_stride = f.yadd_chan_stride; }   // nothing to add
+        } else {      // the tile is used up: a sweep behind this launch starts the next one (its row kn is complete)
+          f.P = 0;
+          new_tile = true;
+        }
+      }
       if (!block_done) f.P = 0;
       {
         Timer t(s, 7, s->st_main);
         RVC_CK(rvc::launch_fused2(A.logB, g, f, s->nch, s->st_main));
       }
       if (!emit_output_copy(s)) return false;
-      if (block_done) s->ypre_block = k0 + 1;
+      if (block_done) {
+        if (new_tile) {
+          if (!run_premultiply(s, kn)) return false;     // (sweep launch: sets sa_t0, ypre_block, ypre_cur)
+        } else {
+          s->ypre_block = kn;
+          s->ypre_cur = f.Y;
+          s->ypre_cur_stride = f.y_chan_stride;
+        }
+      }
     } else {
       {
         Timer t(s, 7, s->st_main);
@@ -897,6 +1000,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     s->xt_valid_lo = s->tail_fft_done;
     const long long done = (n1 % tb == 0) ? (n1 - 1) / tb + 1 : (n1 - 1) / tb;
     if (s->tail_out_done < done) s->tail_out_done = done;
+    s->st_t0 = -1;
     s->n = n1;
     return true;
   }
@@ -962,6 +1066,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       // computed lazily if a later short call continues inside it
       const long long done = (n1 % tb == 0) ? m_last + 1 : m_last;
       if (s->tail_out_done < done) s->tail_out_done = done;
+      s->st_t0 = -1;
       s->n = n1;
       return true;
     }
@@ -1193,6 +1298,7 @@ void rvc_set_clear(rvc_set *s) {
   s->xa_next = 0;
   s->w_next = 0;
   s->xt_valid_lo = 0;
+  s->sa_t0 = s->st_t0 = -1;
 }
 
 void rvc_set_reset(rvc_set *s) {

@@ -58,6 +58,11 @@ struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency
   int B;
   int tag;                  // names the kernel instantiation for profilers: 0 head stage, 1 tail stage
                             // (delay 2), 2 whole-IR delay line of the adaptive long-call path
+  // Block-synchronous time tiling (single-row kernels and the sweep kernel only):
+  const float2 *Yadd;       // optional [channel][B] row added to the single output row (a sweep's partial sum)
+  long long yadd_chan_stride;
+  long long x_hi;           // sweep: input rows with index > x_hi have not arrived yet and read as zero
+  unsigned y_row_mask;      // sweep: output row of block k0 + j is slot (k0 + j) & y_row_mask of Y
 };
 
 struct InvArgs {            // spectrum row(s) -> last B samples of the inverse transform (overlap-save)
@@ -142,6 +147,7 @@ hipError_t launch_fused2(int logB, const FusedArgs &a, const FirArgs &f, int cha
 hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st);
 // arm (a, b) / disarm (nullptr, nullptr) kernel-exact timing events for the next launch on this thread
 void set_launch_events(hipEvent_t a, hipEvent_t b);
+void get_launch_events(hipEvent_t *a, hipEvent_t *b);   // (for launchers in other translation units)
 // one-off: raise the dynamic-LDS limit of the large FFT kernels
 hipError_t prepare_kernels();
 
@@ -152,6 +158,14 @@ int fft8_table_entries(int logB);
 
 // time-tile (output rows per thread) the FIR launcher will pick for M rows
 int fir_time_tile(int M);
+
+// Causal time tiling of the block-synchronous delay line. A "sweep" computes, for the kSweepRows output blocks
+// k0 .. k0 + kSweepRows - 1 at once, the part of  Y_k = sum_i H_i X_{k - delay - i}  whose input rows have already
+// arrived (index <= a.x_hi): every IR row and every delay-line row is read ONCE for kSweepRows blocks instead of once
+// per block. What is missing from block k0 + j -- at most j (+ delay-dependent) recent rows -- is added when that
+// block is due (a single-row launch with FirArgs::Yadd = the sweep's row). Rows go to slot (k0 + j) & y_row_mask.
+constexpr int kSweepRows = 8;
+hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st);
 
 // A prepared impulse as rvc_set_init_impulse sees it (rvc_impulse.hip): device pointers of the
 // prepared channels and their lengths with trailing |x| < 1e-6 dropped (TwoStageFFTConvolver.cpp:107-110).

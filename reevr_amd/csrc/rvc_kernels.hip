@@ -65,6 +65,7 @@ namespace rvc {
 // same interval a profiler reports, without marker packets between kernels.
 static thread_local hipEvent_t t_ev_a = nullptr, t_ev_b = nullptr;
 void set_launch_events(hipEvent_t a, hipEvent_t b) { t_ev_a = a; t_ev_b = b; }
+void get_launch_events(hipEvent_t *a, hipEvent_t *b) { *a = t_ev_a; *b = t_ev_b; }
 #define RVC_LAUNCH(kernel, grid, block, lds, st, ...)                                              \
   do {                                                                                             \
     if (t_ev_a) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, t_ev_a, t_ev_b, 0, __VA_ARGS__); \
@@ -1288,7 +1289,12 @@ __device__ __forceinline__ void fir_row_body(const FirArgs &a, float2 (*part)[64
   __syncthreads();
   if (wave == 0 && active) {
     const float2 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
-    a.Y[(long long)c * a.y_chan_stride + bin] = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+    float2 y = make_float2((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y));
+    if (a.Yadd) {                                        // + the partial sum a sweep left for this block
+      const float2 s = a.Yadd[(long long)c * a.yadd_chan_stride + bin];
+      y.x += s.x; y.y += s.y;
+    }
+    a.Y[(long long)c * a.y_chan_stride + bin] = y;
   }
 }
 
@@ -1297,6 +1303,53 @@ __global__ void __launch_bounds__(256) k_fir_row(const FirArgs a) {
   __shared__ float2 part[4][64];
   fir_row_body(a, part, blockIdx.x, blockIdx.y);
 }
+
+// ----------------------------------------------------------------------------------------
+// Patch of the time-tiled delay line: Y = Yadd + sum_{i < P} H_i X_{k0-delay-i} with P <= kSweepRows - 1 recent
+// partitions (the input rows that arrived after the sweep that left Yadd). Streaming shape: a workgroup = 512 bins of
+// one channel, a thread = two bins (16 bytes), all 2 P row loads of a thread in flight at once, no LDS, no barrier.
+// ----------------------------------------------------------------------------------------
+constexpr int kPatchMax = kSweepRows - 1;
+__device__ __forceinline__ bool fdl_is_patch(const FirArgs &a) { return a.Yadd != nullptr && a.P <= kPatchMax && a.P >= 1; }
+
+__device__ __forceinline__ void fdl_patch_body(const FirArgs &a, const int bx, const int c) {
+  const int bin = bx * 512 + (int)threadIdx.x * 2;
+  if (bin >= a.B) return;
+  const long long B = a.B;
+  const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride + bin;
+  const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride + bin;
+  const long long cbase = a.k0 - a.delay;
+  float4 hv[kPatchMax], xv[kPatchMax];
+#pragma unroll
+  for (int i = 0; i < kPatchMax; ++i) {                 // clamped addresses: every load is issued, unused ones dropped below
+    const int ii = i < a.P ? i : a.P - 1;
+    const long long row = cbase - ii, rr = row < 0 ? 0 : row;
+    hv[i] = *reinterpret_cast<const float4 *>(Hc + (long long)ii * B);
+    xv[i] = *reinterpret_cast<const float4 *>(Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B);
+  }
+  float4 y = *reinterpret_cast<const float4 *>(a.Yadd + (long long)c * a.yadd_chan_stride + bin);
+  const bool packed = (bin == 0);
+#pragma unroll
+  for (int i = 0; i < kPatchMax; ++i) {
+    if (i < a.P && cbase - i >= 0) {                   // uniform
+      const float4 h = hv[i], x = xv[i];
+      const float hz = packed ? 0.f : h.y;
+      const float h3 = packed ? h.y : h.x;
+      y.x = fmaf(h.x, x.x, y.x);
+      y.x = fmaf(-hz, x.y, y.x);
+      y.y = fmaf(h3, x.y, y.y);
+      y.y = fmaf(hz, x.x, y.y);
+      y.z = fmaf(h.z, x.z, y.z);
+      y.z = fmaf(-h.w, x.w, y.z);
+      y.w = fmaf(h.z, x.w, y.w);
+      y.w = fmaf(h.w, x.z, y.w);
+    }
+  }
+  *reinterpret_cast<float4 *>(a.Y + (long long)c * a.y_chan_stride + bin) = y;
+}
+
+template <int STAGE>
+__global__ void __launch_bounds__(256) k_fdl_patch(const FirArgs a) { fdl_patch_body(a, blockIdx.x, blockIdx.y); }
 
 // One launch per block of the streaming path: workgroups [0, n_audio) run block k's audio path
 // (fused_audio<FOLD = true>), the rest compute sum_{i>=2} H_i X_{k+1-i} for block k+1 (fir_row_body;
@@ -1313,7 +1366,8 @@ k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int 
   } else {
     if (threadIdx.x >= 256) return;
     const int idx = (int)blockIdx.x - n_audio;
-    fir_row_body(f, reinterpret_cast<float2 (*)[64]>(smem_raw), idx % fir_bx, idx / fir_bx);
+    if (fdl_is_patch(f)) fdl_patch_body(f, idx % fir_bx, idx / fir_bx);          // (fir_bx = 512-bin tiles per channel)
+    else fir_row_body(f, reinterpret_cast<float2 (*)[64]>(smem_raw), idx % fir_bx, idx / fir_bx);
   }
 }
 
@@ -1438,7 +1492,8 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
   FusedArgs b = a;
   b.channels = channels;
   const int n_audio = (channels + P::TPW - 1) / P::TPW;
-  const int fir_bx = (P::B + 63) / 64;
+  const bool patch = f.Yadd != nullptr && f.P <= kPatchMax && f.P >= 1;
+  const int fir_bx = patch ? (P::B + 511) / 512 : (P::B + 63) / 64;
   const int n_fir = f.P > 0 ? fir_bx * channels : 0;
   constexpr int kThreads = P::WG > 256 ? P::WG : 256;
   RVC_LAUNCH((k_fused_block2<LOGB>), dim3(n_audio + n_fir), dim3(kThreads), lds, st, b, f, n_audio, fir_bx);
@@ -1492,6 +1547,12 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
     if (a.tag == 0) RVC_LAUNCH((k_fir_lds<0>), grid, block, 0, st, a);
     else if (a.tag == 1) RVC_LAUNCH((k_fir_lds<1>), grid, block, 0, st, a);
     else RVC_LAUNCH((k_fir_lds<2>), grid, block, 0, st, a);
+    return hipGetLastError();
+  }
+  if (a.M == 1 && a.Yadd != nullptr && a.P <= kPatchMax && (a.B % 2) == 0) {   // a few recent partitions on top of a sweep row
+    const dim3 grid((a.B + 511) / 512, channels), block(256);
+    if (a.tag == 0) RVC_LAUNCH((k_fdl_patch<0>), grid, block, 0, st, a);
+    else RVC_LAUNCH((k_fdl_patch<1>), grid, block, 0, st, a);
     return hipGetLastError();
   }
   if (a.M == 1) {                         // one block: the latency-oriented row kernel

@@ -1,0 +1,191 @@
+// rvc_sweep.hip -- the sweep kernel of the time-tiled block-synchronous delay line (gfx950).
+//
+// Replaces, for kSweepRows consecutive blocks at once, the reference's per-block loop over the partitions
+// (FFTConvolver.cpp:176-187 calling ComplexMultiplyAccumulate, Utilities.cpp:62-111): see rvc_internal.h.
+//
+// Own translation unit because it is compiled with -fno-slp-vectorize (reevr_amd/build.py): the SLP vectoriser
+// turns the 4*K independent FMA chains of a step into v_pk_fma_f32 with shuffled operands and then needs
+// ~450 spilled VGPRs at the 128-register budget; the kernel is HBM-bound (16 B read per 8*K flops), scalar FMAs
+// at ~1/3 VALU utilisation cost nothing.
+#include <hip/hip_ext.h>
+
+#include "rvc_internal.h"
+
+namespace rvc {
+
+template <int LW> struct SweepVec;
+template <> struct SweepVec<2> { typedef float2 T; };
+template <> struct SweepVec<4> { typedef float4 T; };
+
+typedef float vf2 __attribute__((ext_vector_type(2)));
+typedef float vf4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float2 sweep_ld(const float2 *p) {
+  if constexpr (NT) { const vf2 v = __builtin_nontemporal_load(reinterpret_cast<const vf2 *>(p)); return make_float2(v.x, v.y); }
+  else return *p;
+}
+template <bool NT> __device__ __forceinline__ float4 sweep_ld(const float4 *p) {
+  if constexpr (NT) { const vf4 v = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+  else return *p;
+}
+__device__ __forceinline__ float2 sweep_zero(float2) { return make_float2(0.f, 0.f); }
+__device__ __forceinline__ float4 sweep_zero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void sweep_add(float2 &r, const float2 o) { r.x += o.x; r.y += o.y; }
+__device__ __forceinline__ void sweep_add(float4 &r, const float4 o) { r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+
+// acc += h * x for the lane's bin(s); the FIRST bin may be the packed (DC, Nyquist) one: two real products
+__device__ __forceinline__ void sweep_mac(float2 &acc, const float2 h, const float2 x, const float hz, const float h3) {
+  acc.x = fmaf(h.x, x.x, acc.x);
+  acc.x = fmaf(-hz, x.y, acc.x);
+  acc.y = fmaf(h3, x.y, acc.y);
+  acc.y = fmaf(hz, x.x, acc.y);
+}
+__device__ __forceinline__ void sweep_mac(float4 &acc, const float4 h, const float4 x, const float hz, const float h3) {
+  acc.x = fmaf(h.x, x.x, acc.x);
+  acc.x = fmaf(-hz, x.y, acc.x);
+  acc.y = fmaf(h3, x.y, acc.y);
+  acc.y = fmaf(hz, x.x, acc.y);
+  acc.z = fmaf(h.z, x.z, acc.z);
+  acc.z = fmaf(-h.w, x.w, acc.z);
+  acc.w = fmaf(h.z, x.w, acc.w);
+  acc.w = fmaf(h.w, x.z, acc.w);
+}
+
+// K output blocks k0 .. k0+K-1 at once from the input rows that have arrived (<= a.x_hi). Pure streaming: a wave owns
+// 32 * LW bins (LW floats = LW/2 bins per lane), walks the partitions once with D row pairs requested ahead, keeps the K
+// accumulators and a K-row sliding window of the delay line in registers: one IR row + one delay-line row fetched
+// per step feed K complex MACs per bin.
+//   SPLIT == 1: the four waves of a workgroup take four neighbouring bin tiles (throughput: many channels);
+//   SPLIT == 4: they split the partitions of ONE tile and meet in LDS (few channels: four times the waves, a
+//               quarter of the dependent load rounds each).
+template <int K, int D, int SPLIT, int LW, bool NT>
+__device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepVec<LW>::T (*red)[K][64], const int wg_tile,
+                                               const int c) {
+  static_assert((K & (K - 1)) == 0 && K % D == 0, "window / queue indexing");
+  typedef typename SweepVec<LW>::T V;
+  constexpr int BPL = LW / 2;                       // bins per lane
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = SPLIT == 1 ? wg_tile * 4 + wave : wg_tile;
+  const int bin = tile * (64 * BPL) + lane * BPL;
+  const bool active = bin < a.B;
+  const int b = active ? bin : 0;
+  // this wave's share of the partitions
+  const int q = SPLIT == 1 ? a.P : (a.P + SPLIT - 1) / SPLIT;
+  const int p0 = SPLIT == 1 ? 0 : wave * q;
+  const int P = SPLIT == 1 ? a.P : (p0 + q <= a.P ? q : (a.P > p0 ? a.P - p0 : 0));
+  const long long B = a.B;
+  // wave-uniform row pointers + a 32-bit lane byte offset (saddr form of global_load)
+  const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride + (long long)p0 * B;
+  const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride;
+  const unsigned boff = (unsigned)b * (unsigned)sizeof(float2);
+  const long long cbase = a.k0 - a.delay - p0;     // input row meeting this wave's first partition for output row 0
+  const bool packed = (bin == 0);                  // the lane's FIRST bin is the packed (DC, Nyquist) one
+  const V zero = sweep_zero(V());
+
+  auto loadX = [&](long long row) -> V {           // clamped address, the caller selects
+    long long rr = row < 0 ? 0 : row;
+    rr = rr > a.x_hi ? (a.x_hi < 0 ? 0 : a.x_hi) : rr;
+    const char *rp = reinterpret_cast<const char *>(Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B);
+    return sweep_ld<NT>(reinterpret_cast<const V *>(rp + boff));
+  };
+  auto validX = [&](long long row) -> bool { return row >= 0 && row <= a.x_hi; };   // wave-uniform
+  auto loadH = [&](int i) -> V {
+    const int ii = i < P ? i : (P > 0 ? P - 1 : 0);
+    const char *rp = reinterpret_cast<const char *>(Hc + (long long)ii * B);
+    return sweep_ld<NT>(reinterpret_cast<const V *>(rp + boff));
+  };
+
+  V acc[K], w[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    acc[t] = zero;
+    const V x = loadX(cbase + t);
+    w[t] = validX(cbase + t) ? x : zero;
+  }
+  V hq[D], xq[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    hq[d] = loadH(d);
+    xq[d] = loadX(cbase - d - 1);
+  }
+  auto step = [&](const int i, const int u) {     // u = i mod K, compile-time after unrolling
+    const V h = hq[u % D];
+    const V xin = xq[u % D];
+    hq[u % D] = loadH(i + D);
+    xq[u % D] = loadX(cbase - (i + D) - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const float hz = packed ? 0.f : h.y;            // first bin: ordinary (re, re, im) / packed (DC gain, Nyquist gain, 0)
+    const float h3 = packed ? h.y : h.x;
+#pragma unroll
+    for (int t = 0; t < K; ++t) sweep_mac(acc[t], h, w[(t - u) & (K - 1)], hz, h3);
+    w[(K - 1 - u) & (K - 1)] = validX(cbase - i - 1) ? xin : zero;
+  };
+  const int Pfull = P - (P % K);
+  int i0 = 0;
+  for (; i0 < Pfull; i0 += K) {
+#pragma unroll
+    for (int u = 0; u < K; ++u) step(i0 + u, u);
+  }
+#pragma unroll
+  for (int u = 0; u < K; ++u)
+    if (i0 + u < P) step(i0 + u, u);
+
+  float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
+  if constexpr (SPLIT == 1) {
+    if (active) {
+#pragma unroll
+      for (int t = 0; t < K; ++t)
+        *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = acc[t];
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < K; ++t) red[wave][t][lane] = acc[t];
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int t = wave; t < K; t += SPLIT) {
+        V r = red[0][t][lane];
+#pragma unroll
+        for (int v = 1; v < SPLIT; ++v) sweep_add(r, red[v][t][lane]);
+        *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
+      }
+    }
+  }
+}
+
+// grid (bin tiles, channels), block 256. STAGE names the instantiation for profilers (0 head, 1 tail).
+template <int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
+__global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a) {
+  typedef typename SweepVec<LW>::T V;
+  __shared__ V red[SPLIT == 1 ? 1 : SPLIT][kSweepRows][SPLIT == 1 ? 1 : 64];
+  fdl_sweep_body<kSweepRows, D, SPLIT, LW, NT>(a, reinterpret_cast<V (*)[kSweepRows][64]>(red), blockIdx.x, blockIdx.y);
+}
+
+template <int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
+static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
+  const int tiles = (a.B + 32 * LW - 1) / (32 * LW);
+  const dim3 grid(SPLIT == 1 ? (tiles + 3) / 4 : tiles, channels), block(256);
+  hipEvent_t ea, eb;
+  get_launch_events(&ea, &eb);
+  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep<SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, ea, eb, 0, a);
+  else hipLaunchKernelGGL((k_fdl_sweep<SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a);
+}
+
+template <int STAGE>
+static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
+  // few waves (a stereo pair's tail stage: 2 x 64 tiles of 128 bins): split the partitions over the waves of a workgroup
+  const bool split = (long long)((a.B + 127) / 128) * channels < 2048;
+  // 16 B per lane, 4 row pairs ahead, <= 168 VGPRs (3 waves per SIMD); measured against 8 B per lane, deeper queues,
+  // 2 / 4 waves per SIMD and non-temporal loads on MI355X: all within 3 % (profiles/r2_sweep_variants.txt)
+  if (split) { launch_variant<4, STAGE, 4, 4, 3, false>(a, channels, st); return; }
+  launch_variant<1, STAGE, 4, 4, 3, false>(a, channels, st);
+}
+
+hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st) {
+  if (channels <= 0 || a.P <= 0) return hipSuccess;
+  if (a.tag == 0) launch_stage<0>(a, channels, st);
+  else launch_stage<1>(a, channels, st);
+  return hipGetLastError();
+}
+
+}  // namespace rvc

@@ -531,11 +531,13 @@ def _random_schedule(rng, total, head, tail):
     return out
 
 
+@pytest.mark.parametrize("tiling", ["default", "force"])
 @pytest.mark.parametrize("seed", list(range(48)))
-def test_fuzz_geometry_and_call_pattern(seed):
+def test_fuzz_geometry_and_call_pattern(seed, tiling):
     """Seeded fuzz: random head/tail sizes (incl. non powers of two), IR lengths around the
     stage boundaries, 1-3 channels of different lengths, flags, and call patterns; every run is
-    compared with the oracle sample by sample."""
+    compared with the oracle sample by sample. tiling = force: the causal time tiling of the
+    block-synchronous delay lines (RVC_FLAG_FORCE_TIME_TILING) whatever the stage size."""
     rng = np.random.RandomState(1000 + seed)
     head = int(rng.choice([1, 3, 8, 24, 64, 100, 256, 512, 1024]))
     tail = int(rng.choice([max(head, 16), 2 * max(head, 8), 128, 512, 2048, 8192]))
@@ -555,7 +557,7 @@ def test_fuzz_geometry_and_call_pattern(seed):
     bg = bool(rng.randint(0, 2))
     fixed = bool(rng.randint(0, 2))
     x = np.stack([synth.synth_input(total, 5 * seed + c) for c in range(nch)])
-    s = reevr_amd.ConvolverSet(nch, bg_stream=bg, fixed_partitions=fixed)
+    s = reevr_amd.ConvolverSet(nch, bg_stream=bg, fixed_partitions=fixed, time_tiling=True if tiling == "default" else "force")
     assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
     clear_at = int(rng.randint(0, len(sched))) if rng.randint(0, 3) == 0 else -1
     got = np.empty_like(x)
@@ -580,6 +582,88 @@ def test_fuzz_geometry_and_call_pattern(seed):
         ref = max(np.sqrt(np.mean(want.astype(np.float64) ** 2)), 1e-12)
         assert err / ref <= TOL, (f"seed {seed}: head {head} tail {tail} nch {nch} ir {[len(i) for i in irs]} "
                                   f"bg {bg} fixed {fixed} clear {clear_at}: rel rms {err / ref:.3e}")
+
+
+@pytest.mark.parametrize("tiling", [True, False, "force"])
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_block_synchronous_time_tiling(seed, tiling):
+    """The plug-in's calling pattern -- one call per host block, now and then a ragged one, several calls inside one
+    block, a multi-block call or a block-aligned clear() -- over many sweep tiles (8 blocks each), with the causal
+    time tiling off, on by size (default) and forced: every output sample against the oracle."""
+    rng = np.random.RandomState(4200 + seed)
+    head = int(rng.choice([64, 128, 256, 512]))
+    tail = int(rng.choice([2 * head, 4 * head, 16 * head]))
+    nch = int(rng.randint(1, 4))
+    n_tail_parts = int(rng.choice([1, 3, 9, 20]))
+    base = 2 * tail + n_tail_parts * tail - int(rng.randint(0, tail // 2))
+    irs = [synth.synth_ir(max(1, base - c * int(rng.randint(0, tail))), 1, 300 + 3 * seed + c)[0] for c in range(nch)]
+    total = int(min(max(60 * tail, 40 * 8 * head), 300000))
+    total -= total % head
+    sched, done = [], 0
+    while done < total:
+        r = rng.randint(0, 40)
+        if r == 0:
+            n = int(rng.randint(1, head))                       # ragged: leaves the block grid ...
+        elif r == 1 and done % head:
+            n = head - done % head                              # ... and comes back to it
+        elif r == 2:
+            n = int(rng.randint(2, 6)) * head                   # a multi-block call (general path, drops the tiles)
+        elif r == 3:
+            n = int(rng.randint(5, 9)) * tail                   # a long call (adaptive path)
+        else:
+            n = head if done % head == 0 else head - done % head
+        n = max(1, min(n, total - done))
+        sched.append(n)
+        done += n
+    bg = bool(rng.randint(0, 2))
+    x = np.stack([synth.synth_input(total, 11 * seed + c) for c in range(nch)])
+    s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling=tiling)
+    assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
+    clear_at = int(rng.randint(len(sched) // 4, len(sched))) if rng.randint(0, 3) == 0 else -1
+    got = np.empty_like(x)
+    pos = start = 0
+    for i, n in enumerate(sched):
+        if i >= clear_at >= 0 and pos % head == 0 and start == 0:
+            s.clear()
+            start = pos
+        got[:, pos:pos + n] = s.process(x[:, pos:pos + n])
+        pos += n
+    assert s.last_error == 0, s.last_error_string
+    for c in range(nch):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        want = np.empty(total, np.float32)
+        want[:start] = o.process(x[c, :start]) if start else want[:0]
+        if start:
+            o.clear()
+        want[start:] = o.process(x[c, start:])
+        err = np.sqrt(np.mean((got[c].astype(np.float64) - want) ** 2))
+        ref = max(np.sqrt(np.mean(want.astype(np.float64) ** 2)), 1e-12)
+        assert err / ref <= TOL, (f"seed {seed}: head {head} tail {tail} nch {nch} ir {[len(i) for i in irs]} bg {bg} "
+                                  f"tiling {tiling} clear@{start}: rel rms {err / ref:.3e}")
+
+
+def test_time_tiling_many_channels_device_blocks():
+    """64 lock-step channels (the size at which the zero-latency stage tiles by default), block-synchronous through the
+    device entry, tiling on vs off vs the oracle on three channels."""
+    import torch
+    nch, head, tail, ir_len, nblk = 64, 512, 8192, 70000, 200
+    irs = [synth.synth_ir(ir_len, 1, 500 + c)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 40 + c) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    outs = {}
+    for tiling in (True, False):
+        s = reevr_amd.ConvolverSet(nch, time_tiling=tiling)
+        assert s.init(head, tail, irs, max_len=head)
+        outs[tiling] = s.process_device_blocks(dx, head).cpu().numpy()
+        assert s.last_error == 0
+        s.close()
+    for c in range(nch):
+        assert rel_rms(outs[True][c], outs[False][c]) <= 2e-6, c
+    for c in (0, 31, 63):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(outs[True][c], o.process(x[c])) <= TOL, c
 
 
 @pytest.mark.parametrize("seed", list(range(16)))

@@ -15,11 +15,8 @@ def one(spec):
     name, _, flags = spec.partition(":")
     out = os.path.join(ROOT, "abl_libs", name)
     os.makedirs(out, exist_ok=True)
-    cmd = [build._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-ffp-contract=fast-honor-pragmas", "-w", "-o", os.path.join(out, "libreevr_amd.so")]
-    cmd += ["-DRVC_DEV_BUILD"] + [f for f in flags.split(",") if f]
-    cmd += [os.path.join(build.CSRC, f) for f in build.SOURCES]
-    subprocess.run(cmd, check=True, cwd=build.CSRC)
+    objs = build.compile_objects(os.path.join(out, "obj"), defines=["-DRVC_DEV_BUILD", "-w"] + [f for f in flags.split(",") if f])
+    build.link_lib(objs, os.path.join(out, "libreevr_amd.so"))
     return name
 
 
