@@ -5,10 +5,18 @@ Headline workload (BASELINE.json configs[1], measured the way SURVEY.md 8d defin
 instances with a 10 s IR @ 48 kHz at host block 512 (-> head 512 / tail 8192,
 StereoConvolver.cpp:11-15), driven STRICTLY BLOCK-SYNCHRONOUSLY -- one process() call per
 512-frame host block, exactly the plug-in's calling pattern (src/PluginProcessor.cpp:1793-1797)
--- for `--channels` lock-step channels of ONE convolver set (default 512 = 256 stereo instances,
+-- for `--channels` lock-step channels of ONE convolver set (default 1024 = 512 stereo instances,
 each with its own IR). A single stereo pair moves 1.5 MB per block and cannot fill a 256-CU GPU;
-256 instances keep 4 GB of IR spectra + delay lines in HBM (>> the 256 MiB Infinity Cache), which
+512 instances keep 8 GB of IR spectra + delay lines in HBM (>> the 256 MiB Infinity Cache), which
 is the regime the per-block delay-line sweep (FFTConvolver.cpp:176-187) is HBM-bound in.
+
+Two schedules of that loop are measured in the same run, both strictly causal (nothing of a block
+is used before the block has arrived) and both with the reference's partition sizes:
+  * `value`: the engine's default, causal TIME TILING -- every 8th block a sweep reads a stage's IR
+    spectra and delay line once and leaves partial sums for the next 8 blocks, the blocks in between
+    add their few recent partitions (DESIGN.md): ~3.5x fewer HBM bytes than the reference's loop nest;
+  * `reference_schedule`: RVC_FLAG_NO_TIME_TILING, every block sweeps every partition like
+    FFTConvolver.cpp:176-187: physical bytes = SURVEY.md 8d's algorithmic bytes, frac <= 1.
 
 A "step" is `--blocks-per-step` consecutive host blocks (default 256 = 16 tail periods = 131072
 frames = 2.7 s of audio per channel): 256 per-block launches + 16 tail jobs, so every step does the
@@ -122,7 +130,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5), help="BASELINE.json configuration (1-based index)")
-    ap.add_argument("--channels", type=int, default=512, help="config 2: lock-step channels per GPU (2 per stereo instance)")
+    ap.add_argument("--channels", type=int, default=1024, help="config 2: lock-step channels per GPU (2 per stereo instance)")
+    ap.add_argument("--time-tiling", type=int, default=1, help="0: RVC_FLAG_NO_TIME_TILING (the reference's per-block sweep order)")
     ap.add_argument("--blocks-per-step", type=int, default=256, help="block-synchronous configs: host blocks per step")
     ap.add_argument("--bg-stream", type=int, default=0, help="1: tail stage on the second HIP stream")
     ap.add_argument("--gather", type=int, default=1, help="N > 1: RCCL all_gather of every step's output batch (0: off)")
@@ -201,7 +210,7 @@ def main():
     irs = make_irs(ir_len, instances)
     x = np.stack([synth.synth_input(frames_step * nbuf, 2 * u + c) for u in instances for c in range(2)])
     gen_s = time.perf_counter() - t_gen
-    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream))
+    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream), time_tiling=bool(args.time_tiling))
     t_init = time.perf_counter()
     if not conv.init(host_block, tail, irs, max_len=frames_step if long_call else host_block):
         raise SystemExit(f"init failed: {conv.last_error_string}")
@@ -287,61 +296,116 @@ def main():
     conv.kernel_time_reset()
     PA, PT = conv.partitions(0), conv.partitions(1)
     p_head, p_t0, p_t = ref_partitions(head, tail, ir_len)
-    # Algorithmic bytes per LAUNCH of each kernel family in the block-synchronous regime (SURVEY.md 8d
-    # per-unit figures x the units one launch processes = `nch` channels x one block):
-    alg = {
-        # the per-block launch does one head block of the reference's head AND tail0 sub-convolvers
-        "fused_block": float(nch * (alg_bytes_block(head, p_head) + (alg_bytes_block(head, p_t0) if p_t0 else 0))),
-        "premultiply": float(nch * 16 * PA * (head + 1)),
-        "fir_head": float(nch * 16 * PA * (head + 1)),
-        "fir_tail": float(nch * 16 * p_t * (tail + 1)),
-        "fft_fwd_head": float(nch * (4 * head + 8 * (head + 1))),
-        "fft_inv_head": float(nch * (8 * (head + 1) + 12 * head)),
-        "fft_fwd_tail": float(nch * (4 * tail + 8 * (tail + 1))),
-        "fft_inv_tail": float(nch * (8 * (tail + 1) + 12 * tail)),
-        "ingest": float(nch * 8 * host_block),
-    }
+    tiled = bool(args.time_tiling) and "sweep_tail" in kern
+    K = 8                                                # rvc::kSweepRows
+    row_h, row_t = 8.0 * head * nch, 8.0 * tail * nch    # bytes of one spectrum row of every channel
+    io_blk = nch * (4.0 * 3 * head + 4.0 * 2 * head)     # per block: input + history + tail ring read, output + ring written
+    # Bytes per LAUNCH of each kernel family. Reference schedule: SURVEY.md 8d's algorithmic figures (what the
+    # reference's loop nest moves = what these kernels move). Time-tiled schedule: the bytes of the structure
+    # actually executed, so that frac <= 1 means what it says.
+    if tiled:
+        exe = {
+            # audio part (H0, H1, X_{k-1}, accumulator read; X_k written; samples) + on average (K-1)/2 recent partitions patched
+            "fused_block": 5 * row_h + io_blk + ((K - 1) / 2.0 * 2 + 2) * row_h * (K - 1) / K,
+            "sweep_head": (PA + (PA - 2) + K) * row_h,   # IR rows + arrived delay-line rows read once, K partial rows written
+            "sweep_tail": (2 * PT + K) * row_t,
+            "fir_tail": ((K / 2.0) * 2 + 2) * row_t,      # patch: t = 1..K-1 recent partitions (mean K/2) + the sweep row, 1 row out
+            "premultiply": 2.0 * (PA - 2) * row_h + row_h,
+            "fft_fwd_tail": float(nch * (4 * 2 * tail + 8 * tail)),
+            "fft_inv_tail": float(nch * (8 * tail + 4 * tail)),
+        }
+    else:
+        exe = {
+            # the per-block launch does one head block of the reference's head AND tail0 sub-convolvers
+            "fused_block": float(nch * (alg_bytes_block(head, p_head) + (alg_bytes_block(head, p_t0) if p_t0 else 0))),
+            "premultiply": float(nch * 16 * PA * (head + 1)),
+            "fir_head": float(nch * 16 * PA * (head + 1)),
+            "fir_tail": float(nch * 16 * p_t * (tail + 1)),
+            "fft_fwd_head": float(nch * (4 * head + 8 * (head + 1))),
+            "fft_inv_head": float(nch * (8 * (head + 1) + 12 * head)),
+            "fft_fwd_tail": float(nch * (4 * tail + 8 * (tail + 1))),
+            "fft_inv_tail": float(nch * (8 * (tail + 1) + 12 * tail)),
+            "ingest": float(nch * 8 * host_block),
+        }
     traffic_all, tsrc = {}, None
     tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
     if os.path.exists(tpath) and not long_call:
         tj = json.load(open(tpath))
-        if tj.get("channels") == nch and tj.get("config") == args.config:
+        if tj.get("channels") == nch and tj.get("config") == args.config and bool(tj.get("time_tiling", 0)) == tiled:
             traffic_all = {k: v["traffic_bytes"] for k, v in tj.get("kernels", {}).items()}
             tsrc = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)"
     roof_all = {}
+    exe_bytes_step = 0.0
     for k, v in kern.items():
-        if long_call or k not in alg:
+        if long_call or k not in exe:
             continue
-        gbs = alg[k] / (v["avg_ms"] * 1e-3) / 1e9
+        gbs = exe[k] / (v["avg_ms"] * 1e-3) / 1e9
+        exe_bytes_step += exe[k] * v["launches_per_step"]
         roof_all[k] = {"launches_per_step": v["launches_per_step"], "avg_launch_ms": round(v["avg_ms"], 5),
                        "ms_per_step": round(v["avg_ms"] * v["launches_per_step"], 5),
-                       "alg_bytes_per_launch": alg[k], "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                       "bytes_per_launch": exe[k], "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                        "traffic": traffic_all.get(k)}
     roof = None
     if roof_all:
         dominant = max(roof_all, key=lambda k: roof_all[k]["ms_per_step"])      # largest share of a step
         r = roof_all[dominant]
         roof = {"bound": "hbm", "kernel": dominant, "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": r["frac"], "traffic": r["traffic"], "alg_bytes_per_launch": r["alg_bytes_per_launch"],
+                "frac": r["frac"], "traffic": r["traffic"], "bytes_per_launch": r["bytes_per_launch"],
                 "avg_launch_ms": r["avg_launch_ms"], "traffic_source": tsrc,
-                "note": "block-synchronous regime: every launch re-reads the IR spectra and the delay line of its stage once "
-                        "(16 B per partition x bin, nothing reusable across blocks that have not arrived yet), so physical "
-                        "HBM bytes ~ algorithmic bytes and frac <= 1; 8 flop per 16 B = 0.5 flop/B, far below the fp32 ridge"}
+                "note": ("time-tiled block-synchronous schedule: bytes_per_launch = the bytes of the structure this launch executes "
+                         "(a sweep reads the stage's IR spectra and arrived delay-line rows ONCE per 8 blocks; a patch / the per-block "
+                         "launch only the partitions that arrived since), averaged over the launches of its family; frac <= 1"
+                         if tiled else
+                         "reference schedule: every launch re-reads the IR spectra and the delay line of its stage once (16 B per "
+                         "partition x bin), physical HBM bytes = SURVEY.md 8d algorithmic bytes, frac <= 1") +
+                        "; 0.5-4 flop/B, far below the fp32 ridge"}
     bps = alg_bytes_per_sample(head, tail, ir_len)
     fps = flops_per_sample(head, tail, ir_len)
-    path_gbs = value / world * 1e6 * bps / 1e9
-    path = {"alg_bytes_per_sample": round(bps, 1), "achieved_GBs_per_gpu": round(path_gbs, 1),
-            "frac_of_hbm_peak": round(path_gbs / HBM_PEAK_GBS, 4),
-            "flops_per_sample": round(fps, 1), "frac_of_fp32_peak": round(value / world * 1e6 * fps / 1e12 / FP32_PEAK_TFLOPS, 4),
-            "x_realtime_per_gpu": round(value / world * 1e6 / SR, 1),
-            "note": "whole path: SURVEY.md 8d algorithmic bytes per channel-sample x measured rate (per GPU) / 8 TB/s"}
+    rate_gpu = value / world * 1e6
+    path = {"executed_bytes_per_sample": round(exe_bytes_step / (nch * frames_step), 1) if exe_bytes_step else None,
+            "executed_GBs_per_gpu": round(rate_gpu * exe_bytes_step / (nch * frames_step) / 1e9, 1) if exe_bytes_step else None,
+            "frac_of_hbm_peak": round(rate_gpu * exe_bytes_step / (nch * frames_step) / 1e9 / HBM_PEAK_GBS, 4) if exe_bytes_step else None,
+            "reference_alg_bytes_per_sample": round(bps, 1),
+            "reference_alg_GBs_equivalent": round(rate_gpu * bps / 1e9, 1),
+            "reference_alg_frac_equivalent": round(rate_gpu * bps / 1e9 / HBM_PEAK_GBS, 4),
+            "flops_per_sample": round(fps, 1), "frac_of_fp32_peak": round(rate_gpu * fps / 1e12 / FP32_PEAK_TFLOPS, 4),
+            "x_realtime_per_gpu": round(rate_gpu / SR, 1),
+            "note": "frac_of_hbm_peak = bytes the executed schedule moves per channel-sample x measured rate / 8 TB/s (<= 1). "
+                    "reference_alg_*: SURVEY.md 8d's 1497 B/sample of the REFERENCE's loop nest x the same rate -- with time tiling "
+                    "this exceeds the physical traffic by the tiling's byte saving and is a throughput equivalent, not an "
+                    "efficiency; the `reference_schedule` entry is the run where the two coincide."}
 
     side = {}
     if args.side and args.config == 2 and world == 1:
         conv.close()
+        if tiled:       # the same loop in the reference's sweep order (same channels, same inputs)
+            rconv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream), time_tiling=False)
+            assert rconv.init(host_block, tail, irs, max_len=host_block)
+
+            def rstep(i):
+                b = i % nbuf
+                rconv.process_device_blocks(d_in[:, b * frames_step:(b + 1) * frames_step], host_block,
+                                            d_out[:, b * frames_step:(b + 1) * frames_step], sync=False, order=False)
+            for i in range(pre + 1):
+                rstep(i)
+            rconv.sync()
+            rsteps = max(2, args.steps // 4)
+            tr = time.perf_counter()
+            for i in range(rsteps):
+                rstep(i)
+            rconv.sync()
+            tr = time.perf_counter() - tr
+            rrate = nch * frames_step * rsteps / tr
+            side["reference_schedule"] = {
+                "value": round(rrate / 1e6, 3), "unit": "Msamples/s", "steps": rsteps, "ms_per_step": round(tr / rsteps * 1e3, 4),
+                "alg_bytes_per_sample": round(bps, 1), "achieved_GBs": round(rrate * bps / 1e9, 1),
+                "frac_of_hbm_peak": round(rrate * bps / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "RVC_FLAG_NO_TIME_TILING: same channels / inputs / call pattern, every 512-frame block sweeps all 32 + 57 "
+                        "partitions (FFTConvolver.cpp:176-187): physical bytes = SURVEY.md 8d algorithmic bytes"}
+            rconv.close()
         del d_in, d_out
         torch.cuda.empty_cache()
-        side = side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail)
+        side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
     cpu = None
     if world == 1 and args.cpu_seconds > 0 and args.config == 2:
         cores = os.cpu_count() or 1
@@ -360,6 +424,8 @@ def main():
                    "calls_per_step": 1 if long_call else frames_step // host_block,
                    "partitions": {"head+tail0 (block %d)" % head: PA, "tail (block %d)" % tail: PT},
                    "resident_GB": round(nch * 8.0 * (PA * head + (PT + 2) * tail) * 2 / 1e9, 2),
+                   "schedule": "long call" if long_call else ("causal time tiling (8-block sweeps + patches)" if tiled
+                                                                else "reference order (RVC_FLAG_NO_TIME_TILING)"),
                    "call": ("one process() per step" if long_call else
                             "one process_device() per 512-frame host block for all channels (rvc_set_process_device_blocks), "
                             "device-resident I/O, %d input/output batches rotated" % nbuf),

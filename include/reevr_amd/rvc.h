@@ -167,7 +167,8 @@ const char *rvc_last_error_string(const rvc_set *s);
 
 /* With RVC_FLAG_TIMING: accumulated HIP-event time of one kernel family since the last
  * rvc_set_kernel_time_reset. kernel: 0 ingest, 1 fft_fwd(head) 2 fir(head) 3 fft_inv(head),
- * 4 fft_fwd(tail) 5 fir(tail) 6 fft_inv(tail), 7 fused single-block step, 8 pre-multiply.
+ * 4 fft_fwd(tail) 5 fir(tail; time-tiled streaming: the patch launches) 6 fft_inv(tail), 7 fused single-block step,
+ * 8 pre-multiply, 9 sweep(head) 10 sweep(tail) of the time-tiled delay lines.
  * Synchronises the set. Returns launches. */
 long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms);
 void rvc_set_kernel_time_reset(rvc_set *s);

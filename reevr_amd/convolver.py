@@ -236,7 +236,7 @@ class ConvolverSet:
 
 
 KERNEL_NAMES = ["ingest", "fft_fwd_head", "fir_head", "fft_inv_head", "fft_fwd_tail", "fir_tail", "fft_inv_tail",
-                "fused_block", "premultiply"]
+                "fused_block", "premultiply", "sweep_head", "sweep_tail"]
 
 
 class _Mono:

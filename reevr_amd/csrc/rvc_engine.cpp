@@ -40,7 +40,7 @@
 namespace {
 
 constexpr double kPi = 3.14159265358979323846264338327950288;
-constexpr int kNumKernelIds = 9;
+constexpr int kNumKernelIds = 11;
 
 size_t next_pow2(size_t v) {   // Utilities.h:280-289
   size_t p = 1;
@@ -615,7 +615,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
     } else {
       r.M = (int)K; r.Y = s->sT; r.y_chan_stride = sTstride; r.y_row_mask = (unsigned)(K - 1);
       r.x_hi = m_lo - 2;                           // newest delay-line row that exists
-      Timer tm(s, 5, st);
+      Timer tm(s, 10, st);
       RVC_CK(rvc::launch_fdl_sweep(r, s->nch, st));
       s->st_t0 = m_lo;
       yrows = s->sT + (size_t)((unsigned long long)m_lo & (unsigned long long)(K - 1)) * tb;
@@ -776,7 +776,7 @@ bool run_premultiply(rvc_set *s, long long kb) {
   if (s->tile_A) {    // (state was invalidated: a stand-alone sweep starts a new tile at kb)
     const rvc::FirArgs r = head_sweep_args(s, kb);
     {
-      Timer t(s, 8, s->st_main);
+      Timer t(s, 9, s->st_main);
       RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
     }
     s->sa_t0 = kb;

@@ -890,6 +890,20 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
     if (live && m_in) ring[(unsigned long long)m & a.ring_mask] = s1;
     v[e] = mk<float>(s0, s1);
   }
+  // (FOLD) yp = Ypre + H_1 X_{k-1} needs nothing of this block: formed now, so that only ONE accumulator row per value
+  // stays live across the transform (48 VGPRs fewer -> more of the appended workgroups resident beside the audio waves)
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      if (fold) {
+        const float2 g = h1[e], x = xp[e];
+        float2 yp = ypre[e];
+        if (P::out_idx(tid, e) == 0) yp = make_float2(fmaf(g.x, x.x, yp.x), fmaf(g.y, x.y, yp.y));
+        else yp = make_float2(fmaf(g.x, x.x, fmaf(-g.y, x.y, yp.x)), fmaf(g.x, x.y, fmaf(g.y, x.x, yp.y)));
+        ypre[e] = yp;
+      }
+    }
+  }
   // 2. forward transform, real split; X_k goes to the delay line and, times H0 plus the
   //    pre-multiplied accumulator, becomes Y_k
   fft8_core<LOGB, false, float>(v, lds, T, tid);
@@ -904,14 +918,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
     const int k = P::out_idx(tid, e);
     const C A = v[e];
     const float2 h = h0[e];
-    float2 yp = ypre[e];
-    if constexpr (FOLD) {
-      if (fold) {                                                     // + H_1 X_{k-1}
-        const float2 g = h1[e], x = xp[e];
-        if (k == 0) yp = make_float2(fmaf(g.x, x.x, yp.x), fmaf(g.y, x.y, yp.y));
-        else yp = make_float2(fmaf(g.x, x.x, fmaf(-g.y, x.y, yp.x)), fmaf(g.x, x.y, fmaf(g.y, x.x, yp.y)));
-      }
-    }
+    const float2 yp = ypre[e];                                        // (+ H_1 X_{k-1} already folded in above)
     if (k == 0) {
       const float2 X = make_float2(A.x + A.y, A.x - A.y);             // packed (DC, Nyquist)
       if (live) Xrow[0] = X;
@@ -1360,6 +1367,8 @@ template <int LOGB>
 __global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256))
 k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int fir_bx) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // (The audio workgroups lead the grid: they are the latency path. Letting the accumulator workgroups lead instead
+  // was measured for 512 / 1024 channels: 13.8 -> 15.8 / 18.1 -> 27.0 us per launch.)
   if ((int)blockIdx.x < n_audio) {
     if ((int)threadIdx.x >= Plan8<LOGB>::WG) return;
     fused_audio<LOGB, true>(a, smem_raw, blockIdx.x);

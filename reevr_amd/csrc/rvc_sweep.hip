@@ -9,6 +9,8 @@
 // at ~1/3 VALU utilisation cost nothing.
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "rvc_internal.h"
 
 namespace rvc {
@@ -174,11 +176,25 @@ static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
 template <int STAGE>
 static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
   // few waves (a stereo pair's tail stage: 2 x 64 tiles of 128 bins): split the partitions over the waves of a workgroup
-  const bool split = (long long)((a.B + 127) / 128) * channels < 2048;
-  // 16 B per lane, 4 row pairs ahead, <= 168 VGPRs (3 waves per SIMD); measured against 8 B per lane, deeper queues,
-  // 2 / 4 waves per SIMD and non-temporal loads on MI355X: all within 3 % (profiles/r2_sweep_variants.txt)
+  // ... and for large partitions (the tail stage): measured 10 % faster there on MI355X, 15 % slower on 512-bin rows
+  const bool split = (long long)((a.B + 127) / 128) * channels < 2048 || a.B >= 2048;
+  // 16 B per lane, 4 row pairs ahead, <= 168 VGPRs (3 waves per SIMD), non-temporal loads on the own-tile form; measured
+  // against 8 B per lane, deeper queues, 2 / 4 waves per SIMD on MI355X (profiles/r2_sweep_variants.txt)
   if (split) { launch_variant<4, STAGE, 4, 4, 3, false>(a, channels, st); return; }
-  launch_variant<1, STAGE, 4, 4, 3, false>(a, channels, st);
+#ifdef RVC_DEV_BUILD   // tuning knob of development builds only (tools/abl_build.py)
+  static const int variant = std::getenv("RVC_SWEEP_VARIANT") ? std::atoi(std::getenv("RVC_SWEEP_VARIANT")) : 0;
+  switch (variant) {
+    case 1: launch_variant<1, STAGE, 4, 4, 3, true>(a, channels, st); return;    // + non-temporal loads
+    case 2: launch_variant<1, STAGE, 2, 8, 4, false>(a, channels, st); return;   // 8 B per lane, 8 ahead, 4 waves/SIMD
+    case 3: launch_variant<1, STAGE, 2, 8, 4, true>(a, channels, st); return;
+    case 4: launch_variant<4, STAGE, 4, 4, 3, false>(a, channels, st); return;   // partitions split over the 4 waves
+    case 5: launch_variant<4, STAGE, 4, 4, 3, true>(a, channels, st); return;
+    case 6: launch_variant<4, STAGE, 2, 8, 4, false>(a, channels, st); return;
+    case 7: launch_variant<4, STAGE, 2, 8, 4, true>(a, channels, st); return;
+    default: break;
+  }
+#endif
+  launch_variant<1, STAGE, 4, 4, 3, true>(a, channels, st);
 }
 
 hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st) {
