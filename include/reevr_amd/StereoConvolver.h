@@ -38,9 +38,11 @@ struct Impulse {
 
 class StereoConvolver {
  public:
-  explicit StereoConvolver(int device = 0)
-      : _main(rvc_set_create(2, device, RVC_FLAG_BG_STREAM)),
-        _cross(rvc_set_create(2, device, RVC_FLAG_BG_STREAM)) {}
+  // flags: RVC_FLAG_* of rvc.h for both channel pairs (default: tail stage on the second stream, like the reference's
+  // background thread; add RVC_FLAG_PERSISTENT for the resident per-block kernel)
+  explicit StereoConvolver(int device = 0, unsigned flags = RVC_FLAG_BG_STREAM)
+      : _main(rvc_set_create(2, device, flags)),
+        _cross(rvc_set_create(2, device, flags)) {}
   ~StereoConvolver() {
     rvc_set_destroy(_main);
     rvc_set_destroy(_cross);

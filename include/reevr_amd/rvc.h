@@ -72,6 +72,13 @@ enum {
                                    between add their few recent partitions: same sums, same zero latency, ~3.5x fewer
                                    HBM bytes where the path is bandwidth-bound (many lock-step channels). */
 
+#define RVC_FLAG_PERSISTENT 64u  /* per-block calls (a call inside one head block, head block 512 ... 4096) are served by ONE
+                                   RESIDENT kernel fed through a doorbell in pinned host memory instead of one launch per
+                                   block (the loop of TwoStageFFTConvolver.cpp:151-233): no launch on the latency path.
+                                   The kernel parks itself after 2 s without a call and is relaunched by the next one.
+                                   Device-pointer calls are pipelined: rvc_set_sync() is the only completion point
+                                   (the resident kernel is not on rvc_set_stream). Other call patterns fall back to
+                                   ordinary launches. */
 #define RVC_FLAG_FORCE_TIME_TILING 32u /* testing: time-tile every stage that has partitions to tile, however small
                                    (by default only stages whose per-block sweep is long enough to be bandwidth-bound) */
 
@@ -297,6 +304,12 @@ int rvc_send_pre_device(int device, void *stream, const rvc_send_params *p);
  * 1/n total on the inverse. Host buffers; synchronous; for tests, not for the audio path. 1 = ok. */
 int rvc_debug_rfft(int device, size_t n, int f64, const float *data, float *re, float *im);
 int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re, const float *im);
+
+/* RVC_FLAG_PERSISTENT diagnostics: 100 MHz device timestamps of the resident kernel's last step (doorbell seen, command
+ * fetched, accumulator ready, step done) and its sequence number. 1 = ok. */
+int rvc_debug_persist_stamps(rvc_set *s, unsigned long long *out5);
+/* ... and the median host -> resident kernel -> host round trip of n empty commands, microseconds (-1: not persistent). */
+double rvc_debug_persist_rtt(rvc_set *s, int n);
 
 /* Number of visible HIP devices (0 when there is none or the runtime cannot start). */
 int rvc_device_count(void);

@@ -20,6 +20,7 @@ RVC_FLAG_FFT_F64 = 4
 RVC_FLAG_FIXED_PARTITIONS = 8
 RVC_FLAG_NO_TIME_TILING = 16
 RVC_FLAG_FORCE_TIME_TILING = 32
+RVC_FLAG_PERSISTENT = 64
 RVC_MAX_BLOCK = 16384
 
 # name -> (restype, argtypes); must list every symbol declared in include/reevr_amd/rvc.h
@@ -78,6 +79,8 @@ SIGNATURES = {
     "rvc_send_pre_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "rvc_debug_rfft": (C.c_int, [C.c_int, C.c_size_t, C.c_int, F32P, F32P, F32P]),
     "rvc_debug_irfft": (C.c_int, [C.c_int, C.c_size_t, C.c_int, F32P, F32P, F32P]),
+    "rvc_debug_persist_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
+    "rvc_debug_persist_rtt": (C.c_double, [C.c_void_p, C.c_int]),
     "rvc_device_count": (C.c_int, []),
     "rvc_version": (C.c_char_p, []),
 }

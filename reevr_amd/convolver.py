@@ -33,13 +33,15 @@ class ConvolverSet:
     """n independent mono convolvers sharing one block geometry (one launch per stage)."""
 
     def __init__(self, n_channels: int, device: int = 0, bg_stream: bool = False, timing: bool = False,
-                 fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True):
+                 fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True, persistent: bool = False):
         self._lib = L.lib()
         flags = ((L.RVC_FLAG_BG_STREAM if bg_stream else 0) | (L.RVC_FLAG_TIMING if timing else 0)
                  | (L.RVC_FLAG_FFT_F64 if fft_f64 else 0)
                  | (L.RVC_FLAG_FIXED_PARTITIONS if fixed_partitions else 0)
                  | (0 if time_tiling else L.RVC_FLAG_NO_TIME_TILING)
-                 | (L.RVC_FLAG_FORCE_TIME_TILING if time_tiling == "force" else 0))
+                 | (L.RVC_FLAG_FORCE_TIME_TILING if time_tiling == "force" else 0)
+                 | (L.RVC_FLAG_PERSISTENT if persistent else 0))
+        self.persistent = bool(persistent)
         self.n_channels = int(n_channels)
         self.device = int(device)
         self._h = self._lib.rvc_set_create(self.n_channels, self.device, flags)
@@ -151,7 +153,7 @@ class ConvolverSet:
         ext = self._order_after_torch() if order else None
         self._lib.rvc_set_process_device(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(),
                                          d_out.stride(0), d_in.shape[1])
-        if sync:
+        if sync or self.persistent:     # (persistent mode: completion is only observable through sync)
             self.sync()
             self.check()
         else:
@@ -171,7 +173,7 @@ class ConvolverSet:
         ext = self._order_after_torch() if order else None
         self._lib.rvc_set_process_device_blocks(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(),
                                                 d_out.stride(0), d_in.shape[1], block)
-        if sync:
+        if sync or self.persistent:
             self.sync()
             self.check()
         else:

@@ -113,6 +113,21 @@ struct rvc_set {
   long long sa_t0 = -1, st_t0 = -1;        // blocks [t0, t0 + kSweepRows) have sweep rows; -1: none
   const float2 *ypre_cur = nullptr;        // where the accumulator of block ypre_block lives: a ypre half or a sweep row
   long long ypre_cur_stride = 0;
+  int sa_rows = 0;                         // rows of sA per channel (kSweepRows; twice that in persistent mode)
+  // Persistent block-synchronous kernel (RVC_FLAG_PERSISTENT; rvc_internal.h PkArgs)
+  bool pk_enabled = false, pk_running = false, pk_slot = false;
+  rvc::PkCtl *pk_ctl = nullptr;            // pinned host: doorbell + command ring
+  unsigned *pk_ypre_seq = nullptr, *pk_park = nullptr, *pk_x_seq = nullptr;   // device
+  unsigned *h_pdone = nullptr;             // pinned host: completion flags of the patch workgroups
+  float2 *pk_zero_row = nullptr;           // [nch][B] zeros: the accumulator of blocks 0 and 1 after the clock restarted
+  hipStream_t st_pk = nullptr;
+  int pk_n_audio = 0, pk_n_patch = 0;
+  unsigned pk_seq = 0, pk_retired = 0;     // last command pushed / last one whose block has been retired
+  struct PkStep { long long n0, n1, k; bool block_done; } pk_steps[rvc::kPkRing];
+  long long pk_tile_hi = -1, pk_tile_ready = -1;   // sweeps launched / known complete for every tile start <= this
+  hipEvent_t ev_sweep = nullptr;
+  bool pk_need_acquire = false;
+  unsigned pk_ypre_from = 0;               // step whose patch produces the accumulator of block ypre_block (0: a launch)
   float *d_in = nullptr, *d_out = nullptr;     // staging for the host-pointer API [nch][max_len]
   float *h_in = nullptr, *h_out = nullptr;     // pinned
   long long n = 0;               // absolute sample clock
@@ -182,6 +197,14 @@ bool ensure_streams(rvc_set *s) {
   RVC_CK(rvc::prepare_kernels());
   RVC_CK(hipStreamCreateWithFlags(&s->st_main, hipStreamNonBlocking));
   RVC_CK(hipStreamCreateWithFlags(&s->st_bg, hipStreamNonBlocking));
+  {
+    // the resident kernel gets a stream of its own priority class: the runtime multiplexes streams of one class onto a
+    // few hardware queues, and an ordinary launch queued behind a kernel that never ends would never start
+    int lo = 0, hi = 0;
+    RVC_CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    RVC_CK(hipStreamCreateWithPriority(&s->st_pk, hipStreamNonBlocking, hi));
+  }
+  RVC_CK(hipEventCreateWithFlags(&s->ev_sweep, hipEventDisableTiming));
   RVC_CK(hipEventCreateWithFlags(&s->ev_ingest, hipEventDisableTiming));
   RVC_CK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
   for (s->ev_free = 0; s->ev_free < rvc_set::kMaxJobs; ++s->ev_free)
@@ -226,7 +249,18 @@ void drop_timing(rvc_set *s) {
   }
 }
 
+void pk_stop(rvc_set *s);
+bool pk_acquire_slot();
+void pk_release_slot(rvc_set *s);
+
 void free_device_state(rvc_set *s) {
+  pk_stop(s);
+  pk_release_slot(s);
+  if (s->pk_ctl) hipHostFree(s->pk_ctl);
+  if (s->h_pdone) hipHostFree(s->h_pdone);
+  hipFree(s->pk_ypre_seq); hipFree(s->pk_park); hipFree(s->pk_zero_row); hipFree(s->pk_x_seq);
+  s->pk_ctl = nullptr; s->h_pdone = nullptr; s->pk_ypre_seq = s->pk_park = s->pk_x_seq = nullptr; s->pk_zero_row = nullptr;
+  s->pk_enabled = false;
   if (s->streams_ok) {
     hipSetDevice(s->device);
     hipStreamSynchronize(s->st_bg);
@@ -425,6 +459,9 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   if (s->live && s->two_stage == two_stage && s->head == hb && s->tail == tail_pub && s->max_len == eff_max_len &&
       s->A.P == (int)pa && s->T.P == (int)pt && s->T.PF == (int)pf && s->W.P == (int)pw) {
     if (!use_device(s)) return false;
+    pk_stop(s);                                   // (the IR spectra change: the resident kernel is relaunched by the next call)
+    s->pk_tile_hi = s->pk_tile_ready = -1;
+    s->pk_ypre_from = 0;
     hipStreamSynchronize(s->st_bg);
     hipStreamSynchronize(s->st_main);
     drop_jobs(s);
@@ -493,7 +530,33 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     s->tile_A = tiling && s->fold && A.B >= 64 &&
                 (force ? pa >= 3 : (pa >= 16 && (size_t)s->nch * (pa - 2) * A.B * 16 >= ((size_t)4 << 20)));
     s->tile_T = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
-    if (s->tile_A) RVC_CK(hipMalloc(&s->sA, sizeof(float2) * (size_t)s->nch * K * A.B));
+    // persistent mode: the resident kernel only ever adds a few recent partitions, so the zero-latency stage is tiled
+    bool pk = (s->flags & RVC_FLAG_PERSISTENT) != 0 && tiling && s->fold && rvc::persist_supported(A.logB) && pa >= 3;
+    if (pk && !s->pk_slot) pk = s->pk_slot = pk_acquire_slot();     // (none left: this set uses ordinary launches)
+    if (pk) s->tile_A = true;
+    s->pk_enabled = pk;
+    s->sa_rows = (int)K * (pk ? 2 : 1);
+    if (s->tile_A) RVC_CK(hipMalloc(&s->sA, sizeof(float2) * (size_t)s->nch * (size_t)s->sa_rows * A.B));
+    if (pk) {
+      rvc::persist_workgroups(A.logB, s->nch, &s->pk_n_audio, nullptr);
+      s->pk_n_patch = rvc::persist_workgroups(A.logB, s->nch, nullptr, nullptr) - s->pk_n_audio;
+      RVC_CK(hipHostMalloc(&s->pk_ctl, sizeof(rvc::PkCtl), hipHostMallocDefault));
+      std::memset((void *)s->pk_ctl, 0, sizeof(rvc::PkCtl));
+      RVC_CK(hipHostMalloc(&s->h_pdone, sizeof(unsigned) * (size_t)s->pk_n_patch, hipHostMallocDefault));
+      std::memset(s->h_pdone, 0, sizeof(unsigned) * (size_t)s->pk_n_patch);
+      RVC_CK(hipMalloc(&s->pk_ypre_seq, sizeof(unsigned) * (size_t)s->pk_n_patch));
+      RVC_CK(hipMemset(s->pk_ypre_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_patch));
+      RVC_CK(hipMalloc(&s->pk_x_seq, sizeof(unsigned) * (size_t)s->pk_n_audio));
+      RVC_CK(hipMemset(s->pk_x_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_audio));
+      RVC_CK(hipMalloc(&s->pk_park, sizeof(unsigned)));
+      RVC_CK(hipMemset(s->pk_park, 0, sizeof(unsigned)));
+      RVC_CK(hipMalloc(&s->pk_zero_row, sizeof(float2) * (size_t)s->nch * A.B));
+      RVC_CK(hipMemset(s->pk_zero_row, 0, sizeof(float2) * (size_t)s->nch * A.B));
+      s->pk_seq = s->pk_retired = 0;
+      s->pk_tile_hi = s->pk_tile_ready = -1;
+      s->pk_need_acquire = false;
+      s->pk_ypre_from = 0;
+    }
     if (s->tile_T) RVC_CK(hipMalloc(&s->sT, sizeof(float2) * (size_t)s->nch * K * T.B));
     s->sa_t0 = s->st_t0 = -1;
   }
@@ -501,10 +564,11 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   RVC_CK(hipMalloc(&s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipHostMalloc(&s->h_in, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
   RVC_CK(hipHostMalloc(&s->h_out, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
-  RVC_CK(hipHostMalloc(&s->h_flags, sizeof(unsigned) * (size_t)s->nch, hipHostMallocDefault));
+  RVC_CK(hipHostMalloc(&s->h_flags, sizeof(unsigned) * (size_t)s->nch, hipHostMallocDefault));   // (>= audio workgroups)
   std::memset(s->h_flags, 0, sizeof(unsigned) * (size_t)s->nch);
   s->flag_seq = 0; s->flag_count = 0;
-  RVC_CK(hipDeviceSynchronize());
+  RVC_CK(hipStreamSynchronize(s->st_main));      // (not hipDeviceSynchronize: other sets' resident kernels never finish)
+  RVC_CK(hipStreamSynchronize(s->st_bg));
   s->n = 0;
   s->tail_fft_done = 0;
   s->tail_out_done = 2;
@@ -760,16 +824,16 @@ rvc::FirArgs premultiply_args(rvc_set *s, long long kb) {
 // over the input rows that exist (<= kb - 2); row kb is complete (= sum_{i>=2} H_i X_{kb-i}).
 rvc::FirArgs head_sweep_args(rvc_set *s, long long kb) {
   Stage &A = s->A;
-  const long long K = rvc::kSweepRows;
+  const long long K = rvc::kSweepRows, R = s->sa_rows;
   rvc::FirArgs r{};
   r.H = A.H; r.h_chan_stride = (long long)A.P * (long long)A.B;
   r.X = A.X; r.x_chan_stride = (long long)A.rows * (long long)A.B; r.x_row_mask = A.rows - 1;
-  r.Y = s->sA; r.y_chan_stride = K * (long long)A.B; r.y_row_mask = (unsigned)(K - 1);
+  r.Y = s->sA; r.y_chan_stride = R * (long long)A.B; r.y_row_mask = (unsigned)(R - 1);
   r.k0 = kb; r.M = (int)K; r.P = A.P; r.delay = 0; r.B = (int)A.B; r.x_hi = kb - 2;
   return r;
 }
 const float2 *head_sweep_row(const rvc_set *s, long long k) {
-  return s->sA + (size_t)((unsigned long long)k & (unsigned long long)(rvc::kSweepRows - 1)) * s->A.B;
+  return s->sA + (size_t)((unsigned long long)k & (unsigned long long)(s->sa_rows - 1)) * s->A.B;
 }
 
 bool run_premultiply(rvc_set *s, long long kb) {
@@ -822,6 +886,278 @@ void mark_long_stage_stale(rvc_set *s, long long n1) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Persistent block-synchronous mode (RVC_FLAG_PERSISTENT): host side of k_persist. One command per per-block
+// call goes into the ring in pinned host memory; sweeps and tail jobs stay ordinary launches, issued here when a
+// block RETIRES (its audio workgroups have published their completion flags).
+// ------------------------------------------------------------------------------------------
+constexpr double kPkHostTimeoutS = 5.0;
+// Resident kernels of one process share the few hardware queues of their priority class: more than this many at once
+// could queue one behind another (and wait for it to park). Further persistent sets use ordinary launches.
+constexpr int kPkMaxResident = 2;
+std::atomic<int> g_pk_resident{0};
+
+void pk_push(rvc_set *s, const rvc::PkCmd &c) {
+  rvc::PkCtl *ctl = s->pk_ctl;
+  volatile unsigned long long *slot = reinterpret_cast<volatile unsigned long long *>(&ctl->ring[c.seq % rvc::kPkRing]);
+  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&c);
+  // the device polls the slot itself: each 64-byte line gets its payload first and its sequence word last
+  for (int i = 0; i < 7; ++i) slot[i] = src[i];
+  for (int i = 8; i < 15; ++i) slot[i] = src[i];
+  std::atomic_thread_fence(std::memory_order_release);
+  slot[7] = c.seq;
+  slot[15] = c.seq;
+  std::atomic_thread_fence(std::memory_order_release);
+  ctl->doorbell = c.seq;                                     // (informational: newest command)
+}
+
+bool pk_launch(rvc_set *s, unsigned seq0) {
+  Stage &A = s->A, &T = s->T;
+  const bool has_tail = T.P > 0;
+  const long long hb = (long long)A.B;
+  RVC_CK(hipMemsetAsync(s->pk_park, 0, sizeof(unsigned), s->st_pk));
+  s->pk_ctl->parked = 0;
+  rvc::PkArgs a{};
+  a.fa.ring = s->xring; a.fa.ring_chan_stride = (long long)s->ring_cap; a.fa.ring_mask = s->ring_cap - 1;
+  a.fa.tw = A.tw; a.fa.wsplit = A.wsplit; a.fa.tw8 = A.tw8;
+  a.fa.H0 = A.H; a.fa.h_chan_stride = (long long)A.P * hb;
+  a.fa.H1 = A.P > 1 ? A.H + hb : nullptr;
+  a.fa.Xrow = A.X; a.fa.x_chan_stride = (long long)A.rows * hb; a.fa.x_row_mask = A.rows - 1;
+  a.fa.add = has_tail ? s->tailring : nullptr;
+  a.fa.add_chan_stride = (long long)s->ring_cap; a.fa.add_mask = s->ring_cap - 1;
+  a.fa.add_from = has_tail ? 2 * (long long)T.B : 0;
+  a.pf.H = A.H + 2 * hb; a.pf.h_chan_stride = (long long)A.P * hb;
+  a.pf.X = A.X; a.pf.x_chan_stride = (long long)A.rows * hb; a.pf.x_row_mask = A.rows - 1;
+  a.pf.delay = 2; a.pf.B = (int)hb; a.pf.M = 1;
+  a.ctl = s->pk_ctl; a.ypre_seq = s->pk_ypre_seq; a.x_seq = s->pk_x_seq; a.park = s->pk_park;
+  a.h_done = s->h_flags; a.h_pdone = s->h_pdone;
+  a.seq0 = seq0;
+  a.idle_ticks = (long long)(2.0 * 1e8);                     // 2 s of a silent doorbell: the kernel parks itself
+  if (const char *e = std::getenv("RVC_PERSIST_IDLE_MS")) a.idle_ticks = (long long)(std::atof(e) * 1e5);
+  RVC_CK(rvc::launch_persist(A.logB, a, s->nch, s->st_pk));
+  s->pk_running = true;
+  return true;
+}
+
+// a slot among the process's resident kernels (taken at init, returned when the set's device state goes)
+bool pk_acquire_slot() {
+  int cur = g_pk_resident.load();
+  while (cur < kPkMaxResident)
+    if (g_pk_resident.compare_exchange_weak(cur, cur + 1)) return true;
+  return false;
+}
+void pk_release_slot(rvc_set *s) {
+  if (s->pk_slot) { g_pk_resident.fetch_sub(1); s->pk_slot = false; }
+}
+
+// the kernel parked itself (idle) or hit an internal error: collect it; commands after the last retired one replay
+bool pk_collect(rvc_set *s) {
+  if (!s->pk_running) return true;
+  RVC_CK(hipStreamSynchronize(s->st_pk));
+  s->pk_running = false;
+  if (s->pk_ctl->error) {
+    char buf[96];
+    snprintf(buf, sizeof(buf), "persistent kernel gave up (code 0x%llx)", (unsigned long long)s->pk_ctl->error);
+    s->pk_ctl->error = 0;
+    if (s->err == RVC_OK) { s->err = RVC_ERR_HIP; s->errstr = buf; }
+    return false;
+  }
+  return true;
+}
+
+bool pk_ensure_running(rvc_set *s) {
+  if (s->pk_running && (s->pk_ctl->parked || s->pk_ctl->error)) { if (!pk_collect(s)) return false; }
+  if (!s->pk_running) return pk_launch(s, s->pk_retired);   // (every step is idempotent: unretired ones simply run again)
+  return true;
+}
+
+// wait until every workgroup of the given kind has completed step `seq`
+bool pk_wait_flags(rvc_set *s, volatile unsigned *f, int n, unsigned seq) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n; ++i) {
+    unsigned spins = 0;
+    while ((int)(f[i] - seq) < 0) {
+      if ((++spins & 0xfffu) == 0) {
+        if (!s->pk_running || s->pk_ctl->parked || s->pk_ctl->error) {   // parked under our feet: relaunch, the steps run again
+          if (!pk_ensure_running(s)) return false;
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kPkHostTimeoutS)
+          return fail(s, RVC_ERR_HIP, hipSuccess, "persistent kernel: completion flag timeout");
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return true;
+}
+
+void pk_launch_sweep(rvc_set *s, long long t0) {   // the tile [t0, t0 + K): partial sums over the rows <= t0 - 2 - lag
+  rvc::FirArgs r = head_sweep_args(s, t0);
+  r.x_hi = t0 - 2 - rvc::kPkLag;
+  (void)rvc::launch_fdl_sweep(r, s->nch, s->st_main);
+  (void)hipEventRecord(s->ev_sweep, s->st_main);
+  s->pk_tile_hi = t0;
+}
+
+// post-actions of the steps up to `seq`, in order, once their audio workgroups are done: the tail job of a completed
+// tail block and the sweep of the tile that starts 2 + lag blocks later
+bool pk_retire_upto(rvc_set *s, unsigned seq) {
+  const long long K = rvc::kSweepRows;
+  while ((int)(seq - s->pk_retired) > 0) {
+    const unsigned r = s->pk_retired + 1;
+    if (!pk_wait_flags(s, s->h_flags, s->pk_n_audio, r)) return false;
+    const rvc_set::PkStep &st = s->pk_steps[r % rvc::kPkRing];
+    s->pk_retired = r;
+    if (st.block_done) {
+      if (s->T.P > 0 && !run_tail_job(s, st.n0, st.n1, nullptr, 0, /*bg=*/true)) return false;
+      const long long t0 = st.k + 2 + rvc::kPkLag;
+      if (t0 % K == 0 && t0 > s->pk_tile_hi) pk_launch_sweep(s, t0);
+    }
+  }
+  return true;
+}
+
+// every command consumed by every workgroup (before ordinary launches touch the shared buffers, clear, destroy)
+bool pk_quiesce(rvc_set *s) {
+  if (!s->pk_enabled || s->pk_seq == 0) return true;
+  if (!pk_retire_upto(s, s->pk_seq)) return false;
+  return pk_wait_flags(s, s->h_pdone, s->pk_n_patch, s->pk_seq);
+}
+
+void pk_stop(rvc_set *s) {
+  if (!s->pk_enabled || !s->pk_ctl) return;
+  if (s->pk_running) {
+    if (!(s->pk_ctl->parked || s->pk_ctl->error)) {
+      (void)pk_quiesce(s);
+      rvc::PkCmd c{};
+      c.flags = rvc::PK_QUIT;
+      c.seq = ++s->pk_seq;
+      pk_push(s, c);
+    }
+    hipStreamSynchronize(s->st_pk);
+    s->pk_running = false;
+  }
+  s->pk_retired = s->pk_seq;
+  // nothing is resident any more: every flag stands at the last sequence number (the quit command is never acknowledged)
+  for (int i = 0; i < s->pk_n_audio && s->h_flags; ++i) s->h_flags[i] = s->pk_seq;
+  for (int i = 0; i < s->pk_n_patch && s->h_pdone; ++i) s->h_pdone[i] = s->pk_seq;
+  if (s->pk_ypre_seq && s->streams_ok) {
+    std::vector<unsigned> v((size_t)std::max(s->pk_n_patch, s->pk_n_audio), s->pk_seq);
+    hipMemcpy(s->pk_ypre_seq, v.data(), sizeof(unsigned) * (size_t)s->pk_n_patch, hipMemcpyHostToDevice);
+    hipMemcpy(s->pk_x_seq, v.data(), sizeof(unsigned) * (size_t)s->pk_n_audio, hipMemcpyHostToDevice);
+  }
+}
+
+// waitForBackgroundProcessing on the HOST: the resident kernel is on no stream that could wait for an event
+bool pk_wait_tail(rvc_set *s, long long n1) {
+  const long long m_need = (n1 - 1) / (long long)s->T.B;
+  while (s->job_count > 0 && m_need >= 2) {
+    const rvc_set::Job j = s->jobs[s->job_head];
+    RVC_CK(hipEventSynchronize(j.ev));
+    s->job_head = (s->job_head + 1) % rvc_set::kMaxJobs;
+    --s->job_count;
+    s->ev_pool[s->ev_free++] = j.ev;
+    if (j.m_hi > m_need) break;
+  }
+  return true;
+}
+
+// one per-block call (inside head block k0) through the resident kernel
+bool pk_step(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len) {
+  Stage &A = s->A, &T = s->T;
+  const long long hb = (long long)A.B, K = rvc::kSweepRows;
+  const long long n0 = s->n, n1 = n0 + (long long)len, k0 = n0 / hb;
+  const bool block_done = n1 % hb == 0;
+  const bool has_tail = T.P > 0;
+  // keep the ring shallow, retire what has completed (launches sweeps / tail jobs on time)
+  while (s->pk_seq - s->pk_retired >= (unsigned)(rvc::kPkRing / 4))
+    if (!pk_retire_upto(s, s->pk_retired + 1)) return false;
+  while (s->pk_retired != s->pk_seq) {
+    const unsigned r = s->pk_retired + 1;
+    bool done = true;
+    for (int i = 0; i < s->pk_n_audio && done; ++i) done = (int)(((volatile unsigned *)s->h_flags)[i] - r) >= 0;
+    if (!done) break;
+    if (!pk_retire_upto(s, r)) return false;
+  }
+  // tail contribution of this tail block: produced a tail period ago by a job on the second stream
+  if (has_tail) {
+    if (!pk_wait_tail(s, n1)) return false;
+    const long long need = (n1 - 1) / (long long)T.B + 1;
+    if (s->tail_out_done < need) {                            // (after a clock restart / other call patterns: made now)
+      if (!pk_quiesce(s)) return false;
+      if (!tail_rows(s, need, s->st_main)) return false;
+      RVC_CK(hipStreamSynchronize(s->st_main));
+    }
+  }
+  // the accumulator of block k0
+  unsigned ypre_wait = 0;
+  const float2 *ypre = nullptr;
+  long long ypre_stride = hb;
+  if (s->ypre_block == k0) {
+    ypre = s->ypre_cur; ypre_stride = s->ypre_cur_stride; ypre_wait = s->pk_ypre_from;
+  } else {
+    if (!pk_quiesce(s)) return false;
+    if (k0 > s->xa_next) {     // a long call skipped head blocks: rebuild the delay line's history (ordinary launches)
+      if (!head_spectra(s, head_fft_from(s, k0), k0 - 1, n0, nullptr, 0, 0)) return false;
+      s->xa_next = k0;
+      s->pk_need_acquire = true;
+      s->pk_tile_hi = s->pk_tile_ready = -1;
+    }
+    if (k0 <= 1) {
+      ypre = s->pk_zero_row;   // no block before time 0: sum_{i>=2} H_i X_{k-i} = 0
+    } else {
+      const rvc::FirArgs r = premultiply_args(s, k0);          // the whole sum, one ordinary launch
+      RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
+      ypre = r.Y;
+    }
+    RVC_CK(hipStreamSynchronize(s->st_main));
+    s->ypre_block = k0; s->ypre_cur = ypre; s->ypre_cur_stride = hb; s->pk_ypre_from = 0;
+  }
+  // the sweep rows block k0 + 1 is patched from
+  rvc::PkCmd c{};
+  if (block_done) {
+    const long long kn = k0 + 1, t0 = kn - kn % K;
+    if (s->pk_tile_hi < t0) {     // the retire path has not launched this tile's sweep yet: the block it waits for
+      if (!pk_retire_upto(s, s->pk_seq)) return false;        // (t0 - 2 - lag) may still be in flight -- drain, then
+      if (s->pk_tile_hi < t0) pk_launch_sweep(s, t0);          // (entry / restart) launch it here
+    }
+    if (s->pk_tile_ready < t0) {
+      RVC_CK(hipEventSynchronize(s->ev_sweep));
+      s->pk_tile_ready = s->pk_tile_hi;
+    }
+    c.patch_P = std::min<long long>(kn - t0 + rvc::kPkLag, (long long)A.P - 2);
+    if (c.patch_P < 0) c.patch_P = 0;
+    c.patch_yadd = (unsigned long long)(uintptr_t)head_sweep_row(s, kn);
+    c.patch_yadd_stride = (long long)s->sa_rows * hb;
+    c.patch_y = (unsigned long long)(uintptr_t)(s->ypre + (size_t)(kn & 1) * (size_t)s->nch * (size_t)hb);
+  }
+  if (!pk_ensure_running(s)) return false;
+  c.in = (unsigned long long)(uintptr_t)d_in; c.out = (unsigned long long)(uintptr_t)d_out;
+  c.in_stride = (long long)in_stride; c.out_stride = (long long)out_stride;
+  c.n0 = n0; c.n1 = n1; c.k = k0;
+  c.ypre = (unsigned long long)(uintptr_t)ypre; c.ypre_stride = ypre_stride; c.ypre_wait = ypre_wait;
+  c.flags = (block_done ? rvc::PK_BLOCK_DONE : 0u) | (s->pk_need_acquire ? rvc::PK_ACQUIRE : 0u) |
+            ((d_in == s->h_in && d_out == s->h_out) ? rvc::PK_IO_HOST : 0u);
+  s->pk_need_acquire = false;
+  c.seq = ++s->pk_seq;
+  s->pk_steps[c.seq % rvc::kPkRing] = rvc_set::PkStep{n0, n1, k0, block_done};
+  pk_push(s, c);
+  if (block_done) {
+    const long long kn = k0 + 1;
+    s->ypre_block = kn;
+    if (c.patch_P > 0) {
+      s->ypre_cur = reinterpret_cast<const float2 *>((uintptr_t)c.patch_y); s->ypre_cur_stride = hb;
+    } else {                                                   // (nothing to add: the sweep row is the accumulator)
+      s->ypre_cur = head_sweep_row(s, kn); s->ypre_cur_stride = c.patch_yadd_stride;
+    }
+    s->pk_ypre_from = c.seq;
+  }
+  s->xa_next = block_done ? k0 + 1 : k0;
+  mark_long_stage_stale(s, n1);
+  s->n = n1;
+  return true;
+}
+
 // one process() step of at most max_len samples, device buffers, asynchronous
 bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len) {
   Stage &A = s->A, &T = s->T;
@@ -832,6 +1168,17 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   const long long k0 = n0 / hb, k1 = (n1 - 1) / hb;
 
   // ---- latency path: the call stays inside one head block (the plugin's per-block call) ----
+  if (k0 == k1 && s->pk_enabled) {
+    if (s->out_copy_len != 0) {          // host-pointer call: the resident kernel reads / writes the pinned buffers itself
+      s->out_copy_len = 0;
+      s->flag_count = -1;                // process_end: wait for this step's completion flags
+    }
+    return pk_step(s, d_in, in_stride, d_out, out_stride, len);
+  }
+  if (s->pk_enabled) {                   // any other call pattern: ordinary launches; the resident kernel idles meanwhile
+    if (!pk_quiesce(s)) return false;
+    s->pk_need_acquire = true;
+  }
   if (k0 == k1 && rvc::fused_supported(A.logB, A.f64)) {
     if (has_tail) {
       if (bg) { if (!wait_tail_jobs(s, n1)) return false; }
@@ -878,7 +1225,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
           // inside the current tile: the sweep's row + the partitions whose input arrived after the sweep
           f.P = (int)std::min<long long>(kn - s->sa_t0, (long long)A.P - 2);
           f.Yadd = head_sweep_row(s, kn);
-          f.yadd_chan_stride = K * hb;
+          f.yadd_chan_stride = (long long)s->sa_rows * hb;
           if (f.P <= 0) { f.P = 0; f.Y = const_cast<float2 *>(f.Yadd); f.y_chan_stride = f.yadd_chan_stride; }   // nothing to add
         } else {      // the tile is used up: a sweep behind this launch starts the next one (its row kn is complete)
           f.P = 0;
@@ -1127,6 +1474,8 @@ void rvc_set_destroy(rvc_set *s) {
     for (int i = 0; i < s->ev_free; ++i) hipEventDestroy(s->ev_pool[i]);
     hipEventDestroy(s->ev_ingest);
     hipEventDestroy(s->ev_out);
+    hipEventDestroy(s->ev_sweep);
+    hipStreamDestroy(s->st_pk);
     hipStreamDestroy(s->st_bg);
     hipStreamDestroy(s->st_main);
   }
@@ -1234,7 +1583,10 @@ void rvc_set_process_end(rvc_set *s, float *const *out) {
   s->pending_len = 0;
   if (len == 0) return;
   bool ok = s->pending_ok;
-  if (ok && s->flag_count > 0) {
+  if (ok && s->flag_count < 0) {          // persistent mode: this step's completion flags, then its post-actions
+    s->flag_count = 0;
+    ok = pk_retire_upto(s, s->pk_seq);
+  } else if (ok && s->flag_count > 0) {
     // poll the completion flags the audio workgroups write behind their output stores
     const unsigned want = s->flag_seq;
     const int nf = s->flag_count;
@@ -1288,6 +1640,10 @@ void rvc_set_clear(rvc_set *s) {
   if (!s || !s->live) return;
   // Outstanding tail jobs still write into rings; let them finish, then restart the clock.
   hipSetDevice(s->device);
+  (void)pk_quiesce(s);
+  s->pk_tile_hi = s->pk_tile_ready = -1;
+  s->pk_ypre_from = 0;
+  s->pk_need_acquire = s->pk_enabled;
   hipStreamSynchronize(s->st_bg);
   hipStreamSynchronize(s->st_main);
   drop_jobs(s);
@@ -1317,6 +1673,7 @@ int rvc_set_is_finished(rvc_set *s) {
 void rvc_set_sync(rvc_set *s) {
   if (!s || !s->streams_ok) return;
   hipSetDevice(s->device);
+  (void)pk_quiesce(s);
   hipStreamSynchronize(s->st_bg);
   hipStreamSynchronize(s->st_main);
 }
@@ -1436,6 +1793,46 @@ int rvc_debug_rfft(int device, size_t n, int f64, const float *data, float *re, 
 int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re, const float *im) {
   if (!data || !re || !im) return 0;
   return debug_fft(device, n, f64, true, nullptr, data, re, im, nullptr, nullptr);
+}
+
+// diagnostics: 100 MHz timestamps of the resident kernel's last step (doorbell seen, command fetched, accumulator
+// ready, done) and its sequence number
+int rvc_debug_persist_stamps(rvc_set *s, unsigned long long *out5) {
+  if (!s || !s->pk_ctl || !out5) return 0;
+  for (int i = 0; i < 5; ++i) out5[i] = s->pk_ctl->pad[i];
+  if (std::getenv("RVC_PK_PROFILE")) {
+    volatile unsigned long long *p = s->pk_ctl->pad;
+    fprintf(stderr, "pk stamps (us): tables+IR+acc+Xprev %.2f | tail stream %.2f | samples %.2f\n", (double)(p[5] - p[2]) / 100.0,
+            (double)(p[6] - p[5]) / 100.0, (double)(p[8] - p[6]) / 100.0);
+    fprintf(stderr, "pk stamps (us): cmd->loads done %.2f | fwd fft %.2f | split+mac+exchange %.2f | inv fft %.2f | epilogue+flag %.2f\n",
+            (double)(p[8] - p[2]) / 100.0, (double)(p[9] - p[8]) / 100.0, (double)(p[10] - p[9]) / 100.0,
+            (double)(p[11] - p[10]) / 100.0, (double)(p[3] - p[11]) / 100.0);
+  }
+  return 1;
+}
+
+// diagnostics: round trip of n empty commands through the resident kernel (median microseconds), -1 on failure
+double rvc_debug_persist_rtt(rvc_set *s, int n) {
+  if (!s || !s->pk_enabled || !s->live || n < 1) return -1.0;
+  hipSetDevice(s->device);
+  if (!pk_quiesce(s) || !pk_ensure_running(s)) return -1.0;
+  std::vector<double> us;
+  for (int i = 0; i < n; ++i) {
+    rvc::PkCmd c{};
+    c.flags = rvc::PK_EMPTY;
+    c.seq = ++s->pk_seq;
+    s->pk_steps[c.seq % rvc::kPkRing] = rvc_set::PkStep{0, 0, 0, false};
+    const auto a = std::chrono::steady_clock::now();
+    pk_push(s, c);
+    volatile unsigned *f = s->h_flags;
+    for (int w = 0; w < s->pk_n_audio; ++w) while ((int)(f[w] - c.seq) < 0) {}
+    us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count());
+    f = s->h_pdone;
+    for (int w = 0; w < s->pk_n_patch; ++w) while ((int)(f[w] - c.seq) < 0) {}
+    s->pk_retired = c.seq;
+  }
+  std::sort(us.begin(), us.end());
+  return us[us.size() / 2];
 }
 
 int rvc_device_count(void) {
