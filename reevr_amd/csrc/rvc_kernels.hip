@@ -1096,10 +1096,8 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       if constexpr (PK) {
         const __amdgpu_buffer_rsrc_t rout = xk_rsrc(out);
         if (wide) {
-          if (n >= a.n0 && n < a.n1) {
-            if (a.io_host) *reinterpret_cast<float2 *>(out + (n - a.n0)) = make_float2(t0, t1);
-            else xk_st2(rout, (unsigned)(n - a.n0) * 4u, make_float2(t0, t1));
-          }
+          // (write-through also towards the pinned host buffer: plain stores would sit in the L2 until a release)
+          if (n >= a.n0 && n < a.n1) xk_st2(rout, (unsigned)(n - a.n0) * 4u, make_float2(t0, t1));
         } else {
           if (n >= a.n0 && n < a.n1) xk_st(rout, (unsigned)(n - a.n0) * 4u, t0);
           if (n + 1 >= a.n0 && n + 1 < a.n1) xk_st(rout, (unsigned)(n + 1 - a.n0) * 4u, t1);
@@ -1551,20 +1549,40 @@ __global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256
   const int pidx = (int)blockIdx.x - pa.n_audio;                 // patch workgroup: channel-major
   PkCtl *ctl = pa.ctl;
   unsigned seq = pa.seq0;
+  bool pending = false;        // the previous step's stores are issued but its completion is not published yet
+  // completion of step `sq`: every wave has drained its (write-through) stores, then ONE lane publishes
+  auto publish = [&](const unsigned sq) {
+    if (threadIdx.x == 0) {
+      if (is_audio) {
+        __hip_atomic_store(pa.h_done + blockIdx.x, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(pa.x_seq + blockIdx.x, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        __hip_atomic_store(pa.ypre_seq + pidx, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(pa.h_pdone + pidx, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  };
   for (;;) {
     ++seq;
     // ---- wait for command `seq`: the first 16 threads poll the 16 qwords of its ring slot (ONE PCIe round trip per
-    // poll; the slot's last word equals `seq` once the host has completed it); the other waves sleep at the barrier
+    // poll; each 64-byte line of the slot ends with `seq` once the host has completed it); the other waves sleep at the
+    // barrier. The FIRST poll is in flight while every wave drains the previous step's stores: the round trip that finds
+    // the next command and the acknowledgement of the last step's write-through stores overlap, and the last step's
+    // completion is published as soon as both are in.
+    const volatile unsigned long long *slot = reinterpret_cast<const volatile unsigned long long *>(&ctl->ring[seq % kPkRing]);
+    unsigned long long q = threadIdx.x < 16 ? pk_ld64(slot + threadIdx.x) : 0ull;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pending) { publish(seq - 1u); pending = false; }
     if (threadIdx.x < 64) {
       int ex = 0;
       const long long t0 = wall_clock64();
-      const volatile unsigned long long *slot = reinterpret_cast<const volatile unsigned long long *>(&ctl->ring[seq % kPkRing]);
       for (unsigned spins = 0;; ++spins) {
-        const unsigned long long q = threadIdx.x < 16 ? pk_ld64(slot + threadIdx.x) : 0ull;
         if ((unsigned)__shfl(q, 7) == seq && (unsigned)__shfl(q, 15) == seq) {   // both lines complete
           if (threadIdx.x < 16) s_cmd[threadIdx.x] = q;
           break;
         }
+        q = threadIdx.x < 16 ? pk_ld64(slot + threadIdx.x) : 0ull;
         if ((spins & 31u) != 31u) continue;                      // (the slow checks: every 32nd poll)
         if (pk_ld32(pa.park)) { ex = 1; break; }
         if (wall_clock64() - t0 > pa.idle_ticks) {
@@ -1611,11 +1629,8 @@ __global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256
       __syncthreads();
     }
     if (flags & PK_EMPTY) {      // diagnostics: an empty step (hand-off round trip only)
-      if (threadIdx.x == 0) {
-        if (is_audio) __hip_atomic_store(pa.h_done + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        else __hip_atomic_store(pa.h_pdone + pidx, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
       __syncthreads();
+      publish(seq);
       continue;
     }
     if (is_audio) {
@@ -1644,13 +1659,11 @@ __global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256
       fa.out = reinterpret_cast<float *>(cmd.out); fa.out_chan_stride = cmd.out_stride;
       fa.n0 = cmd.n0; fa.n1 = cmd.n1; fa.k = cmd.k;
       fa.Ypre = reinterpret_cast<const float2 *>(cmd.ypre); fa.ypre_chan_stride = cmd.ypre_stride;
-      fa.done_flag = pa.h_done; fa.seq = seq; fa.io_host = (flags & PK_IO_HOST) ? 1 : 0;
+      fa.done_flag = nullptr; fa.seq = seq; fa.io_host = (flags & PK_IO_HOST) ? 1 : 0;   // (completion: published above, next pass)
 #ifdef RVC_PK_STAMPS
       fa.dbg = const_cast<unsigned long long *>(ctl->pad);
 #endif
-      fused_audio<LOGB, true, true>(fa, smem_raw, blockIdx.x);      // ends with the completion flag (thread 0)
-      if (threadIdx.x == 0)                                          // (every wave drained its stores before that flag)
-        __hip_atomic_store(pa.x_seq + blockIdx.x, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      fused_audio<LOGB, true, true>(fa, smem_raw, blockIdx.x);
       if (stamp) { ctl->pad[3] = (unsigned long long)wall_clock64(); ctl->pad[4] = seq; }
       __syncthreads();                                               // s_cmd / the exchange buffer are reused next step
     } else {
@@ -1677,13 +1690,8 @@ __global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256
         f.Y = reinterpret_cast<float2 *>(cmd.patch_y); f.y_chan_stride = f.B;
         fdl_patch_body<true>(f, pidx % pa.patch_bx, pidx / pa.patch_bx);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every storing wave: write-through stores have landed
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        __hip_atomic_store(pa.ypre_seq + pidx, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(pa.h_pdone + pidx, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
     }
+    pending = true;
   }
 }
 
