@@ -449,23 +449,35 @@ def main():
 def side_measurements(torch, reevr_amd, synth, irs2, local_rank, dev, host_block, tail):
     """ONE stereo pair (the plug-in's own case), three ways. Not the headline."""
     out = {}
-    # (a) block-synchronous: latency per 512-frame block
+    # (a) block-synchronous: per 512-frame block, device-resident loop and host-pointer calls (the audio thread's view),
+    #     with one launch per block (tail job inline / on the second stream) and with the resident kernel
     nblk = 3000
-    xs = torch.from_numpy(np.stack([synth.synth_input(host_block * nblk, c) for c in range(2)])).to(dev)
+    xs_h = np.stack([synth.synth_input(host_block * nblk, c) for c in range(2)])
+    xs = torch.from_numpy(xs_h).to(dev)
     ys = torch.empty_like(xs)
+    torch.cuda.synchronize()
     res = {}
-    for mode, bg in (("tail_on_second_stream", True), ("tail_inline", False)):
-        s = reevr_amd.ConvolverSet(2, device=local_rank, bg_stream=bg)
+    for mode, kw in (("tail_on_second_stream", dict(bg_stream=True)), ("tail_inline", dict(bg_stream=False)),
+                     ("persistent_kernel", dict(bg_stream=True, persistent=True))):
+        s = reevr_amd.ConvolverSet(2, device=local_rank, **kw)
         assert s.init(host_block, tail, irs2, max_len=host_block)
         s.process_device_blocks(xs[:, :host_block * 200].contiguous(), host_block)
         ts = time.perf_counter()
         s.process_device_blocks(xs, host_block, ys)
         te = time.perf_counter() - ts
-        res[mode] = {"Msamples_s": round(2 * host_block * nblk / te / 1e6, 3), "us_per_block": round(te / nblk * 1e6, 2)}
+        _, us = s.process_host_blocks_timed(xs_h[:, :host_block * 1500], host_block)
+        us = np.sort(us[300:])
+        res[mode] = {"Msamples_s": round(2 * host_block * nblk / te / 1e6, 3), "us_per_block": round(te / nblk * 1e6, 2),
+                     "host_call_us_median": round(float(us[len(us) // 2]), 2), "host_call_us_p99": round(float(us[int(len(us) * 0.99)]), 2)}
         s.close()
     best = max(res.values(), key=lambda r: r["Msamples_s"])
     out["stereo_block_sync"] = {"value": best["Msamples_s"], "unit": "Msamples/s", "us_per_block": best["us_per_block"],
-                                "modes": res, "note": "ONE stereo pair, one process_device() call per 512-frame block (host loop in C)"}
+                                "host_call_us_median": min(r["host_call_us_median"] for r in res.values()),
+                                "modes": res,
+                                "note": "ONE stereo pair. us_per_block: one process_device() call per 512-frame block back to back "
+                                        "(host loop in C); host_call_us: rvc_set_process() on host buffers per block, back to back "
+                                        "(pinned staging + hand-off + kernel + copy back; stopwatch in C). persistent_kernel = "
+                                        "RVC_FLAG_PERSISTENT (resident kernel fed through a doorbell, no launch per block)"}
     # (b) offline: one 40 s call per step (adaptive partitioning) and (c) the same through the fixed head/tail sizes
     frames = 40 * SR
     xl = torch.from_numpy(np.stack([synth.synth_input(frames, c) for c in range(2)])).to(dev)

@@ -143,6 +143,12 @@ void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride,
 void rvc_set_process_device_blocks(rvc_set *s, const float *d_in, size_t in_stride, float *d_out,
                                    size_t out_stride, size_t len, size_t block);
 
+/* The same loop over HOST buffers (rvc_set_process per block, block <= max_len), with a stopwatch around every call:
+ * us_per_call (may be NULL) receives ceil(len / block) durations in microseconds -- the per-call latency the plug-in's
+ * audio thread sees, without host-language overhead. */
+void rvc_set_process_host_blocks_timed(rvc_set *s, const float *const *in, float *const *out, size_t len, size_t block,
+                                       double *us_per_call);
+
 /* ---- state ------------------------------------------------------------------------- */
 
 /* Replaces TwoStageFFTConvolver::clear / FFTConvolver::clear (TwoStageFFTConvolver.cpp:69-84,

@@ -104,6 +104,20 @@ class ConvolverSet:
         self._lib.rvc_set_process(self._h, ins, outs, n)
         return out
 
+    def process_host_blocks_timed(self, x: np.ndarray, block: int):
+        """x: (n_channels, len) host array fed through process() in calls of `block` frames, all in C.
+        Returns (output, per-call durations in microseconds)."""
+        x = _f32(x)
+        assert x.ndim == 2 and x.shape[0] == self.n_channels
+        out = np.empty_like(x)
+        ncalls = -(-x.shape[1] // block)
+        us = np.zeros(ncalls, np.float64)
+        ins = (L.F32P * self.n_channels)(*[x[c].ctypes.data_as(L.F32P) for c in range(self.n_channels)])
+        outs = (L.F32P * self.n_channels)(*[out[c].ctypes.data_as(L.F32P) for c in range(self.n_channels)])
+        self._lib.rvc_set_process_host_blocks_timed(self._h, ins, outs, x.shape[1], block,
+                                                    us.ctypes.data_as(C.POINTER(C.c_double)))
+        return out, us
+
     def process_begin(self, x: np.ndarray):
         """Non-blocking half of process(): stage x (n_channels, len <= max_len) and enqueue the work."""
         x = _f32(x)

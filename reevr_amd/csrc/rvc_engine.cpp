@@ -1550,6 +1550,24 @@ void rvc_set_process_device_blocks(rvc_set *s, const float *d_in, size_t in_stri
     rvc_set_process_device(s, d_in + done, in_stride, d_out + done, out_stride, std::min(block, len - done));
 }
 
+// The host's per-block loop over HOST buffers with a stopwatch around every call: what the plug-in's audio thread sees
+// per process() (pinned staging + hand-off + kernel + copy back), measured without any host-language overhead.
+void rvc_set_process_host_blocks_timed(rvc_set *s, const float *const *in, float *const *out, size_t len, size_t block,
+                                       double *us_per_call) {
+  if (!s || !in || !out || block == 0) return;
+  std::vector<const float *> ins((size_t)s->nch);
+  std::vector<float *> outs((size_t)s->nch);
+  size_t call = 0;
+  for (size_t done = 0; done < len; done += block, ++call) {
+    const size_t n = std::min(block, len - done);
+    for (int c = 0; c < s->nch; ++c) { ins[c] = in[c] + done; outs[c] = out[c] + done; }
+    const auto a = std::chrono::steady_clock::now();
+    rvc_set_process_begin(s, ins.data(), n);
+    rvc_set_process_end(s, outs.data());
+    if (us_per_call) us_per_call[call] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count();
+  }
+}
+
 void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   if (!s) return;
   s->pending_len = len;

@@ -26,9 +26,12 @@ def family(name: str, head_log: int, tail_log: int):
     m = re.search(r"k_fir_row<(\d)>", name)
     if m:
         return "premultiply" if m.group(1) == "0" else "fir_tail"
-    m = re.search(r"k_fdl_sweep<[^>]*?(\d)>", name)
+    m = re.search(r"k_fdl_sweep<\d+, (\d)", name)          # <SPLIT, STAGE, ...>
     if m:
-        return "fir_head" if m.group(1) == "0" else "fir_tail"
+        return "sweep_head" if m.group(1) == "0" else "sweep_tail"
+    m = re.search(r"k_fdl_patch<(\d)>", name)
+    if m:
+        return "premultiply" if m.group(1) == "0" else "fir_tail"
     m = re.search(r"k_fir(?:_lds)?<(?:\d+, )?(\d)>", name)
     if m:
         return "fir_head" if m.group(1) == "0" else "fir_tail"   # <1> tail stage, <2> whole-IR line (timed as fir_tail)
@@ -72,7 +75,8 @@ def main():
     ap.add_argument("--calib-write")
     ap.add_argument("--head-log", type=int, default=9)
     ap.add_argument("--tail-log", type=int, default=13)
-    ap.add_argument("--channels", type=int, default=512)
+    ap.add_argument("--channels", type=int, default=1024)
+    ap.add_argument("--time-tiling", type=int, default=1)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--command", default="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --side 0")
     ap.add_argument("-o", "--out", required=True)
@@ -81,7 +85,8 @@ def main():
     wr = per_family(a.write_csv, a.head_log, a.tail_log)
     ff, fk = calib_factor(a.calib_fetch, 2.0)
     fw, wk = calib_factor(a.calib_write, 1.0)
-    out = {"command": a.command, "channels": a.channels, "config": a.config, "unit": "bytes per launch (steady state)",
+    out = {"command": a.command, "channels": a.channels, "config": a.config, "time_tiling": a.time_tiling,
+           "unit": "bytes per launch (mean over the second half of each family's dispatches)",
            "correction": {"fetch_factor": round(ff, 4), "write_factor": round(fw, 4),
                           "calibration": "1 GiB device copy (tools/pmc_calib.py): FETCH_SIZE %s KiB, WRITE_SIZE %s KiB per dispatch "
                                          "for 1048576 KiB read + 1048576 KiB written" % (fk, wk)},
