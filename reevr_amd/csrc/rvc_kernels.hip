@@ -923,9 +923,22 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   const bool wide = PK && ((a.n0 | a.n1) & 1) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(a.out) |
                                                         (uintptr_t)(a.out_chan_stride * 4)) & 7u) == 0;
   C v[P::E];
-  // (persistent kernel: the tail contribution the epilogue adds is requested NOW -- it does not depend on this block --
-  //  instead of costing a system-scope memory round trip behind the inverse transform)
-  float2 addv[PK ? P::E / 2 : 1];
+  // The tail contribution the epilogue adds is requested NOW -- it does not depend on this block -- instead of costing a
+  // memory round trip behind the inverse transform (calls on even sample positions: pairs of samples per access).
+  const bool pre_add = PK ? wide : (((a.n0 | a.n1) & 1) == 0);
+  float2 addv[P::E / 2];
+  if constexpr (!PK) {
+    if (pre_add && a.add) {
+      const float *addc = a.add + (long long)c * a.add_chan_stride;
+      int q = 0;
+#pragma unroll
+      for (int e = 0; e < P::E; ++e)
+        if (!P::out_is_low(e)) {
+          const long long n = a.k * (long long)B + 2 * P::out_idx(tid, e) - B;
+          addv[q++] = *reinterpret_cast<const float2 *>(addc + ((unsigned long long)(n >= a.add_from ? n : a.add_from) & a.add_mask));
+        }
+    }
+  }
   if constexpr (PK) {
     if (wide && a.add) {
       const __amdgpu_buffer_rsrc_t radd = xk_rsrc(a.add + (long long)c * a.add_chan_stride);
@@ -1085,6 +1098,9 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
             u0 = xk_ld(radd, (unsigned)((unsigned long long)(a0 ? n : a.add_from) & a.add_mask) * 4u);
             u1 = xk_ld(radd, (unsigned)((unsigned long long)(a1 ? n + 1 : a.add_from) & a.add_mask) * 4u);
           }
+        } else if (pre_add) {
+          const float2 u2 = addv[P::out_is_low(e) ? 0 : addq];
+          u0 = u2.x; u1 = u2.y;
         } else {
           u0 = add[(unsigned long long)(a0 ? n : a.add_from) & a.add_mask];
           u1 = add[(unsigned long long)(a1 ? n + 1 : a.add_from) & a.add_mask];
@@ -1506,6 +1522,8 @@ __global__ void __launch_bounds__(256) k_fdl_patch(const FirArgs a) { fdl_patch_
 // FirArgs f, one workgroup per 64 bins and channel). The two parts are independent inside the launch.
 // Launched with max(Plan8::WG, 256) threads: the surplus waves of either part retire at once (a
 // terminated wave no longer counts at s_barrier).
+// (Register budget: 170 VGPRs = 2 waves per SIMD. Capping it at 168 / 128 -- 3 / 4 waves per SIMD, 2 / 42 spills -- was
+//  measured for 1024 channels: 18.4 -> 18.7 / 28.5 us per launch. Occupancy is not what bounds this launch.)
 template <int LOGB>
 __global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256))
 k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int fir_bx) {
