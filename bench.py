@@ -221,21 +221,42 @@ def main():
     do_gather = bool(args.gather and world > 1)
     torch.cuda.synchronize()
     state = {"i": 0}
+    # N > 1: the output batch of every step is gathered with ONE all_gather, overlapped with the next step's compute:
+    # the collective is ordered behind this step's kernels (torch's current stream waits for the set's stream) and runs
+    # on the communicator's stream; a batch buffer is reused only after its own gather has completed.
+    g_out = [torch.empty((world,) + (nch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
+    g_stage = [torch.empty((nch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
+    pending = [None] * nbuf
 
     def step(gather=True):
         b = state["i"] % nbuf
         state["i"] += 1
         xi = d_in[:, b * frames_step:(b + 1) * frames_step]
+        if do_gather and gather:
+            if pending[b] is not None:         # the gather that read this batch's buffers two steps ago
+                pending[b].wait()
+                pending[b] = None
+            yo = g_stage[b]                    # contiguous: the collective reads it in place
+            if long_call:
+                conv.process_device(xi, yo, sync=False, order=True)
+            else:
+                conv.process_device_blocks(xi, host_block, yo, sync=False, order=True)
+            pending[b] = shard.gather_batches_async(yo, g_out[b], dist)
+            return
         yo = d_out[:, b * frames_step:(b + 1) * frames_step]
         if long_call:
             conv.process_device(xi, yo, sync=False, order=False)
         else:                                  # the host's per-block loop (in C): one call per 512-frame block
             conv.process_device_blocks(xi, host_block, yo, sync=False, order=False)
-        if do_gather and gather:               # one RCCL all_gather per step (batch of blocks), never per block
-            conv.sync()
-            shard.gather_batches(yo, dist)
+
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     def fence():
+        drain()
         conv.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -263,6 +284,7 @@ def main():
         step()
     # closing bracket: synchronise this rank, stamp, barrier; the reported time is the MAX over ranks of
     # the stamped spans (all ranks left the opening barrier together)
+    drain()
     conv.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -431,7 +453,7 @@ def main():
                             "device-resident I/O, %d input/output batches rotated" % nbuf),
                    "pre_roll_steps": pre, "gather": do_gather,
                    "sharding": "instances dealt to ranks, equal shards, no data-path collective"
-                               + ("; one RCCL all_gather of the output batch per step" if do_gather else "")},
+                               + ("; one RCCL all_gather of the output batch per step, overlapped with the next step" if do_gather else "")},
         "roofline": roof,
         "roofline_all": roof_all,
         "path_roofline": path,

@@ -50,6 +50,21 @@ def gather_batches(local, dist=None):
     return torch.stack(parts)
 
 
+def gather_batches_async(local, out, dist=None):
+    """Non-blocking form: all_gather of `local` (contiguous, equally shaped on every rank) into the preallocated
+    `out` (world, *local.shape); returns a work handle (`.wait()`), or None when there is nothing to communicate.
+    With RCCL the collective is ordered behind the caller's current CUDA stream and runs on the communicator's own
+    stream, so the next batch's kernels (on another stream) overlap it."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        out[0].copy_(local)
+        return None
+    world = dist.get_world_size()
+    assert out.shape[0] == world and tuple(out.shape[1:]) == tuple(local.shape) and local.is_contiguous()
+    if local.is_cuda and dist.get_backend() == "nccl":
+        return dist.all_gather_into_tensor(out.view(world * local.shape[0], *local.shape[1:]), local, async_op=True)
+    return dist.all_gather([out[r] for r in range(world)], local, async_op=True)
+
+
 def reassemble(gathered, n_units: int, world: int):
     """gathered[r][j] holds unit units_for_rank(n_units, world, r)[j]; return them in unit order.
     Requires n_units % world == 0 (equal shards)."""
