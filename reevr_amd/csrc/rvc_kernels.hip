@@ -280,6 +280,32 @@ __device__ __forceinline__ void dft8(cx<R> *a) {
   a[1] = d0; a[3] = d1; a[5] = d2; a[7] = d3;
 }
 
+// ----------------------------------------------------------------------------------------
+// Real split through wavefront shuffles. When a whole transform lives in ONE wave (B/8 <= 64 threads) and the plan
+// has no final radix-2/4 pass (held index of value e = tid + e * NT on both sides of the core), the partner Z[B - k]
+// of a thread's value e sits in lane NT - tid of the same transform, register 7 - e (thread 0: its own register
+// 8 - e): the pairing of the real split is a lane REVERSAL, done with ds_bpermute (__shfl) -- no LDS buffer round
+// trip, no barrier. Used by the transform kernels and by the one-block latency kernel for head blocks of 64 and 512.
+// ----------------------------------------------------------------------------------------
+template <int LOGB> struct WaveSplit {
+  typedef Plan8<LOGB> P;
+  static constexpr bool ok = (P::Q == 1) && (P::S == 1) && (P::NT <= 64);
+};
+template <typename R> __device__ __forceinline__ cx<R> shfl_cx(const cx<R> v, const int src_lane) {
+  if constexpr (sizeof(R) == 4) return mk<R>(__shfl(v.x, src_lane), __shfl(v.y, src_lane));
+  else return mk<R>(__shfl(v.x, src_lane), __shfl(v.y, src_lane));     // (double: two dword shuffles each, by the header)
+}
+// partner of value e of this thread: the value held at natural index B - (tid + e * NT)
+template <int LOGB, typename R>
+__device__ __forceinline__ cx<R> wave_partner(const cx<R> *v, const int tid, const int e) {
+  typedef Plan8<LOGB> P;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int src = lane - tid + ((P::NT - tid) & (P::NT - 1));          // lane of thread NT - tid of the same transform
+  const cx<R> other = shfl_cx<R>(v[7 - e], src);                        // (every lane shuffles: uniform control flow)
+  const cx<R> own = v[(8 - e) & 7];                                     // thread 0 pairs inside itself (e >= 1)
+  return tid == 0 ? own : other;
+}
+
 // Twiddles of one transform, per thread, in registers: they depend on the thread index only, so
 // they are requested at the top of the kernel -- before the input data has even arrived -- and the
 // passes never wait on a twiddle load. Forward and inverse share them (conjugated on use).
@@ -615,6 +641,19 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
 
   constexpr bool kLin = P::kLin;
   const int lt = lpad(tid), ln = lpad_neg(tid);
+  float2 *dst = a.dst + (long long)c * a.dst_chan_stride +
+                (long long)(((unsigned long long)(a.row0 + r_)) & a.row_mask) * B;
+  const R half = (R)0.5;
+  C Zp[P::E / 2];
+  if constexpr (WaveSplit<LOGB>::ok) {
+    // one wave per transform: the partner Z[B - k] comes through a lane reversal (wave_partner), no LDS, no barrier
+    int q = 0;
+#pragma unroll
+    for (int e = 0; e < P::E; ++e)
+      if (P::out_is_low(e)) Zp[q++] = wave_partner<LOGB, R>(v, tid, e);
+    RVC_STAMP(0, 3);
+    if (!live) return;
+  } else {
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < P::E; ++e)
@@ -623,9 +662,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
       else lds[lpad(P::out_idx(tid, e))] = v[e];
     }
   __syncthreads();
-  float2 *dst = a.dst + (long long)c * a.dst_chan_stride +
-                (long long)(((unsigned long long)(a.row0 + r_)) & a.row_mask) * B;
-  const R half = (R)0.5;
   RVC_STAMP(0, 3);
 #if defined(RVC_ABLATE_FWD_STOP) && RVC_ABLATE_FWD_STOP == 3
   if (a.rows > 0) { if (v[0].x == (R)12345.678) a.dst[0] = make_float2((float)v[1].x + (float)ws[0].x, (float)v[P::E - 1].y); return; }
@@ -633,7 +669,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   if (!live) return;                                   // (after the last barrier)
   // all partner reads first (back to back, one wait), then the arithmetic. k == 0 exists only for
   // (tid, e) = (0, 0); its partner slot is redirected to a valid address and its result replaced below.
-  C Zp[P::E / 2];
   {
     int q = 0;
 #pragma unroll
@@ -645,6 +680,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
         if (e == 0) idx = tid == 0 ? lpad(B / 2) : idx;
         Zp[q++] = lds[idx];
       }
+  }
   }
   int q = 0;
 #pragma unroll
@@ -704,6 +740,8 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   const R sc = (R)0.5 / (R)B;
   constexpr bool kLin = P::kLin;
   const int lt = lpad(tid), ln = lpad_neg(tid);
+  C zcs[WaveSplit<LOGB>::ok ? 4 : 1];                      // (wave split: the partners' values stay in registers)
+  C zhalf = mk<R>((R)0, (R)0);
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     if ((e & 7) < 4) {                                   // in_idx(tid, e) < B/2
@@ -716,7 +754,9 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
       if (k == 0) {
         v[e] = mk<R>(sc * ((R)yk.x + (R)yk.y), sc * ((R)yk.x - (R)yk.y));
         const float2 yh = Y[B / 2];                      // and the self-paired bin B/2: Z = conj(Y) / B
-        lds[lpad(B / 2)] = mk<R>((R)2 * sc * (R)yh.x, -(R)2 * sc * (R)yh.y);
+        zhalf = mk<R>((R)2 * sc * (R)yh.x, -(R)2 * sc * (R)yh.y);
+        if constexpr (WaveSplit<LOGB>::ok) zcs[e & 3] = zhalf;
+        else lds[lpad(B / 2)] = zhalf;
       } else {
 #ifdef RVC_ABLATE_FFT_NOLOAD
         const float2 yc = make_float2(2e-3f * (float)(k & 511), (float)(k & 3));
@@ -729,11 +769,24 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
         const C O = cmul(cconj(wsplit[k]), D);
         v[e] = mk<R>(Ev.x - O.y, Ev.y + O.x);            // Z[k]   = E + iO
         const C zc = mk<R>(Ev.x + O.y, O.x - Ev.y);      // Z[B-k] = conj(E) + i conj(O)
-        if constexpr (kLin) lds[ln + lpad_c(B - P::in_c(e))] = zc;
+        if constexpr (WaveSplit<LOGB>::ok) zcs[e & 3] = zc;
+        else if constexpr (kLin) lds[ln + lpad_c(B - P::in_c(e))] = zc;
         else lds[lpad(B - (int)k)] = zc;
       }
     }
   }
+  if constexpr (WaveSplit<LOGB>::ok) {
+    // value e' >= 4 of thread tid = Z[B - k] made by thread NT - tid from its value 7 - e' (thread 0: by itself from
+    // 8 - e'; its e' = 4 is the self-paired bin B/2, parked in slot 0): a lane reversal, no LDS, no barrier
+    const int lane = (int)(threadIdx.x & 63u);
+    const int src = lane - tid + ((P::NT - tid) & (P::NT - 1));
+#pragma unroll
+    for (int e = 4; e < 8; ++e) {
+      const C other = shfl_cx<R>(zcs[7 - e], src);
+      const C own = zcs[(8 - e) & 3];                    // (e = 4 -> slot 0 = zhalf of thread 0)
+      v[e] = tid == 0 ? own : other;
+    }
+  } else {
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < P::E; ++e)
@@ -742,6 +795,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
       else v[e] = lds[lpad(P::in_idx(tid, e))];
     }
   __syncthreads();                                       // the transform's first exchange overwrites the buffer
+  }
   RVC_STAMP(2, 1);
 #ifndef RVC_ABLATE_FFT_NOCORE
   fft8_core<LOGB, true, R>(v, lds, T, tid);
@@ -1022,10 +1076,19 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   RVC_AUDIO_STAMP(8);
   fft8_core<LOGB, false, float>(v, lds, T, tid);
   RVC_AUDIO_STAMP(9);
-  __syncthreads();
+  // The real split pairs bin k with bin B - k. Head blocks of 64 / 512: the whole transform lives in one wave and the
+  // partner arrives through a lane reversal (wave_partner: ds_bpermute, no LDS round trip, no barrier); else through LDS.
+  constexpr bool kWS = WaveSplit<LOGB>::ok;
+  C part[kWS ? P::E : 1];
+  if constexpr (kWS) {
 #pragma unroll
-  for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = v[e];
-  __syncthreads();
+    for (int e = 0; e < P::E; ++e) part[e] = wave_partner<LOGB, float>(v, tid, e);
+  } else {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = v[e];
+    __syncthreads();
+  }
   float2 *Xrow = a.Xrow + (long long)c * a.x_chan_stride + (long long)((unsigned long long)a.k & a.x_row_mask) * B;
   C y[P::E];
 #pragma unroll
@@ -1040,7 +1103,9 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       else if (live) Xrow[0] = X;
       y[e] = mk<float>(fmaf(h.x, X.x, yp.x), fmaf(h.y, X.y, yp.y));  // two real products
     } else {
-      const C Bc = cconj(lds[lpad(B - k)]);
+      C Bc;
+      if constexpr (kWS) Bc = cconj(part[e]);
+      else Bc = cconj(lds[lpad(B - k)]);
       const C Ev = mk<float>(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
       const C D = mk<float>(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
       const C O = mk<float>(D.y, -D.x);
@@ -1050,27 +1115,37 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       y[e] = mk<float>(fmaf(h.x, X.x, fmaf(-h.y, X.y, yp.x)), fmaf(h.x, X.y, fmaf(h.y, X.x, yp.y)));
     }
   }
-  // 3. inverse split needs Y[k] and Y[B-k] in the in_idx mapping: exchange through LDS
-  __syncthreads();
+  // 3. inverse split needs Y[k] and Y[B-k] in the in_idx mapping (= the out_idx mapping when the plan has no final
+  //    radix-2/4 pass): through the wave again, or through LDS
+  if constexpr (kWS) {
 #pragma unroll
-  for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = y[e];
-  __syncthreads();
+    for (int e = 0; e < P::E; ++e) part[e] = wave_partner<LOGB, float>(y, tid, e);
+  } else {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = y[e];
+    __syncthreads();
+  }
   const float sc = 0.5f / (float)B;
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int k = P::in_idx(tid, e);
-    const C Yk = lds[lpad(k)];
+    C Yk;
+    if constexpr (kWS) Yk = y[e];
+    else Yk = lds[lpad(k)];
     if (k == 0) {
       v[e] = mk<float>(sc * (Yk.x + Yk.y), sc * (Yk.x - Yk.y));
     } else {
-      const C Yc = cconj(lds[lpad(B - k)]);
+      C Yc;
+      if constexpr (kWS) Yc = cconj(part[e]);
+      else Yc = cconj(lds[lpad(B - k)]);
       const C Ev = mk<float>(sc * (Yk.x + Yc.x), sc * (Yk.y + Yc.y));
       const C D = mk<float>(sc * (Yk.x - Yc.x), sc * (Yk.y - Yc.y));
       const C O = cmul(cconj(wsi[e]), D);
       v[e] = mk<float>(Ev.x - O.y, Ev.y + O.x);
     }
   }
-  __syncthreads();
+  if constexpr (!kWS) __syncthreads();
   RVC_AUDIO_STAMP(10);
   fft8_core<LOGB, true, float>(v, lds, T, tid);
   RVC_AUDIO_STAMP(11);
