@@ -22,6 +22,13 @@
 // ingest -> [tail: FFT new blocks, FIR, IFFT -> tail ring] -> stage A: FFT, FIR, IFFT(+tail) -> out.
 // A block that a call leaves partly filled is simply transformed again (zero-padded) by the
 // next call, like FFTConvolver.cpp:164-173. clear() just restarts the clock.
+//
+// Block-synchronous calls (one call per host block, the plug-in's pattern) have two refinements on top of that:
+//   * causal time tiling of the delay lines (tile_A / tile_T, rvc_internal.h kSweepRows): every 8th block a sweep reads a
+//     stage's IR spectra and delay line once and leaves partial sums for 8 blocks, the blocks in between patch in the few
+//     partitions whose input arrived since;
+//   * RVC_FLAG_PERSISTENT: the per-block launch is replaced by one resident kernel fed through a command ring in pinned host
+//     memory (pk_* functions below); sweeps and tail jobs stay ordinary launches, issued when a block retires.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

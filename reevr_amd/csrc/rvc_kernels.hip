@@ -6,7 +6,10 @@
 //                                   driven by FFTConvolver.cpp:176-187
 //   k_fft8_inv / k_fft_inv     OouraFFT::ifft  AudioFFT.cpp:139-159 (+ Sum / overlap, FFTConvolver.cpp:193,204;
 //                                              tail add-back TwoStageFFTConvolver.cpp:171-190)
-//   k_fused_block              one whole per-block process() call (TwoStageFFTConvolver.cpp:151-233, len <= head)
+//   k_fused_block / k_fused_block2   one whole per-block process() call (TwoStageFFTConvolver.cpp:151-233, len <= head)
+//   k_persist                  the same, as ONE resident launch fed through a command ring (RVC_FLAG_PERSISTENT)
+//   k_fdl_patch                the few partitions a block adds on top of a sweep row of the time-tiled delay line
+//                              (the sweep itself: rvc_sweep.hip; both replace the per-block loop FFTConvolver.cpp:176-187)
 //   k_ingest                   the memcpy into _inputBuffer / _tailInput (FFTConvolver.cpp:166-169, TwoStage..:196-197)
 //
 // Design notes (DESIGN.md has the full picture):
@@ -23,7 +26,9 @@
 //    (coalesced 512 B per wave per row); each thread keeps 16 consecutive output blocks in
 //    registers and slides a 16-row window of input spectra, so every IR row loaded is used 16
 //    times per wave and 64 times per workgroup (k_fir_lds stages both operands in LDS).
-//  * RVC_ABLATE_* macros (off by default) knock out one ingredient of a kernel for the
+//  * The real split pairs bin k with bin B - k: through a wavefront shuffle (lane reversal) where a transform lives in one
+//    wave (blocks of 64 and 512), through LDS otherwise (WaveSplit / wave_partner).
+//  * RVC_ABLATE_* macros (development builds only, -DRVC_DEV_BUILD) knock out one ingredient of a kernel for the
 //    ablation measurements quoted in DESIGN.md; they produce wrong results by design.
 #include "rvc_internal.h"
 #include "rvc_fft_lds.hpp"
