@@ -39,6 +39,7 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/reevr_amd/rvc.h"
@@ -263,6 +264,7 @@ void pk_release_slot(rvc_set *s);
 void free_device_state(rvc_set *s) {
   pk_stop(s);
   pk_release_slot(s);
+  rvc::FreeGuard guard;              // (other sets' resident kernels stand down while this one frees)
   if (s->pk_ctl) hipHostFree(s->pk_ctl);
   if (s->h_pdone) hipHostFree(s->h_pdone);
   hipFree(s->pk_ypre_seq); hipFree(s->pk_park); hipFree(s->pk_zero_row); hipFree(s->pk_x_seq);
@@ -904,6 +906,9 @@ constexpr double kPkHostTimeoutS = 5.0;
 // could queue one behind another (and wait for it to park). Further persistent sets use ordinary launches.
 constexpr int kPkMaxResident = 2;
 std::atomic<int> g_pk_resident{0};
+std::atomic<int> g_pk_active{0};      // resident kernels running right now (process-wide)
+std::atomic<int> g_pk_pause{0};       // threads about to free device memory (rvc::free_guard_enter)
+bool pk_paused() { return g_pk_pause.load(std::memory_order_acquire) > 0; }
 
 void pk_push(rvc_set *s, const rvc::PkCmd &c) {
   rvc::PkCtl *ctl = s->pk_ctl;
@@ -944,6 +949,7 @@ bool pk_launch(rvc_set *s, unsigned seq0) {
   if (const char *e = std::getenv("RVC_PERSIST_IDLE_MS")) a.idle_ticks = (long long)(std::atof(e) * 1e5);
   RVC_CK(rvc::launch_persist(A.logB, a, s->nch, s->st_pk));
   s->pk_running = true;
+  g_pk_active.fetch_add(1);
   return true;
 }
 
@@ -963,6 +969,7 @@ bool pk_collect(rvc_set *s) {
   if (!s->pk_running) return true;
   RVC_CK(hipStreamSynchronize(s->st_pk));
   s->pk_running = false;
+  g_pk_active.fetch_sub(1);
   if (s->pk_ctl->error) {
     char buf[96];
     snprintf(buf, sizeof(buf), "persistent kernel gave up (code 0x%llx)", (unsigned long long)s->pk_ctl->error);
@@ -1043,6 +1050,7 @@ void pk_stop(rvc_set *s) {
     }
     hipStreamSynchronize(s->st_pk);
     s->pk_running = false;
+    g_pk_active.fetch_sub(1);
   }
   s->pk_retired = s->pk_seq;
   // nothing is resident any more: every flag stands at the last sequence number (the quit command is never acknowledged)
@@ -1100,7 +1108,9 @@ bool pk_step(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size
   unsigned ypre_wait = 0;
   const float2 *ypre = nullptr;
   long long ypre_stride = hb;
-  if (s->ypre_block == k0) {
+  // (an accumulator that ordinary launches left in a sweep row is not taken over: this mode's own sweeps reuse the rows)
+  const bool in_sweep_rows = s->sA && s->ypre_cur >= s->sA && s->ypre_cur < s->sA + (size_t)s->nch * (size_t)s->sa_rows * A.B;
+  if (s->ypre_block == k0 && !in_sweep_rows) {
     ypre = s->ypre_cur; ypre_stride = s->ypre_cur_stride; ypre_wait = s->pk_ypre_from;
   } else {
     if (!pk_quiesce(s)) return false;
@@ -1175,16 +1185,22 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   const long long k0 = n0 / hb, k1 = (n1 - 1) / hb;
 
   // ---- latency path: the call stays inside one head block (the plugin's per-block call) ----
-  if (k0 == k1 && s->pk_enabled) {
+  if (k0 == k1 && s->pk_enabled && !pk_paused()) {
     if (s->out_copy_len != 0) {          // host-pointer call: the resident kernel reads / writes the pinned buffers itself
       s->out_copy_len = 0;
       s->flag_count = -1;                // process_end: wait for this step's completion flags
     }
+    s->sa_t0 = -1;                       // (the sweep rows now follow the resident kernel's tile scheme)
     return pk_step(s, d_in, in_stride, d_out, out_stride, len);
   }
-  if (s->pk_enabled) {                   // any other call pattern: ordinary launches; the resident kernel idles meanwhile
-    if (!pk_quiesce(s)) return false;
+  if (s->pk_enabled) {
+    // any other call pattern -- or another thread is about to free device memory (free_guard_enter) and the resident
+    // kernel has to stand down: ordinary launches; the accumulators / sweep rows are handed over through ypre_block
+    if (pk_paused()) pk_stop(s);
+    else if (!pk_quiesce(s)) return false;
     s->pk_need_acquire = true;
+    s->pk_tile_hi = s->pk_tile_ready = -1;
+    s->pk_ypre_from = 0;
   }
   if (k0 == k1 && rvc::fused_supported(A.logB, A.f64)) {
     if (has_tail) {
@@ -1214,7 +1230,8 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     const bool block_done = n1 % hb == 0;
     // host-pointer call through the pinned buffers: the audio workgroups publish completion flags and
     // process_end polls them -- no event behind the kernel, no wait for the kernel's tail
-    const bool flagged = s->out_copy_len != 0 && s->zero_copy && !s->timing;
+    const bool flagged = s->out_copy_len != 0 && s->zero_copy && !s->timing && !s->pk_enabled;   // (persistent sets: the
+                                                       // flags carry the resident kernel's sequence numbers)
     if (flagged) {
       g.done_flag = s->h_flags;
       g.seq = ++s->flag_seq;
@@ -1455,6 +1472,19 @@ bool zero_device_out(rvc_set *s, float *d_out, size_t out_stride, size_t len) {
 }
 
 }  // namespace
+
+namespace rvc {
+void free_guard_enter() {
+  g_pk_pause.fetch_add(1, std::memory_order_acq_rel);
+  // owners stop their resident kernels at their next call; idle kernels park by themselves within 2 s (their count is
+  // only corrected when the owner collects them, hence the bound)
+  const auto t0 = std::chrono::steady_clock::now();
+  while (g_pk_active.load(std::memory_order_acquire) > 0 &&
+         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.5)
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+}
+void free_guard_leave() { g_pk_pause.fetch_sub(1, std::memory_order_acq_rel); }
+}  // namespace rvc
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -1805,8 +1835,11 @@ static int debug_fft(int device, size_t n, int f64, bool inverse, const float *i
          hipStreamSynchronize(s->st_main) == hipSuccess;
     ok = ok && hipMemcpy(out_t, d_t, sizeof(float) * n, hipMemcpyDeviceToHost) == hipSuccess;
   }
-  hipFree(d_t); hipFree(d_f);
-  free_stage(g);
+  {
+    rvc::FreeGuard guard;
+    hipFree(d_t); hipFree(d_f);
+    free_stage(g);
+  }
   rvc_set_destroy(s);
   return ok ? 1 : 0;
 }

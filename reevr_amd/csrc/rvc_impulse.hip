@@ -292,8 +292,16 @@ bool imp_ready(rvc_impulse *m) {
   return true;
 }
 
+// hipFree waits for every stream of the device, other sets' resident kernels included: see rvc::FreeGuard
+inline void imp_dev_free(void *p) {
+  if (!p) return;
+  rvc::FreeGuard guard;
+  hipFree(p);
+}
+
 void imp_free(rvc_impulse *m) {
   if (m->st) hipStreamSynchronize(m->st);
+  rvc::FreeGuard guard;
   for (int c = 0; c < 4; ++c) {
     if (m->d_raw[c]) hipFree(m->d_raw[c]);
     if (m->d_buf[c]) hipFree(m->d_buf[c]);
@@ -329,8 +337,8 @@ bool stage_a(rvc_impulse *m, const rvc_impulse_params *p) {
   if (!imp_ready(m)) return false;
   const int nblk = (int)((n + rvc::IMP_RED - 1) / rvc::IMP_RED);
   if ((size_t)nblk > m->part_cap) {
-    if (m->d_part_e) hipFree(m->d_part_e);
-    if (m->d_part_m) hipFree(m->d_part_m);
+    imp_dev_free(m->d_part_e);
+    imp_dev_free(m->d_part_m);
     m->d_part_e = nullptr; m->d_part_m = nullptr; m->part_cap = 0;
     IMP_CK(hipMalloc(&m->d_part_e, sizeof(double) * nblk));
     IMP_CK(hipMalloc(&m->d_part_m, sizeof(float) * nblk));
@@ -382,13 +390,13 @@ bool stage_b(rvc_impulse *m, const rvc_impulse_params *p) {
   const bool has_decay = p->decay_lut != nullptr;
   if (has_decay) {
     if (fstride * m->nc > m->frames_cap) {
-      if (m->d_frames) hipFree(m->d_frames);
+      imp_dev_free(m->d_frames);
       m->d_frames = nullptr; m->frames_cap = 0;
       IMP_CK(hipMalloc(&m->d_frames, sizeof(float) * fstride * m->nc));
       m->frames_cap = fstride * m->nc;
     }
     if ((size_t)nframes * rvc::IMP_LUT > m->tab_cap) {
-      if (m->d_tab) hipFree(m->d_tab);
+      imp_dev_free(m->d_tab);
       m->d_tab = nullptr; m->tab_cap = 0;
       IMP_CK(hipMalloc(&m->d_tab, sizeof(float) * (size_t)nframes * rvc::IMP_LUT));
       m->tab_cap = (size_t)nframes * rvc::IMP_LUT;
@@ -466,8 +474,8 @@ int rvc_impulse_set_raw(rvc_impulse *m, int n_channels, const float *const *raw,
   if (!imp_ready(m)) return 0;
   if (len > m->cap) {
     for (int c = 0; c < 4; ++c) {
-      if (m->d_raw[c]) hipFree(m->d_raw[c]);
-      if (m->d_buf[c]) hipFree(m->d_buf[c]);
+      imp_dev_free(m->d_raw[c]);
+      imp_dev_free(m->d_buf[c]);
       m->d_raw[c] = m->d_buf[c] = nullptr;
     }
     m->cap = 0;

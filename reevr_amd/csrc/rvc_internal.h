@@ -201,6 +201,13 @@ struct PkArgs {
   int n_audio, patch_bx;   // audio workgroups; 512-bin patch tiles per channel
   long long idle_ticks;    // wall_clock64 ticks (100 MHz) of doorbell silence after which the kernel parks itself
 };
+// hipFree / hipHostFree wait for EVERY stream of the device -- also for another set's resident kernel, which never
+// finishes while its owner keeps feeding it. Whoever is about to free device memory therefore brackets the frees with
+// free_guard_enter / _leave: resident kernels are asked to stand down (their owners stop them at their next call and use
+// ordinary launches while the request stands; idle ones park by themselves), the caller waits for that (bounded).
+void free_guard_enter();
+void free_guard_leave();
+struct FreeGuard { FreeGuard() { free_guard_enter(); } ~FreeGuard() { free_guard_leave(); } };
 bool persist_supported(int logB);
 int persist_workgroups(int logB, int channels, int *n_audio, int *patch_bx);
 hipError_t launch_persist(int logB, const PkArgs &a, int channels, hipStream_t st);

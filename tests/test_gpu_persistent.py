@@ -170,6 +170,62 @@ def test_create_destroy_rounds_and_slot_limit():
         s.close()
 
 
+def test_other_threads_free_device_memory_while_resident():
+    """hipFree waits for every stream of the device -- also for a resident kernel that is being fed. While the audio
+    thread streams blocks through a persistent set, another thread creates / re-initialises / destroys sets and impulse
+    objects (the plug-in's IR hot-swap with a new geometry): the resident kernel stands down for the frees (FreeGuard),
+    the other thread is never held for long, and the audio stays correct."""
+    import threading
+    head, tail, nblk = 512, 8192, 3000
+    irs = list(synth.synth_ir(30000, 2, 9))
+    x = np.stack([synth.synth_input(head * nblk, c) for c in range(2)])
+    want = oracle(irs, x, head, tail)
+    s = reevr_amd.ConvolverSet(2, persistent=True)
+    assert s.init(head, tail, irs, max_len=head)
+    got = []
+    stop = threading.Event()
+    worst = [0.0]
+    rounds = [0]
+    errors = []
+
+    def worker():
+        try:
+            k = 0
+            while not stop.is_set():
+                t0 = time.perf_counter()
+                b = reevr_amd.ConvolverSet(2)
+                assert b.init(256 << (k % 3), 8192, list(synth.synth_ir(5000 + 3000 * (k % 4), 2, 50 + k)), max_len=4096)
+                b.process(x[:, :3000])
+                b.close()                                   # hipFree while the other set's kernel is resident
+                imp = reevr_amd.Impulse()
+                imp.prepare(48000.0)
+                imp.setRaw(0.5 * x[0, :4000 + 1000 * (k % 3)], 0.5 * x[1, :4000 + 1000 * (k % 3)])
+                imp.recalcImpulse()
+                del imp
+                if not stop.is_set():                       # (a round cut short by the end of the stream does not count)
+                    worst[0] = max(worst[0], time.perf_counter() - t0)
+                    rounds[0] += 1
+                k += 1
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    th = threading.Thread(target=worker)
+    th.start()
+    for i in range(nblk):
+        got.append(s.process(x[:, i * head:(i + 1) * head]))
+        time.sleep(0.0003)                              # a (fast) real-time host: a block every 0.3 ms for ~1 s
+    stop.set()
+    th.join(timeout=30)
+    assert not th.is_alive() and not errors, errors
+    got = np.concatenate(got, axis=1)
+    assert s.last_error == 0, s.last_error_string
+    for c in range(2):
+        assert rel_rms(got[c], want[c]) <= TOL, c
+    assert rounds[0] >= 3, rounds[0]
+    assert worst[0] < 1.5, f"a round of create/init/destroy on the other thread took {worst[0]:.2f} s"
+    s.close()
+
+
 def test_stereo_convolver_shim_persistent_cpp():
     """examples/host_block_loop.cpp with the persistent flag: the C++ drop-in classes through the C ABI, quad (two
     resident kernels), bounded run; prints the call latency it measured."""
