@@ -150,7 +150,7 @@ struct rvc_set {
   hipEvent_t ev_ingest = nullptr;
   // Tail jobs enqueued on st_bg, oldest first. Fixed capacity and a pre-created event pool: nothing on the
   // process() / clear() path allocates (the reference's real-time rule, FFTConvolver.h:44-47).
-  struct Job { long long m_hi; hipEvent_t ev; };
+  struct Job { long long m_lo, m_hi; hipEvent_t ev; };   // produced the tail contributions of output blocks [m_lo, m_hi)
   static constexpr int kMaxJobs = 32;
   Job jobs[kMaxJobs];
   int job_head = 0, job_count = 0;
@@ -203,6 +203,8 @@ bool ensure_streams(rvc_set *s) {
     return fail(s, RVC_ERR_NO_DEVICE, e, "no usable HIP device (this engine has no CPU fallback)");
   if (!use_device(s)) return false;
   RVC_CK(rvc::prepare_kernels());
+  // (Measured for the many-channel lock-step loop, profiles/r2_bg_overlap.txt: a high-priority foreground stream and a
+  //  background stream confined to 192 / 128 / 64 CUs by a CU mask change the step time by less than 2 % either way.)
   RVC_CK(hipStreamCreateWithFlags(&s->st_main, hipStreamNonBlocking));
   RVC_CK(hipStreamCreateWithFlags(&s->st_bg, hipStreamNonBlocking));
   {
@@ -592,7 +594,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
 // Queue a tail job's completion event. The queue holds at most kMaxJobs entries; a caller that never
 // reads the tail blocks it produced (kMaxJobs tail periods without a wait) makes the oldest job's event
 // be waited for here, which frees its slot.
-bool push_job(rvc_set *s, long long m_hi, hipStream_t st) {
+bool push_job(rvc_set *s, long long m_lo, long long m_hi, hipStream_t st) {
   if (s->job_count == rvc_set::kMaxJobs) {
     rvc_set::Job &o = s->jobs[s->job_head];
     RVC_CK(hipStreamWaitEvent(s->st_main, o.ev, 0));
@@ -600,7 +602,7 @@ bool push_job(rvc_set *s, long long m_hi, hipStream_t st) {
     s->job_head = (s->job_head + 1) % rvc_set::kMaxJobs;
     --s->job_count;
   }
-  rvc_set::Job j{m_hi, s->ev_pool[--s->ev_free]};
+  rvc_set::Job j{m_lo, m_hi, s->ev_pool[--s->ev_free]};
   RVC_CK(hipEventRecord(j.ev, st));
   s->jobs[(s->job_head + s->job_count) % rvc_set::kMaxJobs] = j;
   ++s->job_count;
@@ -727,22 +729,24 @@ bool run_tail_job(rvc_set *s, long long n0, long long n1, const float *src2, siz
     RVC_CK(hipStreamWaitEvent(st, s->ev_ingest, 0));
   }
   if (!tail_spectra(s, n0, n1, src2, in_stride, st)) return false;
+  const long long m_lo = s->tail_out_done;
   if (!tail_rows(s, mb1 + 2, st)) return false;
-  if (bg && !push_job(s, mb1 + 2, st)) return false;
+  if (bg && !push_job(s, m_lo, mb1 + 2, st)) return false;
   return true;
 }
 
-// waitForBackgroundProcessing: make the foreground stream wait for the job(s) that produced the
-// tail blocks a call ending at n1 reads
+// waitForBackgroundProcessing: make the foreground stream wait for the job(s) that produced the tail blocks a call
+// ending at n1 reads -- and only those: the job enqueued when tail block m-2 completed delivers output block m, a whole
+// tail period later (TwoStageFFTConvolver.cpp:213-222: wait, swap, start the next job), and runs under the head-stage
+// work of the period in between.
 bool wait_tail_jobs(rvc_set *s, long long n1) {
   const long long m_need = (n1 - 1) / (long long)s->T.B;
-  while (s->job_count > 0 && m_need >= 2) {
+  while (s->job_count > 0 && s->jobs[s->job_head].m_lo <= m_need) {   // (jobs are ordered)
     const rvc_set::Job j = s->jobs[s->job_head];
-    RVC_CK(hipStreamWaitEvent(s->st_main, j.ev, 0));   // jobs are ordered: all up to the first one covering m_need
+    RVC_CK(hipStreamWaitEvent(s->st_main, j.ev, 0));
     s->job_head = (s->job_head + 1) % rvc_set::kMaxJobs;
     --s->job_count;
     s->ev_pool[s->ev_free++] = j.ev;
-    if (j.m_hi > m_need) break;
   }
   return true;
 }
