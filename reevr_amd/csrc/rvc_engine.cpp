@@ -207,13 +207,6 @@ bool ensure_streams(rvc_set *s) {
   //  background stream confined to 192 / 128 / 64 CUs by a CU mask change the step time by less than 2 % either way.)
   RVC_CK(hipStreamCreateWithFlags(&s->st_main, hipStreamNonBlocking));
   RVC_CK(hipStreamCreateWithFlags(&s->st_bg, hipStreamNonBlocking));
-  {
-    // the resident kernel gets a stream of its own priority class: the runtime multiplexes streams of one class onto a
-    // few hardware queues, and an ordinary launch queued behind a kernel that never ends would never start
-    int lo = 0, hi = 0;
-    RVC_CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    RVC_CK(hipStreamCreateWithPriority(&s->st_pk, hipStreamNonBlocking, hi));
-  }
   RVC_CK(hipEventCreateWithFlags(&s->ev_sweep, hipEventDisableTiming));
   RVC_CK(hipEventCreateWithFlags(&s->ev_ingest, hipEventDisableTiming));
   RVC_CK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
@@ -549,6 +542,14 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     s->sa_rows = (int)K * (pk ? 2 : 1);
     if (s->tile_A) RVC_CK(hipMalloc(&s->sA, sizeof(float2) * (size_t)s->nch * (size_t)s->sa_rows * A.B));
     if (pk) {
+      if (!s->st_pk) {
+        // the resident kernel gets a stream of its own priority class: the runtime multiplexes streams of one class onto a
+        // few hardware queues, and an ordinary launch queued behind a kernel that never ends would never start. (Created for
+        // persistent sets only: sets that never asked for one should not see a second priority class on the device.)
+        int lo = 0, hi = 0;
+        RVC_CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        RVC_CK(hipStreamCreateWithPriority(&s->st_pk, hipStreamNonBlocking, hi));
+      }
       rvc::persist_workgroups(A.logB, s->nch, &s->pk_n_audio, nullptr);
       s->pk_n_patch = rvc::persist_workgroups(A.logB, s->nch, nullptr, nullptr) - s->pk_n_audio;
       RVC_CK(hipHostMalloc(&s->pk_ctl, sizeof(rvc::PkCtl), hipHostMallocDefault));
@@ -1516,7 +1517,7 @@ void rvc_set_destroy(rvc_set *s) {
     hipEventDestroy(s->ev_ingest);
     hipEventDestroy(s->ev_out);
     hipEventDestroy(s->ev_sweep);
-    hipStreamDestroy(s->st_pk);
+    if (s->st_pk) hipStreamDestroy(s->st_pk);
     hipStreamDestroy(s->st_bg);
     hipStreamDestroy(s->st_main);
   }
