@@ -1071,13 +1071,12 @@ void pk_stop(rvc_set *s) {
 // waitForBackgroundProcessing on the HOST: the resident kernel is on no stream that could wait for an event
 bool pk_wait_tail(rvc_set *s, long long n1) {
   const long long m_need = (n1 - 1) / (long long)s->T.B;
-  while (s->job_count > 0 && m_need >= 2) {
+  while (s->job_count > 0 && s->jobs[s->job_head].m_lo <= m_need) {   // (only the jobs this call reads: cf. wait_tail_jobs)
     const rvc_set::Job j = s->jobs[s->job_head];
     RVC_CK(hipEventSynchronize(j.ev));
     s->job_head = (s->job_head + 1) % rvc_set::kMaxJobs;
     --s->job_count;
     s->ev_pool[s->ev_free++] = j.ev;
-    if (j.m_hi > m_need) break;
   }
   return true;
 }

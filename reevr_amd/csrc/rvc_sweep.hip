@@ -10,6 +10,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "rvc_internal.h"
 
@@ -99,38 +100,57 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
 
   V acc[K], w[K];
 #pragma unroll
-  for (int t = 0; t < K; ++t) {
-    acc[t] = zero;
-    const V x = loadX(cbase + t);
-    w[t] = validX(cbase + t) ? x : zero;
-  }
-  V hq[D], xq[D];
+  for (int t = 0; t < K; ++t) acc[t] = zero;
+  // Walk of the wave's partitions. Forward: partition i = 0, 1, ..: the window slides towards older rows. Reverse: i = P-1,
+  // P-2, ..: towards newer rows. With the partitions split over the four waves, neighbouring waves share K rows of the
+  // delay line (the oldest K of wave v are the window wave v+1 starts from); even waves walk in reverse, odd ones
+  // forward, so both sharers touch those rows at the same moment -- waves 0|1 and 2|3 when they start, 1|2 when they
+  // end -- and the second request is served by the CU's L1 / the XCD's L2 instead of HBM.
+  auto walk = [&](auto rev_tag) {
+    constexpr bool REV = decltype(rev_tag)::value;
+    const long long r0 = REV ? cbase - (P - 1) : cbase;          // oldest row of the first window
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    hq[d] = loadH(d);
-    xq[d] = loadX(cbase - d - 1);
-  }
-  auto step = [&](const int i, const int u) {     // u = i mod K, compile-time after unrolling
-    const V h = hq[u % D];
-    const V xin = xq[u % D];
-    hq[u % D] = loadH(i + D);
-    xq[u % D] = loadX(cbase - (i + D) - 1);
-    __builtin_amdgcn_sched_barrier(0);
-    const float hz = packed ? 0.f : h.y;            // first bin: ordinary (re, re, im) / packed (DC gain, Nyquist gain, 0)
-    const float h3 = packed ? h.y : h.x;
+    for (int t = 0; t < K; ++t) {
+      const V x = loadX(r0 + t);
+      w[t] = validX(r0 + t) ? x : zero;
+    }
+    // row entering the window behind step s, partition of step s
+    auto in_row = [&](int s) -> long long { return REV ? r0 + K + s : cbase - s - 1; };
+    auto part = [&](int s) -> int { return REV ? (P - 1 - s > 0 ? P - 1 - s : 0) : s; };
+    V hq[D], xq[D];
 #pragma unroll
-    for (int t = 0; t < K; ++t) sweep_mac(acc[t], h, w[(t - u) & (K - 1)], hz, h3);
-    w[(K - 1 - u) & (K - 1)] = validX(cbase - i - 1) ? xin : zero;
+    for (int d = 0; d < D; ++d) {
+      hq[d] = loadH(part(d));
+      xq[d] = loadX(in_row(d));
+    }
+    auto step = [&](const int s, const int u) {     // u = s mod K, compile-time after unrolling
+      const V h = hq[u % D];
+      const V xin = xq[u % D];
+      hq[u % D] = loadH(part(s + D));
+      xq[u % D] = loadX(in_row(s + D));
+      __builtin_amdgcn_sched_barrier(0);
+      const float hz = packed ? 0.f : h.y;            // first bin: ordinary (re, re, im) / packed (DC gain, Nyquist gain, 0)
+      const float h3 = packed ? h.y : h.x;
+#pragma unroll
+      for (int t = 0; t < K; ++t) sweep_mac(acc[t], h, w[(REV ? t + u : t - u) & (K - 1)], hz, h3);
+      w[(REV ? u : K - 1 - u) & (K - 1)] = validX(in_row(s)) ? xin : zero;   // (the slot of the row that just left)
+    };
+    const int Pfull = P - (P % K);
+    int s0 = 0;
+    for (; s0 < Pfull; s0 += K) {
+#pragma unroll
+      for (int u = 0; u < K; ++u) step(s0 + u, u);
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u)
+      if (s0 + u < P) step(s0 + u, u);
   };
-  const int Pfull = P - (P % K);
-  int i0 = 0;
-  for (; i0 < Pfull; i0 += K) {
-#pragma unroll
-    for (int u = 0; u < K; ++u) step(i0 + u, u);
-  }
-#pragma unroll
-  for (int u = 0; u < K; ++u)
-    if (i0 + u < P) step(i0 + u, u);
+#if defined(RVC_SWEEP_NOREV) && defined(RVC_DEV_BUILD)   // A/B switch of development builds (tools/abl_build.py)
+  walk(std::false_type());
+#else
+  if (SPLIT != 1 && (wave & 1) == 0) walk(std::true_type());
+  else walk(std::false_type());
+#endif
 
   float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
   if constexpr (SPLIT == 1) {
