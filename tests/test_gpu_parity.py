@@ -666,6 +666,36 @@ def test_time_tiling_many_channels_device_blocks():
         assert rel_rms(outs[True][c], o.process(x[c])) <= TOL, c
 
 
+@pytest.mark.parametrize("tiling", [False, True, "force"])
+@pytest.mark.parametrize("head,tail,parts,nch", [(64, 128, 5, 3), (64, 1024, 3, 2), (256, 512, 12, 2), (512, 8192, 2, 4),
+                                                  (128, 2048, 20, 1)])
+def test_device_block_loop_tail_on_second_stream(head, tail, parts, nch, tiling):
+    """The asynchronous per-block loop (rvc_set_process_device_blocks, nothing waits on the host) with the tail stage on
+    the second stream: the foreground stream runs a whole tail period ahead of each tail job (Convolver.cpp:84-95 /
+    TwoStageFFTConvolver.cpp:213-222 hook points), so every ring the two streams share is exercised with both of them
+    busy. Short tail periods (2 .. 16 head blocks), many of them; every sample against the oracle; twice, to catch
+    anything that depends on timing."""
+    import torch
+    ir_len = 2 * tail + parts * tail - tail // 3
+    irs = [synth.synth_ir(ir_len - 17 * c, 1, 700 + c)[0] for c in range(nch)]
+    nblk = max(40 * (tail // head), 600)
+    x = np.stack([synth.synth_input(head * nblk, 70 + c) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    want = []
+    for c in range(nch):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        want.append(o.process(x[c]))
+    for rep in range(2):
+        s = reevr_amd.ConvolverSet(nch, bg_stream=True, time_tiling=tiling)
+        assert s.init(head, tail, irs, max_len=head)
+        got = s.process_device_blocks(dx, head).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        s.close()
+        for c in range(nch):
+            assert rel_rms(got[c], want[c]) <= TOL, (rep, c, rel_rms(got[c], want[c]))
+
+
 @pytest.mark.parametrize("seed", list(range(16)))
 def test_fuzz_single_stage_sets(seed):
     """The same for single-stage (FFTConvolver) sets: block sizes 16..4096, IR lengths on either side of
