@@ -5,10 +5,13 @@ Headline workload (BASELINE.json configs[1], measured the way SURVEY.md 8d defin
 instances with a 10 s IR @ 48 kHz at host block 512 (-> head 512 / tail 8192,
 StereoConvolver.cpp:11-15), driven STRICTLY BLOCK-SYNCHRONOUSLY -- one process() call per
 512-frame host block, exactly the plug-in's calling pattern (src/PluginProcessor.cpp:1793-1797)
--- for `--channels` lock-step channels of ONE convolver set (default 1024 = 512 stereo instances,
+-- for `--channels` lock-step channels of ONE convolver set (default 4096 = 2048 stereo instances,
 each with its own IR). A single stereo pair moves 1.5 MB per block and cannot fill a 256-CU GPU;
-512 instances keep 8 GB of IR spectra + delay lines in HBM (>> the 256 MiB Infinity Cache), which
-is the regime the per-block delay-line sweep (FFTConvolver.cpp:176-187) is HBM-bound in.
+2048 instances keep 33 GB of IR spectra + delay lines in HBM (>> the 256 MiB Infinity Cache, 11 % of
+the 288 GB), which is the regime the per-block delay-line sweep (FFTConvolver.cpp:176-187) is
+HBM-bound in; the per-launch fixed cost (4 us launch + a 3 us dependent chain per 512-frame block) is
+amortised over 4096 channels: 512 / 1024 / 2048 / 4096 / 8192 channels were measured at
+9.2 / 10.9 / 11.5 / 12.5 / 12.2 Gsamples/s (profiles/r2_lockstep/channels_sweep.txt).
 
 Two schedules of that loop are measured in the same run, both strictly causal (nothing of a block
 is used before the block has arrived) and both with the reference's partition sizes:
@@ -130,7 +133,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5), help="BASELINE.json configuration (1-based index)")
-    ap.add_argument("--channels", type=int, default=1024, help="config 2: lock-step channels per GPU (2 per stereo instance)")
+    ap.add_argument("--channels", type=int, default=4096, help="config 2: lock-step channels per GPU (2 per stereo instance)")
     ap.add_argument("--time-tiling", type=int, default=1, help="0: RVC_FLAG_NO_TIME_TILING (the reference's per-block sweep order)")
     ap.add_argument("--blocks-per-step", type=int, default=256, help="block-synchronous configs: host blocks per step")
     ap.add_argument("--bg-stream", type=int, default=0, help="1: tail stage on the second HIP stream")
@@ -208,7 +211,9 @@ def main():
 
     t_gen = time.perf_counter()
     irs = make_irs(ir_len, instances)
-    x = np.stack([synth.synth_input(frames_step * nbuf, 2 * u + c) for u in instances for c in range(2)])
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+        x = np.stack(list(ex.map(lambda uc: synth.synth_input(frames_step * nbuf, 2 * uc[0] + uc[1]),
+                                 [(u, c) for u in instances for c in range(2)])))
     gen_s = time.perf_counter() - t_gen
     conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream), time_tiling=bool(args.time_tiling))
     t_init = time.perf_counter()

@@ -371,17 +371,27 @@ template <int LOGB, typename R> struct Tw8 {
 
 // v[e] = x[in_idx(e)] on entry, X[out_idx(e)] on exit (unscaled). `lds` holds LDS_ELEMS values.
 // Ends with all LDS reads done but NO trailing barrier.
-#ifdef RVC_ABLATE_NOBARRIER
-#define RVC_CORE_SYNC() do {} while (0)
-#else
-#define RVC_CORE_SYNC() __syncthreads()
+// SOLO: the transform lives in ONE wave that shares its workgroup with waves doing something else (k_fused_block2w): a
+// wave's LDS instructions execute in order, so the exchange needs no s_barrier -- only the compiler must not move the
+// reads above the writes (a workgroup barrier there would wait for the other waves).
+template <bool SOLO> __device__ __forceinline__ void core_sync() {
+#ifndef RVC_ABLATE_NOBARRIER
+  if constexpr (SOLO) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
 #endif
+}
+#define RVC_CORE_SYNC() core_sync<SOLO>()
 #ifdef RVC_ABLATE_CORE_NOLDS
 #define RVC_CORE_LDS(stmt) do {} while (0)
 #else
 #define RVC_CORE_LDS(stmt) stmt
 #endif
-template <int LOGB, bool INV, typename R>
+template <int LOGB, bool INV, typename R, bool SOLO = false>
 __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, R> &T, const int tid) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
@@ -924,16 +934,25 @@ __device__ __forceinline__ void xk_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, kXkAux);
 }
 
-#ifdef RVC_PK_STAMPS
+#if defined(RVC_DEV_BUILD) && defined(RVC_BLOCK_STAMPS)
+// development builds: per-workgroup timestamps of the LAST one-block launch (tools/block_stamps.py)
+__device__ unsigned long long g_block_stamps[4096 * 16];
+extern "C" int rvc_debug_block_stamps(unsigned long long *out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 1 : 0;
+}
+#define RVC_AUDIO_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (!PK && (threadIdx.x & 63) == 0 && wg < 4096) g_block_stamps[wg * 16 + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#elif defined(RVC_PK_STAMPS)
 #define RVC_AUDIO_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (PK && a.dbg && wg == 0 && threadIdx.x == 0) a.dbg[i] = (unsigned long long)wall_clock64(); } while (0)
 #else
 #define RVC_AUDIO_STAMP(i) do {} while (0)
 #endif
-template <int LOGB, bool FOLD, bool PK = false>
+template <int LOGB, bool FOLD, bool PK = false, bool SOLO = false>
 __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, const int wg) {
+  static_assert(!SOLO || (WaveSplit<LOGB>::ok && Plan8<LOGB>::WG == 64), "SOLO: the whole transform in one wave");
   typedef Plan8<LOGB> P;
   typedef cx<float> C;
   constexpr int B = P::B;
+  RVC_AUDIO_STAMP(4);
   const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;
   C *lds = reinterpret_cast<C *>(smem_raw) + sub * P::LDS_ELEMS;
   const int c_raw = wg * P::TPW + sub;
@@ -1079,7 +1098,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   // 2. forward transform, real split; X_k goes to the delay line and, times H0 plus the
   //    pre-multiplied accumulator, becomes Y_k
   RVC_AUDIO_STAMP(8);
-  fft8_core<LOGB, false, float>(v, lds, T, tid);
+  fft8_core<LOGB, false, float, SOLO>(v, lds, T, tid);
   RVC_AUDIO_STAMP(9);
   // The real split pairs bin k with bin B - k. Head blocks of 64 / 512: the whole transform lives in one wave and the
   // partner arrives through a lane reversal (wave_partner: ds_bpermute, no LDS round trip, no barrier); else through LDS.
@@ -1152,7 +1171,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   }
   if constexpr (!kWS) __syncthreads();
   RVC_AUDIO_STAMP(10);
-  fft8_core<LOGB, true, float>(v, lds, T, tid);
+  fft8_core<LOGB, true, float, SOLO>(v, lds, T, tid);
   RVC_AUDIO_STAMP(11);
   // 4. the block's samples are z[B/2 .. B); only [n0, n1) is wanted; add the tail contribution
   float *out = a.out + (long long)c * a.out_chan_stride;
@@ -1204,10 +1223,11 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       }
     }
   }
+  RVC_AUDIO_STAMP(12);
   if (a.done_flag) {   // output is in (host-visible) memory: tell the polling host, do not make it wait for kernel end
     if constexpr (PK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores: landed when acknowledged
     else __threadfence_system();
-    __syncthreads();
+    core_sync<SOLO>();
     if (threadIdx.x == 0) __hip_atomic_store(a.done_flag + wg, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
@@ -1621,6 +1641,90 @@ k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int 
   }
 }
 
+// The same patch by ONE wave for a whole 512-entry row (head block 512): 4 x (64 lanes x 2 bins) per row, the partitions
+// in rounds of three (24 requests of 16 bytes per lane in flight).
+__device__ __forceinline__ void fdl_patch_wave512(const FirArgs &a, const int c) {
+  constexpr int NQ = 4, CH = 3;
+  const int lane = (int)threadIdx.x & 63;
+  const long long B = a.B;
+  const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride + lane * 2;
+  const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride + lane * 2;
+  const long long cbase = a.k0 - a.delay;
+  float4 y[NQ];
+  {
+    const float2 *yr = a.Yadd + (long long)c * a.yadd_chan_stride + lane * 2;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) y[q] = *reinterpret_cast<const float4 *>(yr + q * 128);
+  }
+  for (int i0 = 0; i0 < a.P; i0 += CH) {                 // (uniform)
+    float4 hv[CH][NQ], xv[CH][NQ];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {                       // clamped addresses: every load is issued, unused ones dropped below
+      const int ii = i0 + u < a.P ? i0 + u : a.P - 1;
+      const long long row = cbase - ii, rr = row < 0 ? 0 : row;
+      const float2 *hr = Hc + (long long)ii * B;
+      const float2 *xr = Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        hv[u][q] = *reinterpret_cast<const float4 *>(hr + q * 128);
+        xv[u][q] = *reinterpret_cast<const float4 *>(xr + q * 128);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      if (i0 + u < a.P && cbase - (i0 + u) >= 0) {       // uniform
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const float4 h = hv[u][q], x = xv[u][q];
+          const bool packed = (q == 0 && lane == 0);     // entry 0 of the row: (DC, Nyquist), two real products
+          const float hz = packed ? 0.f : h.y;
+          const float h3 = packed ? h.y : h.x;
+          y[q].x = fmaf(h.x, x.x, y[q].x);
+          y[q].x = fmaf(-hz, x.y, y[q].x);
+          y[q].y = fmaf(h3, x.y, y[q].y);
+          y[q].y = fmaf(hz, x.x, y[q].y);
+          y[q].z = fmaf(h.z, x.z, y[q].z);
+          y[q].z = fmaf(-h.w, x.w, y[q].z);
+          y[q].w = fmaf(h.z, x.w, y[q].w);
+          y[q].w = fmaf(h.w, x.z, y[q].w);
+        }
+      }
+    }
+  }
+  float2 *yo = a.Y + (long long)c * a.y_chan_stride + lane * 2;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) *reinterpret_cast<float4 *>(yo + q * 128) = y[q];
+}
+
+// Head block 512, time-tiled delay line: ONE workgroup of two waves per channel -- wave 0 runs block k's audio path,
+// wave 1 patches block k+1's accumulator. At 2 waves per SIMD (the audio path's registers) a CU then holds the four
+// channels it is given ALL AT ONCE; with separate 256-thread patch workgroups behind the audio workgroups
+// (k_fused_block2) it held one patch workgroup at a time and the launch ended four patch rounds after it began.
+template <int LOGB>
+__global__ void __launch_bounds__(128) k_fused_block2w(const FusedArgs a, const FirArgs f) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#if defined(RVC_DEV_BUILD) && defined(RVC_ABL_NOAUDIO)
+  if (threadIdx.x < 64) return;
+#endif
+#if defined(RVC_DEV_BUILD) && defined(RVC_ABL_NOPATCH)
+  if (threadIdx.x >= 64) return;
+#endif
+  if (threadIdx.x < 64) fused_audio<LOGB, true, false, true>(a, smem_raw, blockIdx.x);
+  else if (f.P > 0) {
+#if defined(RVC_DEV_BUILD) && defined(RVC_PATCH_SLEEP)
+    for (int i = 0; i < RVC_PATCH_SLEEP; ++i) __builtin_amdgcn_s_sleep(32);   // 32 x 64 cycles ~ 0.85 us each
+#endif
+#if defined(RVC_DEV_BUILD) && defined(RVC_BLOCK_STAMPS)
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_block_stamps[blockIdx.x * 16 + 0] = (unsigned long long)wall_clock64();
+#endif
+    fdl_patch_wave512(f, blockIdx.x);
+#if defined(RVC_DEV_BUILD) && defined(RVC_BLOCK_STAMPS)
+    __builtin_amdgcn_s_waitcnt(0);
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_block_stamps[blockIdx.x * 16 + 1] = (unsigned long long)wall_clock64();
+#endif
+  }
+}
+
 // ----------------------------------------------------------------------------------------
 // Persistent block-synchronous kernel (rvc_internal.h, PkArgs): replaces one launch per 512-frame block by one
 // RESIDENT launch that is fed through a doorbell in pinned host memory -- the loop it serves is the reference's
@@ -1949,6 +2053,14 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
   b.channels = channels;
   const int n_audio = (channels + P::TPW - 1) / P::TPW;
   const bool patch = f.Yadd != nullptr && f.P <= kPatchMax && f.P >= 1;
+#if !(defined(RVC_NO_BLOCK2W) && defined(RVC_DEV_BUILD))   // (A/B switch of development builds, tools/abl_build.py)
+  if constexpr (LOGB == 9) {
+    if (patch || f.P <= 0) {
+      RVC_LAUNCH((k_fused_block2w<LOGB>), dim3(channels), dim3(128), lds, st, b, f);
+      return hipGetLastError();
+    }
+  }
+#endif
   const int fir_bx = patch ? (P::B + 511) / 512 : (P::B + 63) / 64;
   const int n_fir = f.P > 0 ? fir_bx * channels : 0;
   constexpr int kThreads = P::WG > 256 ? P::WG : 256;

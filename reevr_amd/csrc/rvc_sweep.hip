@@ -200,9 +200,9 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
   const bool split = (long long)((a.B + 127) / 128) * channels < 2048 || a.B >= 2048;
   // 16 B per lane, 4 row pairs ahead, <= 168 VGPRs (3 waves per SIMD), non-temporal loads on the own-tile form; measured
   // against 8 B per lane, deeper queues, 2 / 4 waves per SIMD on MI355X (profiles/r2_sweep_variants.txt)
-  if (split) { launch_variant<4, STAGE, 4, 4, 3, false>(a, channels, st); return; }
 #ifdef RVC_DEV_BUILD   // tuning knob of development builds only (tools/abl_build.py)
   static const int variant = std::getenv("RVC_SWEEP_VARIANT") ? std::atoi(std::getenv("RVC_SWEEP_VARIANT")) : 0;
+  if (split && variant == 0) { launch_variant<4, STAGE, 4, 4, 3, false>(a, channels, st); return; }
   switch (variant) {
     case 1: launch_variant<1, STAGE, 4, 4, 3, true>(a, channels, st); return;    // + non-temporal loads
     case 2: launch_variant<1, STAGE, 2, 8, 4, false>(a, channels, st); return;   // 8 B per lane, 8 ahead, 4 waves/SIMD
@@ -213,6 +213,8 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
     case 7: launch_variant<4, STAGE, 2, 8, 4, true>(a, channels, st); return;
     default: break;
   }
+#else
+  if (split) { launch_variant<4, STAGE, 4, 4, 3, false>(a, channels, st); return; }
 #endif
   launch_variant<1, STAGE, 4, 4, 3, true>(a, channels, st);
 }

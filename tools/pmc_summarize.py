@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--calib-write")
     ap.add_argument("--head-log", type=int, default=9)
     ap.add_argument("--tail-log", type=int, default=13)
-    ap.add_argument("--channels", type=int, default=1024)
+    ap.add_argument("--channels", type=int, default=4096)
     ap.add_argument("--time-tiling", type=int, default=1)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--command", default="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --side 0")
