@@ -1567,17 +1567,19 @@ __global__ void __launch_bounds__(256) k_fir_row(const FirArgs a) {
 constexpr int kPatchMax = kSweepRows - 1 + kSweepLagMax;   // (the persistent mode sweeps a few blocks early)
 __device__ __forceinline__ bool fdl_is_patch(const FirArgs &a) { return a.Yadd != nullptr && a.P <= kPatchMax && a.P >= 1; }
 
-template <bool PK = false>
-__device__ __forceinline__ void fdl_patch_body(const FirArgs &a, const int bx, const int c) {
+// NP = the number of partitions the code is unrolled for: exactly a.P when the caller dispatches on it (fdl_patch_any:
+// no request is issued twice), kPatchMax with clamped addresses otherwise (the resident kernel: one code path).
+template <bool PK, int NP>
+__device__ __forceinline__ void fdl_patch_n(const FirArgs &a, const int bx, const int c) {
   const int bin = bx * 512 + (int)threadIdx.x * 2;
   if (bin >= a.B) return;
   const long long B = a.B;
   const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride + bin;
   const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride + bin;
   const long long cbase = a.k0 - a.delay;
-  float4 hv[kPatchMax], xv[kPatchMax];
+  float4 hv[NP], xv[NP];
 #pragma unroll
-  for (int i = 0; i < kPatchMax; ++i) {                 // clamped addresses: every load is issued, unused ones dropped below
+  for (int i = 0; i < NP; ++i) {                        // clamped addresses: every load is issued, unused ones dropped below
     const int ii = i < a.P ? i : a.P - 1;
     const long long row = cbase - ii, rr = row < 0 ? 0 : row;
     hv[i] = *reinterpret_cast<const float4 *>(Hc + (long long)ii * B);
@@ -1594,7 +1596,7 @@ __device__ __forceinline__ void fdl_patch_body(const FirArgs &a, const int bx, c
   }
   const bool packed = (bin == 0);
 #pragma unroll
-  for (int i = 0; i < kPatchMax; ++i) {
+  for (int i = 0; i < NP; ++i) {
     if (i < a.P && cbase - i >= 0) {                   // uniform
       const float4 h = hv[i], x = xv[i];
       const float hz = packed ? 0.f : h.y;
@@ -1613,9 +1615,27 @@ __device__ __forceinline__ void fdl_patch_body(const FirArgs &a, const int bx, c
   if constexpr (PK) xk_st4(xk_rsrc(yo), (unsigned)bin * 8u, y);
   else *reinterpret_cast<float4 *>(yo + bin) = y;
 }
+template <bool PK = false>
+__device__ __forceinline__ void fdl_patch_body(const FirArgs &a, const int bx, const int c) { fdl_patch_n<PK, kPatchMax>(a, bx, c); }
+// dispatch on the (launch-uniform) partition count
+__device__ __forceinline__ void fdl_patch_any(const FirArgs &a, const int bx, const int c) {
+  static_assert(kPatchMax == 10, "cases below");
+  switch (a.P) {
+    case 1: fdl_patch_n<false, 1>(a, bx, c); break;
+    case 2: fdl_patch_n<false, 2>(a, bx, c); break;
+    case 3: fdl_patch_n<false, 3>(a, bx, c); break;
+    case 4: fdl_patch_n<false, 4>(a, bx, c); break;
+    case 5: fdl_patch_n<false, 5>(a, bx, c); break;
+    case 6: fdl_patch_n<false, 6>(a, bx, c); break;
+    case 7: fdl_patch_n<false, 7>(a, bx, c); break;
+    case 8: fdl_patch_n<false, 8>(a, bx, c); break;
+    case 9: fdl_patch_n<false, 9>(a, bx, c); break;
+    default: fdl_patch_n<false, 10>(a, bx, c); break;
+  }
+}
 
 template <int STAGE>
-__global__ void __launch_bounds__(256) k_fdl_patch(const FirArgs a) { fdl_patch_body<false>(a, blockIdx.x, blockIdx.y); }
+__global__ void __launch_bounds__(256) k_fdl_patch(const FirArgs a) { fdl_patch_any(a, blockIdx.x, blockIdx.y); }
 
 // One launch per block of the streaming path: workgroups [0, n_audio) run block k's audio path
 // (fused_audio<FOLD = true>), the rest compute sum_{i>=2} H_i X_{k+1-i} for block k+1 (fir_row_body;
