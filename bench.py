@@ -28,8 +28,12 @@ same work. Inputs / outputs are resident in HBM (two batches, rotated).
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
 N > 1: instances are dealt to ranks (unit mod world), every rank runs the same
-number of channels (weak scaling), no data-path collective; the output batch of every step is
-gathered with ONE RCCL all_gather per step (`--gather 0` turns it off). One JSON line on rank 0.
+number of channels (weak scaling), no data-path collective. The gather of output blocks north_star names is ONE RCCL
+all_gather per step, issued asynchronously and overlapped with the next step: configs 4 and 5 gather every channel (one
+job whose outputs are collected); config 2 hosts thousands of independent instances per GPU whose outputs have no consumer
+on the other GPUs, so by default it gathers the output blocks of 8 stereo instances per GPU -- config 4's size -- and
+`--gather 2` gathers every channel (at 4096 channels per GPU that is ~400 GB/s inbound per GPU on 8 GPUs, the xGMI
+links' whole capacity); `--gather 0` turns it off. One JSON line on rank 0.
 
 Other BASELINE configurations: `--config 4` (8 stereo instances sharded over the ranks, block-synchronous,
 strong scaling) and `--config 5` (64 mono channels, 5 s IR, block 4096, offline render = one long
@@ -137,7 +141,9 @@ def main():
     ap.add_argument("--time-tiling", type=int, default=1, help="0: RVC_FLAG_NO_TIME_TILING (the reference's per-block sweep order)")
     ap.add_argument("--blocks-per-step", type=int, default=256, help="block-synchronous configs: host blocks per step")
     ap.add_argument("--bg-stream", type=int, default=0, help="1: tail stage on the second HIP stream")
-    ap.add_argument("--gather", type=int, default=1, help="N > 1: RCCL all_gather of every step's output batch (0: off)")
+    ap.add_argument("--gather", type=int, default=1,
+                    help="N > 1: RCCL all_gather per step; 1: configs 4/5 every channel, config 2 the outputs of 8 stereo "
+                         "instances per GPU; 2: every channel; 0: off")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--side", type=int, default=1, help="0: skip the side measurements")
     ap.add_argument("--watchdog", type=float, default=1500.0,
@@ -229,8 +235,9 @@ def main():
     # N > 1: the output batch of every step is gathered with ONE all_gather, overlapped with the next step's compute:
     # the collective is ordered behind this step's kernels (torch's current stream waits for the set's stream) and runs
     # on the communicator's stream; a batch buffer is reused only after its own gather has completed.
-    g_out = [torch.empty((world,) + (nch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
-    g_stage = [torch.empty((nch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
+    gch = nch if (args.gather >= 2 or args.config != 2) else min(nch, 16)      # channels per rank that are gathered
+    g_out = [torch.empty((world,) + (gch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
+    g_stage = [torch.empty((gch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
     pending = [None] * nbuf
 
     def step(gather=True):
@@ -241,11 +248,15 @@ def main():
             if pending[b] is not None:         # the gather that read this batch's buffers two steps ago
                 pending[b].wait()
                 pending[b] = None
-            yo = g_stage[b]                    # contiguous: the collective reads it in place
+            # (every channel gathered: the set writes the contiguous staging batch the collective reads in place)
+            yo = g_stage[b] if gch == nch else d_out[:, b * frames_step:(b + 1) * frames_step]
             if long_call:
                 conv.process_device(xi, yo, sync=False, order=True)
             else:
                 conv.process_device_blocks(xi, host_block, yo, sync=False, order=True)
+            if gch != nch:
+                g_stage[b].copy_(yo[:gch])     # (torch's current stream, ordered behind the set's stream by order=True)
+                yo = g_stage[b]
             pending[b] = shard.gather_batches_async(yo, g_out[b], dist)
             return
         yo = d_out[:, b * frames_step:(b + 1) * frames_step]
@@ -456,9 +467,9 @@ def main():
                    "call": ("one process() per step" if long_call else
                             "one process_device() per 512-frame host block for all channels (rvc_set_process_device_blocks), "
                             "device-resident I/O, %d input/output batches rotated" % nbuf),
-                   "pre_roll_steps": pre, "gather": do_gather,
+                   "pre_roll_steps": pre, "gather": do_gather, "gathered_channels_per_gpu": gch if do_gather else 0,
                    "sharding": "instances dealt to ranks, equal shards, no data-path collective"
-                               + ("; one RCCL all_gather of the output batch per step, overlapped with the next step" if do_gather else "")},
+                               + (f"; one RCCL all_gather of the output blocks of {gch} channels per GPU per step, overlapped with the next step" if do_gather else "")},
         "roofline": roof,
         "roofline_all": roof_all,
         "path_roofline": path,

@@ -33,8 +33,10 @@ def _ndev():
 
 
 @pytest.mark.parametrize("extra", [["--config", "2", "--channels", "8", "--blocks-per-step", "32"],
+                                   ["--config", "2", "--channels", "40", "--blocks-per-step", "32"],
+                                   ["--config", "2", "--channels", "40", "--blocks-per-step", "32", "--gather", "2"],
                                    ["--config", "4", "--blocks-per-step", "32"],
-                                   ["--config", "5"]], ids=["cfg2", "cfg4", "cfg5"])
+                                   ["--config", "5"]], ids=["cfg2", "cfg2_bounded_gather", "cfg2_full_gather", "cfg4", "cfg5"])
 def test_bench_two_ranks(extra):
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
@@ -53,7 +55,10 @@ def test_bench_two_ranks(extra):
     want_scaling = "weak" if extra[1] == "2" else "strong"
     assert rec["scaling"] == want_scaling
     if extra[1] == "2":
-        assert rec["config"]["channels_per_gpu"] == 8 and rec["config"]["instances_total"] == 8
+        nch = int(extra[3])
+        assert rec["config"]["channels_per_gpu"] == nch and rec["config"]["instances_total"] == nch
+        # default: the output blocks of 8 stereo instances per GPU are gathered; --gather 2: every channel
+        assert rec["config"]["gathered_channels_per_gpu"] == (nch if "--gather" in extra else min(nch, 16))
     if extra[1] == "4":
         assert rec["config"]["channels_per_gpu"] == 8          # 8 stereo instances over 2 ranks
     if extra[1] == "5":
