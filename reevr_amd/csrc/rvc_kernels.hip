@@ -7,6 +7,7 @@
 //   k_fft8_inv / k_fft_inv     OouraFFT::ifft  AudioFFT.cpp:139-159 (+ Sum / overlap, FFTConvolver.cpp:193,204;
 //                                              tail add-back TwoStageFFTConvolver.cpp:171-190)
 //   k_fused_block / k_fused_block2   one whole per-block process() call (TwoStageFFTConvolver.cpp:151-233, len <= head)
+//   k_fused_block2w            the same for head block 512 with a time-tiled delay line: audio wave + patch wave per channel
 //   k_persist                  the same, as ONE resident launch fed through a command ring (RVC_FLAG_PERSISTENT)
 //   k_fdl_patch                the few partitions a block adds on top of a sweep row of the time-tiled delay line
 //                              (the sweep itself: rvc_sweep.hip; both replace the per-block loop FFTConvolver.cpp:176-187)
@@ -1718,22 +1719,14 @@ __device__ __forceinline__ void fdl_patch_wave512(const FirArgs &a, const int c)
 
 // Head block 512, time-tiled delay line: ONE workgroup of two waves per channel -- wave 0 runs block k's audio path,
 // wave 1 patches block k+1's accumulator. At 2 waves per SIMD (the audio path's registers) a CU then holds the four
-// channels it is given ALL AT ONCE; with separate 256-thread patch workgroups behind the audio workgroups
-// (k_fused_block2) it held one patch workgroup at a time and the launch ended four patch rounds after it began.
+// channels it is given ALL AT ONCE, and the launch dispatches a quarter of the waves k_fused_block2 does (256-thread
+// audio workgroups of which three waves retire at once + separate 256-thread patch workgroups, one resident per CU).
+// Measured for 1024 channels: 17.4 -> 17.0 us per launch; where the rest goes: DESIGN.md section 7, tools/block_stamps.py.
 template <int LOGB>
 __global__ void __launch_bounds__(128) k_fused_block2w(const FusedArgs a, const FirArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-#if defined(RVC_DEV_BUILD) && defined(RVC_ABL_NOAUDIO)
-  if (threadIdx.x < 64) return;
-#endif
-#if defined(RVC_DEV_BUILD) && defined(RVC_ABL_NOPATCH)
-  if (threadIdx.x >= 64) return;
-#endif
   if (threadIdx.x < 64) fused_audio<LOGB, true, false, true>(a, smem_raw, blockIdx.x);
   else if (f.P > 0) {
-#if defined(RVC_DEV_BUILD) && defined(RVC_PATCH_SLEEP)
-    for (int i = 0; i < RVC_PATCH_SLEEP; ++i) __builtin_amdgcn_s_sleep(32);   // 32 x 64 cycles ~ 0.85 us each
-#endif
 #if defined(RVC_DEV_BUILD) && defined(RVC_BLOCK_STAMPS)
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_block_stamps[blockIdx.x * 16 + 0] = (unsigned long long)wall_clock64();
 #endif
