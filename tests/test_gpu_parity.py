@@ -666,6 +666,31 @@ def test_time_tiling_many_channels_device_blocks():
         assert rel_rms(outs[True][c], o.process(x[c])) <= TOL, c
 
 
+def test_lockstep_1024_channels_at_bench_geometry():
+    """The bench's regime at a size the oracle can follow: 1024 lock-step channels (8 GB resident), 10 s IRs, head 512 /
+    tail 8192, 300 per-block calls through the device entry (two tail sweep tiles, 37 head tiles; several workgroup rounds
+    per launch). Six channels spread over the set against the oracle; and channel pairs that were given the same IR and
+    the same input must agree bit for bit wherever they run."""
+    import torch
+    nch, head, tail, nblk = 1024, 512, 8192, 300
+    base = [synth.synth_ir(480000, 2, inst=i) for i in range(4)]
+    irs = [base[(c // 2) % 4][c % 2] for c in range(nch)]
+    xs = [synth.synth_input(head * nblk, 90 + i) for i in range(8)]
+    x = np.stack([xs[c % 8] for c in range(nch)])            # channels c and c + 8 share IR and input
+    s = reevr_amd.ConvolverSet(nch)
+    assert s.init(head, tail, irs, max_len=head), s.last_error_string
+    got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
+    assert s.last_error == 0, s.last_error_string
+    s.close()
+    for c in (0, 1, 6, 511, 777, 1023):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(got[c], o.process(x[c])) <= TOL, c
+    for c in range(8):
+        for d in range(c + 8, nch, 8):
+            assert np.array_equal(got[c], got[d]), (c, d)
+
+
 @pytest.mark.parametrize("tiling", [False, True, "force"])
 @pytest.mark.parametrize("head,tail,parts,nch", [(64, 128, 5, 3), (64, 1024, 3, 2), (256, 512, 12, 2), (512, 8192, 2, 4),
                                                   (128, 2048, 20, 1)])
