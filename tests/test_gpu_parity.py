@@ -691,6 +691,32 @@ def test_lockstep_1024_channels_at_bench_geometry():
             assert np.array_equal(got[c], got[d]), (c, d)
 
 
+def test_lockstep_4096_channels_impulse_identity():
+    """bench.py's default size (4096 lock-step channels, 33 GB resident, several workgroup rounds per launch) through
+    size-independent properties: a unit impulse in gives the IR out (the definition of the convolution) on channels
+    spread over the set, and all channels that share an IR agree bit for bit -- compared on the device."""
+    import torch
+    nch, head, tail, nblk, at = 4096, 512, 8192, 200, 5
+    base = [synth.synth_ir(480000, 2, inst=i) for i in range(4)]
+    irs = [base[(c // 2) % 4][c % 2] for c in range(nch)]
+    s = reevr_amd.ConvolverSet(nch)
+    assert s.init(head, tail, irs, max_len=head), s.last_error_string
+    n = head * nblk
+    dx = torch.zeros((nch, n), device="cuda")
+    dx[:, at] = 1.0
+    dy = s.process_device_blocks(dx, head)
+    assert s.last_error == 0, s.last_error_string
+    s.close()
+    for c in range(8):                                   # 8 distinct (IR, channel) combinations, cycled
+        ref = dy[c]
+        want = np.zeros(n, np.float32)
+        want[at:] = irs[c][:n - at]
+        err = np.sqrt(np.mean((ref.cpu().numpy().astype(np.float64) - want) ** 2))
+        assert err <= 1e-7, (c, err)
+        same = dy[c::8]
+        assert bool((same == ref.unsqueeze(0)).all()), c
+
+
 @pytest.mark.parametrize("tiling", [False, True, "force"])
 @pytest.mark.parametrize("head,tail,parts,nch", [(64, 128, 5, 3), (64, 1024, 3, 2), (256, 512, 12, 2), (512, 8192, 2, 4),
                                                   (128, 2048, 20, 1)])
