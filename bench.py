@@ -39,7 +39,7 @@ Other BASELINE configurations: `--config 4` (8 stereo instances sharded over the
 strong scaling) and `--config 5` (64 mono channels, 5 s IR, block 4096, offline render = one long
 call per step, sharded 64/N per rank, strong scaling).
 
-Side numbers on the same line (rank 0, N = 1): one stereo pair block-synchronously (the plug-in's own
+Side numbers on the same line (rank 0, N = 1): the same loop with 1024 channels per launch, one stereo pair block-synchronously (the plug-in's own
 case: latency per block), the offline long-call rate of a stereo pair (adaptive partitioning), the
 same forced through the reference's partition sizes, and the CPU baseline.
 """
@@ -441,6 +441,29 @@ def main():
                 "note": "RVC_FLAG_NO_TIME_TILING: same channels / inputs / call pattern, every 512-frame block sweeps all 32 + 57 "
                         "partitions (FFTConvolver.cpp:176-187): physical bytes = SURVEY.md 8d algorithmic bytes"}
             rconv.close()
+        if tiled and nch > 1024:   # the same loop with a quarter of the channels per launch (the fixed cost of a launch shows)
+            qn = 1024
+            qconv = reevr_amd.ConvolverSet(qn, device=local_rank, bg_stream=bool(args.bg_stream), time_tiling=True)
+            assert qconv.init(host_block, tail, irs[:qn], max_len=host_block)
+
+            def qstep(i):
+                b = i % nbuf
+                qconv.process_device_blocks(d_in[:qn, b * frames_step:(b + 1) * frames_step], host_block,
+                                            d_out[:qn, b * frames_step:(b + 1) * frames_step], sync=False, order=False)
+            for i in range(pre + 1):
+                qstep(i)
+            qconv.sync()
+            qsteps = max(4, args.steps // 2)
+            tq = time.perf_counter()
+            for i in range(qsteps):
+                qstep(i)
+            qconv.sync()
+            tq = time.perf_counter() - tq
+            side["lockstep_1024_channels"] = {"value": round(qn * frames_step * qsteps / tq / 1e6, 3), "unit": "Msamples/s",
+                                              "steps": qsteps, "ms_per_step": round(tq / qsteps * 1e3, 4),
+                                              "note": "same loop, schedule and kernels with 1024 channels (512 stereo instances, "
+                                                      "8 GB resident) per launch"}
+            qconv.close()
         del d_in, d_out
         torch.cuda.empty_cache()
         side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
