@@ -145,11 +145,15 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
     for (int u = 0; u < K; ++u)
       if (s0 + u < P) step(s0 + u, u);
   };
+  // (a wave without partitions -- fewer partitions than waves -- requests nothing: its clamped IR row would be the row
+  //  BEHIND the channel's last partition, for the last channel behind the allocation)
 #if defined(RVC_SWEEP_NOREV) && defined(RVC_DEV_BUILD)   // A/B switch of development builds (tools/abl_build.py)
-  walk(std::false_type());
+  if (P > 0) walk(std::false_type());
 #else
-  if (SPLIT != 1 && (wave & 1) == 0) walk(std::true_type());
-  else walk(std::false_type());
+  if (P > 0) {
+    if (SPLIT != 1 && (wave & 1) == 0) walk(std::true_type());
+    else walk(std::false_type());
+  }
 #endif
 
   float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;

@@ -1,17 +1,24 @@
 """Run the seeded fuzz tests over many more seeds than the suite does (GPU box):
     python tests/stress_fuzz.py [first] [count]"""
-import os, sys, traceback
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import test_gpu_parity as T
+from tests import test_gpu_persistent as TP
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-bad = 0
+bad = runs = 0
 for seed in range(first, first + count):
-    for fn in (T.test_fuzz_geometry_and_call_pattern, T.test_fuzz_single_stage_sets):
+    jobs = [(T.test_fuzz_geometry_and_call_pattern, (seed, "default")), (T.test_fuzz_geometry_and_call_pattern, (seed, "force")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, False)), (T.test_fuzz_block_synchronous_time_tiling, (seed, True)),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "force")), (T.test_fuzz_single_stage_sets, (seed,)), (TP.test_fuzz_call_patterns_persistent, (seed,))]
+    for fn, a in jobs:
+        runs += 1
+        if os.environ.get("STRESS_LOG"):
+            print("RUN", fn.__name__, a, flush=True)
         try:
-            fn(seed)
+            fn(*a)
         except Exception as e:
             bad += 1
-            print("FAIL", fn.__name__, seed, str(e)[:300])
-print("seeds", first, "..", first + count - 1, "failures", bad)
+            print("FAIL", fn.__name__, a, str(e)[:300], flush=True)
+print("seeds", first, "..", first + count - 1, "runs", runs, "failures", bad)

@@ -585,7 +585,7 @@ def test_fuzz_geometry_and_call_pattern(seed, tiling):
 
 
 @pytest.mark.parametrize("tiling", [True, False, "force"])
-@pytest.mark.parametrize("seed", list(range(24)))
+@pytest.mark.parametrize("seed", list(range(24)) + [226])   # 226: 3 tail partitions on 4 sweep waves (a wave without work)
 def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     """The plug-in's calling pattern -- one call per host block, now and then a ragged one, several calls inside one
     block, a multi-block call or a block-aligned clear() -- over many sweep tiles (8 blocks each), with the causal
