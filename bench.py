@@ -9,21 +9,28 @@ StereoConvolver.cpp:11-15), driven STRICTLY BLOCK-SYNCHRONOUSLY -- one process()
 each with its own IR). A single stereo pair moves 1.5 MB per block and cannot fill a 256-CU GPU;
 2048 instances keep 33 GB of IR spectra + delay lines in HBM (>> the 256 MiB Infinity Cache, 11 % of
 the 288 GB), which is the regime the per-block delay-line sweep (FFTConvolver.cpp:176-187) is
-HBM-bound in; the per-launch fixed cost (4 us launch + a 3 us dependent chain per 512-frame block) is
-amortised over 4096 channels: 512 / 1024 / 2048 / 4096 / 8192 channels were measured at
-9.2 / 10.9 / 11.5 / 12.5 / 12.2 Gsamples/s (profiles/r2_lockstep/channels_sweep.txt).
+HBM-bound in.
 
 Two schedules of that loop are measured in the same run, both strictly causal (nothing of a block
 is used before the block has arrived) and both with the reference's partition sizes:
   * `value`: the engine's default, causal TIME TILING -- every 8th block a sweep reads a stage's IR
     spectra and delay line once and leaves partial sums for the next 8 blocks, the blocks in between
-    add their few recent partitions (DESIGN.md): ~3.5x fewer HBM bytes than the reference's loop nest;
+    add their few recent partitions; long delay lines get two levels of it (DESIGN.md);
   * `reference_schedule`: RVC_FLAG_NO_TIME_TILING, every block sweeps every partition like
-    FFTConvolver.cpp:176-187: physical bytes = SURVEY.md 8d's algorithmic bytes, frac <= 1.
+    FFTConvolver.cpp:176-187: physical bytes = SURVEY.md 8d's algorithmic bytes, frac <= 1. Its
+    fraction of the HBM peak is `roofline.alg_frac_reference_schedule`.
+
+The other BASELINE configurations run in the SAME lock-step regime in the same default run
+(`--configs 1,3,5`; entries `config1` / `config3` / `config5` of the line): config 1 (mono, 1 s IR,
+one FFTConvolver of block 512), config 3 (30 s IR @ 96 kHz, block 256 -> head 256 / tail 8192,
+350 tail partitions) and config 5's geometry (5 s IR, block 4096) -- each with both schedules and
+the CPU reference timed beside it.
 
 A "step" is `--blocks-per-step` consecutive host blocks (default 256 = 16 tail periods = 131072
 frames = 2.7 s of audio per channel): 256 per-block launches + 16 tail jobs, so every step does the
-same work. Inputs / outputs are resident in HBM (two batches, rotated).
+same work. Inputs / outputs are resident in HBM (two batches, rotated). The timed run carries its own
+correctness probe: channel 0 is fed unit impulses instead of noise, and its output in the LAST timed
+step must be the (shifted, overlapped) impulse response.
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
@@ -32,16 +39,15 @@ number of channels (weak scaling), no data-path collective. The gather of output
 all_gather per step, issued asynchronously and overlapped with the next step: configs 4 and 5 gather every channel (one
 job whose outputs are collected); config 2 hosts thousands of independent instances per GPU whose outputs have no consumer
 on the other GPUs, so by default it gathers the output blocks of 8 stereo instances per GPU -- config 4's size -- and
-`--gather 2` gathers every channel (at 4096 channels per GPU that is ~400 GB/s inbound per GPU on 8 GPUs, the xGMI
-links' whole capacity); `--gather 0` turns it off. One JSON line on rank 0.
+`--gather 2` gathers every channel; `--gather 0` turns it off. Under torch.distributed.run the collective also runs with
+ONE rank (the RCCL code path on a 1-GPU box). One JSON line on rank 0.
 
-Other BASELINE configurations: `--config 4` (8 stereo instances sharded over the ranks, block-synchronous,
-strong scaling) and `--config 5` (64 mono channels, 5 s IR, block 4096, offline render = one long
-call per step, sharded 64/N per rank, strong scaling).
+`--config 4` (8 stereo instances sharded over the ranks, block-synchronous, strong scaling) and `--config 5` (64 mono
+channels, 5 s IR, block 4096, offline render = one long call per step, sharded 64/N per rank, strong scaling) are the
+multi-GPU forms of those configurations; `--config 1` / `--config 3` run that configuration as the headline.
 
-Side numbers on the same line (rank 0, N = 1): the same loop with 1024 channels per launch, one stereo pair block-synchronously (the plug-in's own
-case: latency per block), the offline long-call rate of a stereo pair (adaptive partitioning), the
-same forced through the reference's partition sizes, and the CPU baseline.
+Side numbers on the same line (rank 0, N = 1): one stereo pair block-synchronously (the plug-in's own case: latency per
+block), the offline long-call rate of a stereo pair, and the CPU baselines.
 """
 from __future__ import annotations
 
@@ -61,6 +67,21 @@ import numpy as np  # noqa: E402
 SR = 48000
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3  # vector fp32 (same guide)
+K2 = 8                    # rvc::kSweepRows: the tile the per-block patches work on
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3_traffic.json")
+
+# BASELINE.json configurations as lock-step workloads: IR length, host block, single-stage?, default channels per GPU,
+# host blocks per step (whole tail periods)
+WORKLOADS = {
+    1: dict(ir_len=48000, host_block=512, single=True, channels=8192, blocks=256,
+            text="mono, 1 s IR @ 48 kHz, block=512, single FFTConvolver"),
+    2: dict(ir_len=480000, host_block=512, single=False, channels=4096, blocks=256,
+            text="stereo, 10 s IR @ 48 kHz, block=512 (head 512 / tail 8192), TwoStage convolver"),
+    3: dict(ir_len=2880000, host_block=256, single=False, channels=1024, blocks=256,
+            text="stereo, 30 s IR @ 96 kHz, block=256 (head 256 / tail 8192; 64 + 350 partitions), TwoStage convolver"),
+    5: dict(ir_len=240000, host_block=4096, single=False, channels=4096, blocks=32,
+            text="mono channels, 5 s IR @ 48 kHz, block=4096 (head 4096 / tail 8192), TwoStage convolver"),
+}
 
 
 def alg_bytes_block(B: int, P: int) -> int:
@@ -69,7 +90,10 @@ def alg_bytes_block(B: int, P: int) -> int:
 
 
 def ref_partitions(head: int, tail: int, ir_len: int):
-    """Partition counts of the reference's head / tail0 / tail sub-convolvers (TwoStageFFTConvolver.cpp:117-138)."""
+    """Partition counts of the reference's head / tail0 / tail sub-convolvers (TwoStageFFTConvolver.cpp:117-138);
+    tail == 0: one FFTConvolver of block `head` (FFTConvolver.cpp:113-116)."""
+    if not tail:
+        return -(-ir_len // head), 0, 0
     p_head = -(-min(ir_len, tail) // head)
     p_t0 = -(-min(max(ir_len - tail, 0), tail) // head)
     p_t = -(-max(ir_len - 2 * tail, 0) // tail)
@@ -79,6 +103,8 @@ def ref_partitions(head: int, tail: int, ir_len: int):
 def alg_bytes_per_sample(head: int, tail: int, ir_len: int) -> float:
     """Per channel-sample, reference structure head / tail0 / tail."""
     p_head, p_t0, p_t = ref_partitions(head, tail, ir_len)
+    if not tail:
+        return alg_bytes_block(head, p_head) / head
     per_tail_block = (tail // head) * (alg_bytes_block(head, p_head) + (alg_bytes_block(head, p_t0) if p_t0 else 0))
     per_tail_block += alg_bytes_block(tail, p_t) if p_t else 0
     return per_tail_block / tail
@@ -90,21 +116,26 @@ def flops_per_sample(head: int, tail: int, ir_len: int) -> float:
         N = 2 * B
         return 2 * 2.5 * N * np.log2(N) + 8 * P * (B + 1)
     p_head, p_t0, p_t = ref_partitions(head, tail, ir_len)
+    if not tail:
+        return float(blk(head, p_head) / head)
     per = (tail // head) * (blk(head, p_head) + (blk(head, p_t0) if p_t0 else 0)) + (blk(tail, p_t) if p_t else 0)
     return float(per / tail)
 
 
-def make_irs(ir_len: int, instances):
-    """One synthetic stereo IR per instance (reevr_amd.synth), generated in parallel."""
+def make_irs(ir_len: int, instances, distinct: int = 0):
+    """One synthetic stereo IR per instance (reevr_amd.synth), generated in parallel. distinct > 0: only
+    that many different instances are synthesised and cycled through (every channel still gets its OWN spectra in HBM)."""
     from reevr_amd import synth
+    ids = list(instances)
+    uniq = sorted(set(i % distinct for i in ids)) if distinct else sorted(set(ids))
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
-        sets = list(ex.map(lambda i: synth.synth_ir(ir_len, 2, inst=i), instances))
-    return [s[c] for s in sets for c in range(2)]
+        sets = dict(zip(uniq, ex.map(lambda i: synth.synth_ir(ir_len, 2, inst=i), uniq)))
+    return [sets[i % distinct if distinct else i][c] for i in ids for c in range(2)]
 
 
-def cpu_baseline(irs, x, head_block: int, budget_s: float) -> dict:
+def cpu_baseline(irs, x, head_block: int, tail: int, budget_s: float, what: str) -> dict:
     """The reference itself (oracle/_ref, kind "reference") or the C restatement (kind "port") on this
-    host's cores: 512-frame process() calls back to back, tail inline, one instance per thread, driven
+    host's cores: host-block-sized process() calls back to back, tail inline, one instance per thread, driven
     by a pthread loop in C (oracle/cpu_bench.c -- no Python in the loop). Bounded to ~budget_s."""
     from oracle import oracle_py as O
     which = "ref" if O.have_ref() else "orc"
@@ -117,12 +148,12 @@ def cpu_baseline(irs, x, head_block: int, budget_s: float) -> dict:
                 break
     except OSError:
         pass
-    n1, w1, _ = O.cpu_bench(which, 1, head_block, 8192, head_block, irs[:2], x[:2], budget_s * 0.4)
-    nm, wm, per = O.cpu_bench(which, cores, head_block, 8192, head_block, irs, x, budget_s * 0.6)
+    n1, w1, _ = O.cpu_bench(which, 1, head_block, tail, head_block, irs[:1], x[:1], budget_s * 0.4)
+    nm, wm, per = O.cpu_bench(which, cores, head_block, tail, head_block, irs, x, budget_s * 0.6)
     return {
         "value": round(n1 / w1 / 1e6, 3), "unit": "Msamples/s", "cores": 1,
         "kind": "reference" if which == "ref" else "port",
-        "sample": f"mono instance, 10 s IR, head {head_block} / tail 8192, {head_block}-frame process() calls back to back, "
+        "sample": f"mono instance, {what}, {head_block}-frame process() calls back to back, "
                   f"tail inline: {n1} samples in {w1:.1f} s on 1 thread (C loop, oracle/cpu_bench.c)",
         "cpu_model": model, "flags": "g++ -O3 (SSE2 MAC as shipped, Utilities.cpp:62-111)",
         "all_cores": {"value": round(nm / wm / 1e6, 3), "cores": cores,
@@ -131,21 +162,293 @@ def cpu_baseline(irs, x, head_block: int, budget_s: float) -> dict:
     }
 
 
+def geometry(host_block: int, single: bool):
+    head = 1
+    while head < host_block:
+        head *= 2
+    return head, (0 if single else max(8192, 2 * head))                # StereoConvolver.cpp:11-15
+
+
+def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block: int, tiled: bool) -> dict:
+    """Bytes per LAUNCH of each kernel family. Reference schedule: SURVEY.md 8d's algorithmic figures (what the
+    reference's loop nest moves = what these kernels move). Time-tiled schedule: the bytes of the structure
+    actually executed, so that frac <= 1 means what it says."""
+    n1 = nch // max(1, conv.subsets)                       # channels per launch (child sets launch separately)
+    PA, PT = conv.partitions(0), conv.partitions(1)
+    p_head, p_t0, p_t = ref_partitions(head, tail, ir_len)
+    row_h, row_t = 8.0 * head * n1, 8.0 * max(tail, 1) * n1   # bytes of one spectrum row of every channel of a launch
+    io_blk = n1 * (4.0 * 3 * head + 4.0 * 2 * head)        # per block: input + history + tail ring read, output + ring written
+    if not tiled:
+        exe = {
+            # the per-block launch does one head block of the reference's head AND tail0 sub-convolvers
+            "fused_block": float(n1 * (alg_bytes_block(head, p_head) + (alg_bytes_block(head, p_t0) if p_t0 else 0))),
+            "premultiply": float(n1 * 16 * PA * (head + 1)),
+            "fir_head": float(n1 * 16 * PA * (head + 1)),
+            "fft_fwd_head": float(n1 * (4 * head + 8 * (head + 1))),
+            "fft_inv_head": float(n1 * (8 * (head + 1) + 12 * head)),
+            "ingest": float(n1 * 8 * host_block),
+        }
+        if tail:
+            exe.update({"fir_tail": float(n1 * 16 * p_t * (tail + 1)),
+                        "fft_fwd_tail": float(n1 * (4 * tail + 8 * (tail + 1))),
+                        "fft_inv_tail": float(n1 * (8 * (tail + 1) + 12 * tail))})
+        return exe
+    KA, KT = conv.tile_rows(0), conv.tile_rows(1)
+
+    def sweep2_rows(K1, P, delay):       # second-level sweep: mean over the groups 1 .. K1/8 - 1 of a first-level tile
+        gs = range(1, K1 // K2)
+        return float(np.mean([min(P, K2 * g + K2 + 1 - delay) + K2 * g + 2 * K2 for g in gs])) if K1 > K2 else 0.0
+    exe = {}
+    if KA:
+        # audio part (H0, H1, X_{k-1}, accumulator read; X_k written; samples) + on average (K2-1)/2 recent partitions patched
+        exe["fused_block"] = 5 * row_h + io_blk + ((K2 - 1) / 2.0 * 2 + 2) * row_h * (K2 - 1) / K2
+        exe["sweep_head"] = (PA + (PA - 2) + KA) * row_h     # IR rows + arrived delay-line rows read once, KA partial rows written
+        exe["sweep2_head"] = sweep2_rows(KA, PA, 0) * row_h
+    else:                                                    # zero-latency stage not tiled: every block reads all of it
+        exe["fused_block"] = 5 * row_h + io_blk + (2.0 * max(PA - 2, 0) + 1) * row_h
+    exe["premultiply"] = 2.0 * max(PA - 2, 0) * row_h + row_h
+    if tail and PT:
+        if KT:
+            exe["sweep_tail"] = (2 * PT + KT) * row_t
+            exe["sweep2_tail"] = sweep2_rows(KT, PT, 2) * row_t
+            exe["fir_tail"] = ((K2 / 2.0) * 2 + 2) * row_t   # patch: t = 1..7 recent partitions (mean 4) + the sweep row, 1 row out
+        else:
+            exe["fir_tail"] = (2.0 * PT + 1) * row_t
+        exe["fft_fwd_tail"] = float(n1 * (4 * 2 * tail + 8 * tail))
+        exe["fft_inv_tail"] = float(n1 * (8 * tail + 4 * tail))
+    return exe
+
+
+def probe_expected(ir: np.ndarray, frames_step: int, last_step: int, at: int) -> np.ndarray:
+    """Channel 0 is fed a unit impulse at offset `at` of input batch 0, i.e. at absolute sample s * frames_step + at of
+    every EVEN step s: its output in step `last_step` is the sum of the impulse responses those impulses started."""
+    want = np.zeros(frames_step, np.float64)
+    for s in range(0, last_step + 1, 2):
+        off = (last_step - s) * frames_step - at             # IR index of the step's first sample
+        lo = max(0, -off)
+        n = min(frames_step, len(ir) - off)
+        if n > lo:
+            want[lo:n] += ir[off + lo:off + n]
+    return want
+
+
+class Lockstep:
+    """One lock-step workload on this rank: the set, its resident input / output batches, the step function."""
+
+    def __init__(self, torch, reevr_amd, synth, cfg: int, instances, local_rank: int, tiling: bool, bg: bool,
+                 blocks_per_step: int, long_call: bool = False, distinct: int = 0, irs=None, x=None):
+        self.torch, self.cfg = torch, cfg
+        w = WORKLOADS[cfg if cfg in WORKLOADS else 2]
+        self.ir_len, self.host_block, self.single = w["ir_len"], w["host_block"], w["single"]
+        self.long_call = long_call
+        self.head, self.tail = geometry(self.host_block, self.single)
+        self.nch = 2 * len(instances)
+        self.frames_step = 20 * SR if long_call else blocks_per_step * self.host_block
+        self.frames_step -= self.frames_step % self.host_block
+        self.nbuf = 1 if long_call else 2
+        self.dev = torch.device("cuda", local_rank)
+        self.probe_at = 5
+        self.last_out = None
+        t0 = time.perf_counter()
+        self.irs = irs if irs is not None else make_irs(self.ir_len, instances, distinct)
+        if x is None:
+            with concurrent.futures.ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+                x = np.stack(list(ex.map(lambda uc: synth.synth_input(self.frames_step * self.nbuf, 2 * uc[0] + uc[1]),
+                                         [(u, c) for u in instances for c in range(2)])))
+            if not long_call:                  # correctness probe: channel 0 gets unit impulses instead of noise
+                x[0, :] = 0.0
+                x[0, self.probe_at] = 1.0
+        self.x = x
+        self.synth_s = time.perf_counter() - t0
+        self.conv = reevr_amd.ConvolverSet(self.nch, device=local_rank, bg_stream=bg, time_tiling=tiling)
+        t0 = time.perf_counter()
+        max_len = self.frames_step if long_call else self.host_block
+        ok = (self.conv.init_uniform(self.host_block, self.irs, max_len=max_len) if self.single
+              else self.conv.init(self.host_block, self.tail, self.irs, max_len=max_len))
+        if not ok:
+            raise SystemExit(f"init failed: {self.conv.last_error_string}")
+        self.conv.sync()
+        self.init_ms = (time.perf_counter() - t0) * 1e3
+        self.d_in = torch.from_numpy(self.x).to(self.dev)
+        self.d_out = torch.empty_like(self.d_in)
+        torch.cuda.synchronize()
+        self.i = 0
+        self.tiled = bool(tiling) and (self.conv.tile_rows(0) > 0 or self.conv.tile_rows(1) > 0)
+
+    def batch(self, b):
+        f = self.frames_step
+        return self.d_in[:, b * f:(b + 1) * f], self.d_out[:, b * f:(b + 1) * f]
+
+    def step(self, out=None, order=False):
+        b = self.i % self.nbuf
+        self.i += 1
+        xi, yo = self.batch(b)
+        if out is not None:
+            yo = out
+        if self.long_call:
+            self.conv.process_device(xi, yo, sync=False, order=order)
+        else:                                  # the host's per-block loop (in C): one call per host block
+            self.conv.process_device_blocks(xi, self.host_block, yo, sync=False, order=order)
+        self.last_out = yo
+        return b, yo
+
+    def preroll(self):
+        """untimed run to the steady state: the tail delay line holds P_T tail blocks of history and rows before
+        time 0 are never fetched, so the first P_T + 2 tail periods move fewer bytes"""
+        pre = 0
+        if not self.long_call:
+            span = self.tail if self.tail else self.head
+            parts = self.conv.partitions(1) if self.tail else self.conv.partitions(0)
+            pre = -(-(parts + 4) * span // self.frames_step)
+            for _ in range(pre):
+                self.step()
+            self.conv.sync()
+        else:
+            t_pre = time.perf_counter()
+            while time.perf_counter() - t_pre < 0.05:
+                self.step()
+                self.conv.sync()
+        return pre
+
+    def check_probe(self):
+        """the last step's output of channel 0 against the impulse responses its impulses started (see probe_expected)"""
+        if self.long_call or self.i == 0:
+            return None
+        last = self.i - 1
+        got = self.last_out[0].cpu().numpy().astype(np.float64)
+        want = probe_expected(self.irs[0].astype(np.float64), self.frames_step, last, self.probe_at)
+        err = float(np.sqrt(np.mean((got - want) ** 2)))
+        ref = float(np.sqrt(np.mean(want ** 2)))
+        return {"channel": 0, "step": last, "rms_error": err, "rms_expected": ref,
+                "ok": bool(err <= 1e-5 * max(ref, 1e-12) + 1e-9)}
+
+    def kernel_times(self, KERNEL_NAMES):
+        """per-kernel durations of ONE step, live, with HIP events on the streams the kernels run on"""
+        self.conv.set_timing(True)
+        self.conv.kernel_time_reset()
+        self.step()
+        self.conv.sync()
+        kern = {}
+        for kid, name in enumerate(KERNEL_NAMES):
+            n, ms = self.conv.kernel_time(kid)
+            if n:
+                kern[name] = {"launches_per_step": float(n), "avg_ms": ms / n}
+        self.conv.set_timing(False)
+        self.conv.kernel_time_reset()
+        return kern
+
+    def timed(self, steps: int, warmup: int):
+        for _ in range(warmup):
+            self.step()
+        self.conv.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.conv.sync()
+        el = time.perf_counter() - t0
+        return self.nch * self.frames_step * steps / el, el / steps * 1e3
+
+    def close(self):
+        self.conv.close()
+        del self.d_in, self.d_out
+        self.torch.cuda.empty_cache()
+
+
+def roofline_tables(kern: dict, exe: dict, traffic: dict):
+    roof_all, exe_bytes_step = {}, 0.0
+    for k, v in kern.items():
+        if k not in exe or exe[k] <= 0:
+            continue
+        gbs = exe[k] / (v["avg_ms"] * 1e-3) / 1e9
+        exe_bytes_step += exe[k] * v["launches_per_step"]
+        roof_all[k] = {"launches_per_step": v["launches_per_step"], "avg_launch_ms": round(v["avg_ms"], 5),
+                       "ms_per_step": round(v["avg_ms"] * v["launches_per_step"], 5),
+                       "bytes_per_launch": exe[k], "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                       "traffic": traffic.get(k)}
+    return roof_all, exe_bytes_step
+
+
+def load_traffic(nch: int, cfg: int, tiled: bool):
+    if not os.path.exists(TRAFFIC_JSON):
+        return {}, None
+    tj = json.load(open(TRAFFIC_JSON))
+    ent = tj.get("config%d" % cfg, tj if tj.get("config") == cfg else None)
+    if not ent or ent.get("channels") != nch or bool(ent.get("time_tiling", 0)) != tiled:
+        return {}, None
+    return ({k: v["traffic_bytes"] for k, v in ent.get("kernels", {}).items()},
+            "profiles/r3_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)")
+
+
+def side_config(torch, reevr_amd, synth, KERNEL_NAMES, cfg: int, channels: int, local_rank: int, steps: int, cpu_s: float):
+    """One of the other BASELINE configurations in the lock-step regime (single GPU): the engine's schedule, the
+    reference's schedule (RVC_FLAG_NO_TIME_TILING) on the same inputs, and the CPU reference beside them."""
+    w = WORKLOADS[cfg]
+    inst = list(range(channels // 2))
+    ls = Lockstep(torch, reevr_amd, synth, cfg, inst, local_rank, True, False, w["blocks"], distinct=128)
+    pre = ls.preroll()
+    rate, ms = ls.timed(steps, 2)
+    probe = ls.check_probe()
+    ls.conv.check()
+    kern = ls.kernel_times(KERNEL_NAMES)
+    exe = executed_bytes(ls.conv, ls.nch, ls.head, ls.tail, ls.ir_len, ls.host_block, ls.tiled)
+    traffic, tsrc = load_traffic(ls.nch, cfg, ls.tiled)
+    roof_all, exe_step = roofline_tables(kern, exe, traffic)
+    bps = alg_bytes_per_sample(ls.head, ls.tail, ls.ir_len)
+    exe_bps = exe_step / (ls.nch * ls.frames_step) if exe_step else None
+    out = {
+        "workload": f"{w['text']}: {channels} lock-step channels, one process() per {ls.host_block}-frame block",
+        "value": round(rate / 1e6, 3), "unit": "Msamples/s", "steps": steps, "ms_per_step": round(ms, 4),
+        "channels": channels, "frames_per_channel_per_step": ls.frames_step, "pre_roll_steps": pre,
+        "partitions": {"zero-latency stage": ls.conv.partitions(0), "tail stage": ls.conv.partitions(1)},
+        "tile_blocks": {"zero-latency stage": ls.conv.tile_rows(0), "tail stage": ls.conv.tile_rows(1)},
+        "subsets": ls.conv.subsets,
+        "executed_bytes_per_sample": round(exe_bps, 1) if exe_bps else None,
+        "frac_of_hbm_peak_executed_bytes": round(rate * exe_bps / 1e9 / HBM_PEAK_GBS, 4) if exe_bps else None,
+        "alg_bytes_per_sample": round(bps, 1),
+        "alg_equiv": round(rate * bps / 1e9 / HBM_PEAK_GBS, 4),
+        "probe": probe, "roofline_all": roof_all, "traffic_source": tsrc,
+        "init_ms": round(ls.init_ms, 1), "synth_s": round(ls.synth_s, 1),
+    }
+    irs, x = ls.irs, ls.x
+    ls.close()
+    # the same loop in the reference's sweep order (same channels, same inputs)
+    rs = Lockstep(torch, reevr_amd, synth, cfg, inst, local_rank, False, False, w["blocks"], irs=irs, x=x)
+    rs.preroll()
+    rsteps = max(2, steps // 4)
+    rrate, rms = rs.timed(rsteps, 1)
+    rs.conv.check()
+    rs.close()
+    out["reference_schedule"] = {"value": round(rrate / 1e6, 3), "unit": "Msamples/s", "steps": rsteps,
+                                 "ms_per_step": round(rms, 4), "achieved_GBs": round(rrate * bps / 1e9, 1),
+                                 "alg_frac": round(rrate * bps / 1e9 / HBM_PEAK_GBS, 4)}
+    out["alg_frac_reference_schedule"] = out["reference_schedule"]["alg_frac"]
+    if cpu_s > 0:
+        cores = os.cpu_count() or 1
+        n_ir = min(len(irs), max(2, cores))
+        xin = [np.ascontiguousarray(x[1 + c % (len(x) - 1)]) for c in range(n_ir)]      # (channel 0 carries the probe)
+        out["cpu_baseline"] = cpu_baseline(irs[:n_ir], xin, ls.host_block, ls.tail, cpu_s, w["text"])
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5), help="BASELINE.json configuration (1-based index)")
-    ap.add_argument("--channels", type=int, default=4096, help="config 2: lock-step channels per GPU (2 per stereo instance)")
+    ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4, 5), help="BASELINE.json configuration (1-based index)")
+    ap.add_argument("--channels", type=int, default=0, help="lock-step channels per GPU (2 per stereo instance; 0: the config's default)")
     ap.add_argument("--time-tiling", type=int, default=1, help="0: RVC_FLAG_NO_TIME_TILING (the reference's per-block sweep order)")
-    ap.add_argument("--blocks-per-step", type=int, default=256, help="block-synchronous configs: host blocks per step")
+    ap.add_argument("--blocks-per-step", type=int, default=0, help="block-synchronous configs: host blocks per step (0: the config's default)")
     ap.add_argument("--bg-stream", type=int, default=0, help="1: tail stage on the second HIP stream")
     ap.add_argument("--gather", type=int, default=1,
-                    help="N > 1: RCCL all_gather per step; 1: configs 4/5 every channel, config 2 the outputs of 8 stereo "
-                         "instances per GPU; 2: every channel; 0: off")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU baseline leg (0 = skip)")
+                    help="under torch.distributed.run: RCCL all_gather per step; 1: configs 4/5 every channel, others the "
+                         "outputs of 8 stereo instances per GPU; 2: every channel; 0: off")
+    ap.add_argument("--configs", type=str, default="1,3,5", help="other BASELINE configurations measured in the same run (N = 1, config 2)")
+    ap.add_argument("--config-steps", type=int, default=8, help="timed steps of each of those")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the headline's CPU baseline leg (0 = skip)")
+    ap.add_argument("--config-cpu-seconds", type=float, default=8.0, help="budget of each other configuration's CPU leg")
     ap.add_argument("--side", type=int, default=1, help="0: skip the side measurements")
+    ap.add_argument("--tune", type=str, default="", help="rvc_debug_set_tuning knobs, e.g. k1=32,subsets=2 (measurement hook)")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a stuck run dumps every thread's stack and exits (0: off)")
     args = ap.parse_args()
@@ -156,6 +459,9 @@ def main():
     import torch
     import reevr_amd
     from reevr_amd import KERNEL_NAMES, shard, synth
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        assert reevr_amd.set_tuning(k, int(v)), k
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -181,89 +487,62 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ---- workload ----------------------------------------------------------------------------
-    if args.config == 2:
-        ir_len, host_block, long_call = 10 * SR, 512, False
-        if args.channels < 2 or args.channels % 2:
+    long_call = False
+    wcfg = args.config
+    if args.config in (1, 2, 3):
+        w = WORKLOADS[args.config]
+        channels = args.channels or w["channels"]
+        if channels < 2 or channels % 2:
             raise SystemExit("--channels must be a positive even number (stereo instances)")
-        n_inst = args.channels // 2
+        n_inst = channels // 2
         instances = shard.units_for_rank(n_inst * world, world, rank)  # rank = unit mod world, equal shards
         scaling = "weak"
-        workload = (f"stereo, 10 s IR @ 48 kHz, block=512 (head 512 / tail 8192), TwoStage convolver: {n_inst} stereo "
-                    f"instances per GPU in lock-step, one process() per 512-frame block")
+        workload = f"{w['text']}: {n_inst} stereo instances per GPU in lock-step, one process() per {w['host_block']}-frame block"
     elif args.config == 4:
-        ir_len, host_block, long_call = 10 * SR, 512, False
+        wcfg = 2
         if 8 % world:
             raise SystemExit("--config 4 shards 8 stereo instances: --gpus must divide 8")
         instances = shard.units_for_rank(8, world, rank)
         scaling = "strong"
         workload = "8 independent stereo instances, 10 s IR @ 48 kHz, block=512, sharded over the GPUs (unit mod world)"
     else:
-        ir_len, host_block, long_call = 5 * SR, 4096, True
+        long_call = True
         if 32 % world:
             raise SystemExit("--config 5 shards 64 mono channels (32 pairs): --gpus must divide 32")
         instances = shard.units_for_rank(32, world, rank)
         scaling = "strong"
         workload = "batched offline render: 64 mono channels, 5 s IR @ 48 kHz, block=4096, 64/N channels per GPU, one long call per step"
-    nch = 2 * len(instances)
-    head = 1
-    while head < host_block:
-        head *= 2
-    tail = max(8192, 2 * head)                                        # StereoConvolver.cpp:11-15
-    if not long_call and (args.blocks_per_step < 1 or (args.blocks_per_step * host_block) % tail):
-        raise SystemExit("--blocks-per-step must cover whole tail periods (a multiple of %d)" % (tail // host_block))
-    frames_step = 20 * SR if long_call else args.blocks_per_step * host_block   # frames per channel per step
-    frames_step -= frames_step % host_block
-    nbuf = 1 if long_call else 2                                      # input / output batches rotated through
+    blocks = args.blocks_per_step or WORKLOADS[wcfg]["blocks"]
+    head, tail = geometry(WORKLOADS[wcfg]["host_block"], WORKLOADS[wcfg]["single"])
+    host_block = WORKLOADS[wcfg]["host_block"]
+    if not long_call and (blocks < 1 or (blocks * host_block) % (tail or head)):
+        raise SystemExit("--blocks-per-step must cover whole tail periods (a multiple of %d)" % ((tail or head) // host_block))
 
-    t_gen = time.perf_counter()
-    irs = make_irs(ir_len, instances)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
-        x = np.stack(list(ex.map(lambda uc: synth.synth_input(frames_step * nbuf, 2 * uc[0] + uc[1]),
-                                 [(u, c) for u in instances for c in range(2)])))
-    gen_s = time.perf_counter() - t_gen
-    conv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream), time_tiling=bool(args.time_tiling))
-    t_init = time.perf_counter()
-    if not conv.init(host_block, tail, irs, max_len=frames_step if long_call else host_block):
-        raise SystemExit(f"init failed: {conv.last_error_string}")
-    conv.sync()
-    init_ms = (time.perf_counter() - t_init) * 1e3
-    d_in = torch.from_numpy(x).to(dev)
-    d_out = torch.empty_like(d_in)
-    do_gather = bool(args.gather and world > 1)
-    torch.cuda.synchronize()
-    state = {"i": 0}
-    # N > 1: the output batch of every step is gathered with ONE all_gather, overlapped with the next step's compute:
-    # the collective is ordered behind this step's kernels (torch's current stream waits for the set's stream) and runs
+    ls = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, bool(args.time_tiling), bool(args.bg_stream), blocks,
+                  long_call=long_call, distinct=128 if wcfg == 3 else 0)
+    conv, nch, frames_step, nbuf, ir_len = ls.conv, ls.nch, ls.frames_step, ls.nbuf, ls.ir_len
+    do_gather = bool(args.gather and dist is not None)
+    # The output batch of every step is gathered with ONE all_gather, overlapped with the next step's compute:
+    # the collective is ordered behind this step's kernels (torch's current stream waits for the set's streams) and runs
     # on the communicator's stream; a batch buffer is reused only after its own gather has completed.
-    gch = nch if (args.gather >= 2 or args.config != 2) else min(nch, 16)      # channels per rank that are gathered
+    gch = nch if (args.gather >= 2 or args.config in (4, 5)) else min(nch, 16)      # channels per rank that are gathered
     g_out = [torch.empty((world,) + (gch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
     g_stage = [torch.empty((gch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
     pending = [None] * nbuf
 
     def step(gather=True):
-        b = state["i"] % nbuf
-        state["i"] += 1
-        xi = d_in[:, b * frames_step:(b + 1) * frames_step]
         if do_gather and gather:
+            b = ls.i % nbuf
             if pending[b] is not None:         # the gather that read this batch's buffers two steps ago
                 pending[b].wait()
                 pending[b] = None
             # (every channel gathered: the set writes the contiguous staging batch the collective reads in place)
-            yo = g_stage[b] if gch == nch else d_out[:, b * frames_step:(b + 1) * frames_step]
-            if long_call:
-                conv.process_device(xi, yo, sync=False, order=True)
-            else:
-                conv.process_device_blocks(xi, host_block, yo, sync=False, order=True)
+            _, yo = ls.step(out=g_stage[b] if gch == nch else None, order=True)
             if gch != nch:
-                g_stage[b].copy_(yo[:gch])     # (torch's current stream, ordered behind the set's stream by order=True)
-                yo = g_stage[b]
-            pending[b] = shard.gather_batches_async(yo, g_out[b], dist)
+                g_stage[b].copy_(yo[:gch])     # (torch's current stream, ordered behind the set's streams by order=True)
+            pending[b] = shard.gather_batches_async(g_stage[b], g_out[b], dist)
             return
-        yo = d_out[:, b * frames_step:(b + 1) * frames_step]
-        if long_call:
-            conv.process_device(xi, yo, sync=False, order=False)
-        else:                                  # the host's per-block loop (in C): one call per 512-frame block
-            conv.process_device_blocks(xi, host_block, yo, sync=False, order=False)
+        ls.step()
 
     def drain():
         for b in range(nbuf):
@@ -279,19 +558,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # untimed pre-roll to the steady state: the tail delay line holds P_T tail blocks of history and
-    # rows before time 0 are never fetched, so the first P_T + 2 tail periods move fewer bytes
-    pre = 0
-    if not long_call:
-        pre = -(-(conv.partitions(1) + 4) * tail // frames_step)
-        for _ in range(pre):
-            step()
-        conv.sync()
-    else:
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.05:
-            step()
-            conv.sync()
+    pre = ls.preroll()
     for _ in range(args.warmup):
         step()
     fence()
@@ -306,8 +573,16 @@ def main():
     elapsed = time.perf_counter() - t0
     fence()
     conv.check()
+    probe = ls.check_probe()                  # (channel 0's last timed step against its impulse response)
+    gather_ok = None
+    if do_gather:                              # the gathered batch of the last step against the set's own output
+        lb = (ls.i - 1) % nbuf
+        mine = g_out[lb][rank if not same_device else dist.get_rank()]
+        _, yo = ls.batch(lb)
+        src = g_stage[lb] if gch == nch else yo[:gch]
+        gather_ok = bool(torch.equal(mine, src))
     elapsed = shard.max_over_ranks(elapsed, dist, dev)    # slowest rank
-    total_ch = nch * world if args.config == 2 else (16 if args.config == 4 else 64)
+    total_ch = nch * world if args.config in (1, 2, 3) else (16 if args.config == 4 else 64)
     total_samples = total_ch * frames_step * args.steps
     value = total_samples / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
@@ -318,71 +593,16 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- per-kernel durations, live, with HIP events on the stream the kernels run on ----
-    conv.set_timing(True)
-    conv.kernel_time_reset()
-    ksteps = 1
-    for _ in range(ksteps):
-        step(gather=False)                     # (rank 0 only: no collective here)
-    conv.sync()
-    kern = {}
-    for kid, name in enumerate(KERNEL_NAMES):
-        n, ms = conv.kernel_time(kid)
-        if n:
-            kern[name] = {"launches_per_step": n / ksteps, "avg_ms": ms / n}
-    conv.set_timing(False)
-    conv.kernel_time_reset()
+    # ---- per-kernel durations, live, with HIP events on the streams the kernels run on ----
+    kern = ls.kernel_times(KERNEL_NAMES)
     PA, PT = conv.partitions(0), conv.partitions(1)
-    p_head, p_t0, p_t = ref_partitions(head, tail, ir_len)
-    tiled = bool(args.time_tiling) and "sweep_tail" in kern
-    K = 8                                                # rvc::kSweepRows
-    row_h, row_t = 8.0 * head * nch, 8.0 * tail * nch    # bytes of one spectrum row of every channel
-    io_blk = nch * (4.0 * 3 * head + 4.0 * 2 * head)     # per block: input + history + tail ring read, output + ring written
-    # Bytes per LAUNCH of each kernel family. Reference schedule: SURVEY.md 8d's algorithmic figures (what the
-    # reference's loop nest moves = what these kernels move). Time-tiled schedule: the bytes of the structure
-    # actually executed, so that frac <= 1 means what it says.
-    if tiled:
-        exe = {
-            # audio part (H0, H1, X_{k-1}, accumulator read; X_k written; samples) + on average (K-1)/2 recent partitions patched
-            "fused_block": 5 * row_h + io_blk + ((K - 1) / 2.0 * 2 + 2) * row_h * (K - 1) / K,
-            "sweep_head": (PA + (PA - 2) + K) * row_h,   # IR rows + arrived delay-line rows read once, K partial rows written
-            "sweep_tail": (2 * PT + K) * row_t,
-            "fir_tail": ((K / 2.0) * 2 + 2) * row_t,      # patch: t = 1..K-1 recent partitions (mean K/2) + the sweep row, 1 row out
-            "premultiply": 2.0 * (PA - 2) * row_h + row_h,
-            "fft_fwd_tail": float(nch * (4 * 2 * tail + 8 * tail)),
-            "fft_inv_tail": float(nch * (8 * tail + 4 * tail)),
-        }
-    else:
-        exe = {
-            # the per-block launch does one head block of the reference's head AND tail0 sub-convolvers
-            "fused_block": float(nch * (alg_bytes_block(head, p_head) + (alg_bytes_block(head, p_t0) if p_t0 else 0))),
-            "premultiply": float(nch * 16 * PA * (head + 1)),
-            "fir_head": float(nch * 16 * PA * (head + 1)),
-            "fir_tail": float(nch * 16 * p_t * (tail + 1)),
-            "fft_fwd_head": float(nch * (4 * head + 8 * (head + 1))),
-            "fft_inv_head": float(nch * (8 * (head + 1) + 12 * head)),
-            "fft_fwd_tail": float(nch * (4 * tail + 8 * (tail + 1))),
-            "fft_inv_tail": float(nch * (8 * (tail + 1) + 12 * tail)),
-            "ingest": float(nch * 8 * host_block),
-        }
-    traffic_all, tsrc = {}, None
-    tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
-    if os.path.exists(tpath) and not long_call:
-        tj = json.load(open(tpath))
-        if tj.get("channels") == nch and tj.get("config") == args.config and bool(tj.get("time_tiling", 0)) == tiled:
-            traffic_all = {k: v["traffic_bytes"] for k, v in tj.get("kernels", {}).items()}
-            tsrc = "profiles/r2_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)"
-    roof_all = {}
-    exe_bytes_step = 0.0
-    for k, v in kern.items():
-        if long_call or k not in exe:
-            continue
-        gbs = exe[k] / (v["avg_ms"] * 1e-3) / 1e9
-        exe_bytes_step += exe[k] * v["launches_per_step"]
-        roof_all[k] = {"launches_per_step": v["launches_per_step"], "avg_launch_ms": round(v["avg_ms"], 5),
-                       "ms_per_step": round(v["avg_ms"] * v["launches_per_step"], 5),
-                       "bytes_per_launch": exe[k], "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                       "traffic": traffic_all.get(k)}
+    tiled = ls.tiled
+    exe = {} if long_call else executed_bytes(conv, nch, head, tail, ir_len, host_block, tiled)
+    traffic_all, tsrc = ({}, None) if long_call else load_traffic(nch, args.config, tiled)
+    roof_all, exe_bytes_step = roofline_tables(kern, exe, traffic_all)
+    bps = alg_bytes_per_sample(head, tail, ir_len)
+    fps = flops_per_sample(head, tail, ir_len)
+    rate_gpu = value / world * 1e6
     roof = None
     if roof_all:
         dominant = max(roof_all, key=lambda k: roof_all[k]["ms_per_step"])      # largest share of a step
@@ -390,89 +610,72 @@ def main():
         roof = {"bound": "hbm", "kernel": dominant, "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": r["frac"], "traffic": r["traffic"], "bytes_per_launch": r["bytes_per_launch"],
                 "avg_launch_ms": r["avg_launch_ms"], "traffic_source": tsrc,
+                # SURVEY.md 8d's numerator (1497 B per channel-sample of the REFERENCE's loop nest): as a fraction of the
+                # peak only where the executed schedule moves those bytes (reference_schedule, filled in below); with
+                # time tiling the same figure x this run's rate is a throughput EQUIVALENT (> 1 is not an efficiency)
+                "alg_frac_reference_schedule": None,
+                "alg_equiv": round(rate_gpu * bps / 1e9 / HBM_PEAK_GBS, 4),
+                "alg_bytes_per_sample": round(bps, 1),
                 "note": ("time-tiled block-synchronous schedule: bytes_per_launch = the bytes of the structure this launch executes "
-                         "(a sweep reads the stage's IR spectra and arrived delay-line rows ONCE per 8 blocks; a patch / the per-block "
-                         "launch only the partitions that arrived since), averaged over the launches of its family; frac <= 1"
+                         "(a sweep reads the stage's IR spectra and arrived delay-line rows ONCE per tile; a patch / the per-block "
+                         "launch only the partitions that arrived since), averaged over the launches of its family; frac <= 1. "
+                         "alg_frac_reference_schedule = SURVEY 8d bytes x the rate of the reference-order run / 8 TB/s; alg_equiv = "
+                         "the same bytes x THIS run's rate / 8 TB/s (a throughput equivalent, not an efficiency)"
                          if tiled else
                          "reference schedule: every launch re-reads the IR spectra and the delay line of its stage once (16 B per "
                          "partition x bin), physical HBM bytes = SURVEY.md 8d algorithmic bytes, frac <= 1") +
                         "; 0.5-4 flop/B, far below the fp32 ridge"}
-    bps = alg_bytes_per_sample(head, tail, ir_len)
-    fps = flops_per_sample(head, tail, ir_len)
-    rate_gpu = value / world * 1e6
-    path = {"executed_bytes_per_sample": round(exe_bytes_step / (nch * frames_step), 1) if exe_bytes_step else None,
-            "executed_GBs_per_gpu": round(rate_gpu * exe_bytes_step / (nch * frames_step) / 1e9, 1) if exe_bytes_step else None,
-            "frac_of_hbm_peak": round(rate_gpu * exe_bytes_step / (nch * frames_step) / 1e9 / HBM_PEAK_GBS, 4) if exe_bytes_step else None,
+        if not tiled:
+            roof["alg_frac_reference_schedule"] = roof["alg_equiv"]
+    exe_bps = exe_bytes_step / (nch * frames_step) if exe_bytes_step else None
+    path = {"executed_bytes_per_sample": round(exe_bps, 1) if exe_bps else None,
+            "executed_GBs_per_gpu": round(rate_gpu * exe_bps / 1e9, 1) if exe_bps else None,
+            "frac_of_hbm_peak": round(rate_gpu * exe_bps / 1e9 / HBM_PEAK_GBS, 4) if exe_bps else None,
             "reference_alg_bytes_per_sample": round(bps, 1),
             "reference_alg_GBs_equivalent": round(rate_gpu * bps / 1e9, 1),
             "reference_alg_frac_equivalent": round(rate_gpu * bps / 1e9 / HBM_PEAK_GBS, 4),
             "flops_per_sample": round(fps, 1), "frac_of_fp32_peak": round(rate_gpu * fps / 1e12 / FP32_PEAK_TFLOPS, 4),
             "x_realtime_per_gpu": round(rate_gpu / SR, 1),
             "note": "frac_of_hbm_peak = bytes the executed schedule moves per channel-sample x measured rate / 8 TB/s (<= 1). "
-                    "reference_alg_*: SURVEY.md 8d's 1497 B/sample of the REFERENCE's loop nest x the same rate -- with time tiling "
+                    "reference_alg_*: SURVEY.md 8d's bytes of the REFERENCE's loop nest x the same rate -- with time tiling "
                     "this exceeds the physical traffic by the tiling's byte saving and is a throughput equivalent, not an "
                     "efficiency; the `reference_schedule` entry is the run where the two coincide."}
 
-    side = {}
-    if args.side and args.config == 2 and world == 1:
-        conv.close()
+    side, cpu, others = {}, None, {}
+    lockstep_cfg = args.config in (1, 2, 3)
+    irs, x = ls.irs, ls.x
+    init_ms, synth_s, subsets = ls.init_ms, ls.synth_s, conv.subsets
+    tiles = {"zero-latency stage": conv.tile_rows(0), "tail stage": conv.tile_rows(1)}
+    if args.side and lockstep_cfg and world == 1:
+        ls.close()
         if tiled:       # the same loop in the reference's sweep order (same channels, same inputs)
-            rconv = reevr_amd.ConvolverSet(nch, device=local_rank, bg_stream=bool(args.bg_stream), time_tiling=False)
-            assert rconv.init(host_block, tail, irs, max_len=host_block)
-
-            def rstep(i):
-                b = i % nbuf
-                rconv.process_device_blocks(d_in[:, b * frames_step:(b + 1) * frames_step], host_block,
-                                            d_out[:, b * frames_step:(b + 1) * frames_step], sync=False, order=False)
-            for i in range(pre + 1):
-                rstep(i)
-            rconv.sync()
+            rs = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, False, bool(args.bg_stream), blocks, irs=irs, x=x)
+            rs.preroll()
             rsteps = max(2, args.steps // 4)
-            tr = time.perf_counter()
-            for i in range(rsteps):
-                rstep(i)
-            rconv.sync()
-            tr = time.perf_counter() - tr
-            rrate = nch * frames_step * rsteps / tr
+            rrate, rms = rs.timed(rsteps, 1)
+            rs.conv.check()
+            rs.close()
             side["reference_schedule"] = {
-                "value": round(rrate / 1e6, 3), "unit": "Msamples/s", "steps": rsteps, "ms_per_step": round(tr / rsteps * 1e3, 4),
+                "value": round(rrate / 1e6, 3), "unit": "Msamples/s", "steps": rsteps, "ms_per_step": round(rms, 4),
                 "alg_bytes_per_sample": round(bps, 1), "achieved_GBs": round(rrate * bps / 1e9, 1),
                 "frac_of_hbm_peak": round(rrate * bps / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "RVC_FLAG_NO_TIME_TILING: same channels / inputs / call pattern, every 512-frame block sweeps all 32 + 57 "
-                        "partitions (FFTConvolver.cpp:176-187): physical bytes = SURVEY.md 8d algorithmic bytes"}
-            rconv.close()
-        if tiled and nch > 1024:   # the same loop with a quarter of the channels per launch (the fixed cost of a launch shows)
-            qn = 1024
-            qconv = reevr_amd.ConvolverSet(qn, device=local_rank, bg_stream=bool(args.bg_stream), time_tiling=True)
-            assert qconv.init(host_block, tail, irs[:qn], max_len=host_block)
-
-            def qstep(i):
-                b = i % nbuf
-                qconv.process_device_blocks(d_in[:qn, b * frames_step:(b + 1) * frames_step], host_block,
-                                            d_out[:qn, b * frames_step:(b + 1) * frames_step], sync=False, order=False)
-            for i in range(pre + 1):
-                qstep(i)
-            qconv.sync()
-            qsteps = max(4, args.steps // 2)
-            tq = time.perf_counter()
-            for i in range(qsteps):
-                qstep(i)
-            qconv.sync()
-            tq = time.perf_counter() - tq
-            side["lockstep_1024_channels"] = {"value": round(qn * frames_step * qsteps / tq / 1e6, 3), "unit": "Msamples/s",
-                                              "steps": qsteps, "ms_per_step": round(tq / qsteps * 1e3, 4),
-                                              "note": "same loop, schedule and kernels with 1024 channels (512 stereo instances, "
-                                                      "8 GB resident) per launch"}
-            qconv.close()
-        del d_in, d_out
-        torch.cuda.empty_cache()
-        side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
-    cpu = None
-    if world == 1 and args.cpu_seconds > 0 and args.config == 2:
+                "note": "RVC_FLAG_NO_TIME_TILING: same channels / inputs / call pattern, every host block sweeps every "
+                        "partition (FFTConvolver.cpp:176-187): physical bytes = SURVEY.md 8d algorithmic bytes"}
+            if roof is not None:
+                roof["alg_frac_reference_schedule"] = side["reference_schedule"]["frac_of_hbm_peak"]
+        if args.config == 2:
+            side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
+    if world == 1 and args.cpu_seconds > 0 and lockstep_cfg:
         cores = os.cpu_count() or 1
         n_cpu_irs = min(len(irs), max(2, cores))
-        xin = [np.ascontiguousarray(x[c % nch, :frames_step * nbuf]) for c in range(min(n_cpu_irs, nch))]
-        cpu = cpu_baseline(irs[:n_cpu_irs], xin, host_block, args.cpu_seconds)
+        xin = [np.ascontiguousarray(x[1 + c % (nch - 1)]) for c in range(n_cpu_irs)]          # (channel 0 carries the probe)
+        cpu = cpu_baseline(irs[:n_cpu_irs], xin, host_block, tail, args.cpu_seconds, WORKLOADS[wcfg]["text"])
+    if args.config == 2 and world == 1 and args.side:
+        del irs, x
+        for c in [int(v) for v in args.configs.split(",") if v.strip()]:
+            if c in WORKLOADS and c != 2:
+                others["config%d" % c] = side_config(torch, reevr_amd, synth, KERNEL_NAMES, c, WORKLOADS[c]["channels"],
+                                                     local_rank, args.config_steps, args.config_cpu_seconds)
 
     line = {
         "metric": "Msamples/s convolved (stereo, 10s IR, block=512); % HBM roofline",
@@ -484,27 +687,33 @@ def main():
                    "frames_per_channel_per_step": frames_step, "host_block": host_block,
                    "calls_per_step": 1 if long_call else frames_step // host_block,
                    "partitions": {"head+tail0 (block %d)" % head: PA, "tail (block %d)" % tail: PT},
+                   "tile_blocks": tiles, "subsets": subsets,
                    "resident_GB": round(nch * 8.0 * (PA * head + (PT + 2) * tail) * 2 / 1e9, 2),
-                   "schedule": "long call" if long_call else ("causal time tiling (8-block sweeps + patches)" if tiled
-                                                                else "reference order (RVC_FLAG_NO_TIME_TILING)"),
+                   "schedule": "long call" if long_call else ("causal time tiling (sweeps + patches; two levels for long delay lines)"
+                                                                if tiled else "reference order (RVC_FLAG_NO_TIME_TILING)"),
                    "call": ("one process() per step" if long_call else
-                            "one process_device() per 512-frame host block for all channels (rvc_set_process_device_blocks), "
-                            "device-resident I/O, %d input/output batches rotated" % nbuf),
+                            "one process_device() per %d-frame host block for all channels (rvc_set_process_device_blocks), "
+                            "device-resident I/O, %d input/output batches rotated" % (host_block, nbuf)),
                    "pre_roll_steps": pre, "gather": do_gather, "gathered_channels_per_gpu": gch if do_gather else 0,
+                   "gather_matches_output": gather_ok, "tune": args.tune,
                    "sharding": "instances dealt to ranks, equal shards, no data-path collective"
                                + (f"; one RCCL all_gather of the output blocks of {gch} channels per GPU per step, overlapped with the next step" if do_gather else "")},
         "roofline": roof,
+        "probe": probe,
         "roofline_all": roof_all,
         "path_roofline": path,
         "kernels_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()},
         **side,
         "cpu_baseline": cpu,
-        "init_ms": round(init_ms, 2), "synth_s": round(gen_s, 2),
+        **others,
+        "init_ms": round(init_ms, 2), "synth_s": round(synth_s, 2),
     }
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if probe is not None and not probe["ok"]:
+        raise SystemExit("correctness probe failed: %r" % (probe,))
 
 
 def side_measurements(torch, reevr_amd, synth, irs2, local_rank, dev, host_block, tail):
@@ -519,6 +728,7 @@ def side_measurements(torch, reevr_amd, synth, irs2, local_rank, dev, host_block
     torch.cuda.synchronize()
     res = {}
     for mode, kw in (("tail_on_second_stream", dict(bg_stream=True)), ("tail_inline", dict(bg_stream=False)),
+                     ("tail_inline_f32", dict(bg_stream=False, fft_f32=True)),
                      ("persistent_kernel", dict(bg_stream=True, persistent=True))):
         s = reevr_amd.ConvolverSet(2, device=local_rank, **kw)
         assert s.init(host_block, tail, irs2, max_len=host_block)
@@ -537,8 +747,9 @@ def side_measurements(torch, reevr_amd, synth, irs2, local_rank, dev, host_block
                                 "modes": res,
                                 "note": "ONE stereo pair. us_per_block: one process_device() call per 512-frame block back to back "
                                         "(host loop in C); host_call_us: rvc_set_process() on host buffers per block, back to back "
-                                        "(pinned staging + hand-off + kernel + copy back; stopwatch in C). persistent_kernel = "
-                                        "RVC_FLAG_PERSISTENT (resident kernel fed through a doorbell, no launch per block)"}
+                                        "(pinned staging + hand-off + kernel + copy back; stopwatch in C). Default precision of a "
+                                        "set this small: tail transforms (8192) in double; tail_inline_f32 = RVC_FLAG_FFT_F32. "
+                                        "persistent_kernel = RVC_FLAG_PERSISTENT (experimental: resident kernel fed through a doorbell)"}
     # (b) offline: one 40 s call per step (adaptive partitioning) and (c) the same through the fixed head/tail sizes
     frames = 40 * SR
     xl = torch.from_numpy(np.stack([synth.synth_input(frames, c) for c in range(2)])).to(dev)

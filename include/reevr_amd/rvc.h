@@ -51,11 +51,16 @@ enum {
                                    events at the reference's start/waitForBackgroundProcessing
                                    hook points (TwoStageFFTConvolver.cpp:213-222, Convolver.cpp:84-95) */
 #define RVC_FLAG_TIMING 2u      /* bracket every kernel launch with HIP events (rvc_set_kernel_time) */
-#define RVC_FLAG_FFT_F64 4u     /* run the FFTs in double, spectra still stored as float -- the reference's
-                                   precision (Ooura in double, AudioFFT.cpp:114-159). Default is float32
-                                   transforms (~1e-7 relative, 100x inside the 1e-5 RMS parity bound and
-                                   faster). Largest partition RVC_MAX_BLOCK/2. IR spectra are computed
-                                   in double at init in either mode. */
+#define RVC_FLAG_FFT_F64 4u     /* run EVERY transform in double, spectra still stored as float -- the reference's
+                                   precision (Ooura in double, AudioFFT.cpp:114-159). Largest partition
+                                   RVC_MAX_BLOCK/2. IR spectra are computed in double at init in any mode.
+                                   Default (neither this nor RVC_FLAG_FFT_F32): sets of up to 8 channels -- the
+                                   plug-in's case, where a transform costs nothing -- run the stages with
+                                   partitions of 2048 ... 8192 samples in double (so that the reference's own
+                                   known-answer rule, test/Test.cpp:129-145, holds for every one of its cases) and
+                                   smaller partitions in float; larger (lock-step) sets run float32 throughout
+                                   (~1e-7 relative, 100x inside the 1e-5 RMS parity bound). */
+#define RVC_FLAG_FFT_F32 256u   /* float32 transforms also for small sets (the default of large ones) */
 
 #define RVC_FLAG_FIXED_PARTITIONS 8u /* always use the reference's head/tail partition sizes. Default: a long
                                    call (>= 5 tail blocks) computes the tail blocks that lie entirely
@@ -70,17 +75,25 @@ enum {
                                    tiling -- every 8th block a sweep reads them ONCE and leaves partial sums for the
                                    next 8 blocks (only partitions whose input has already arrived), the blocks in
                                    between add their few recent partitions: same sums, same zero latency, ~3.5x fewer
-                                   HBM bytes where the path is bandwidth-bound (many lock-step channels). */
+                                   HBM bytes where the path is bandwidth-bound (many lock-step channels). Delay lines
+                                   of more than 40 partitions get two levels of it: a first-level sweep every 16
+                                   blocks over all partitions, second-level sweeps every 8 blocks over what arrived
+                                   since (BASELINE config 3's 350 tail partitions: ~1.7x fewer bytes again). */
 
-#define RVC_FLAG_PERSISTENT 64u  /* per-block calls (a call inside one head block, head block 512 ... 4096) are served by ONE
+#define RVC_FLAG_PERSISTENT 64u  /* EXPERIMENTAL (its 99th-percentile call time is above the launch path's: DESIGN.md 5b).
+                                   Per-block calls (a call inside one head block, head block 512 ... 4096) are served by ONE
                                    RESIDENT kernel fed through a doorbell in pinned host memory instead of one launch per
                                    block (the loop of TwoStageFFTConvolver.cpp:151-233): no launch on the latency path.
                                    The kernel parks itself after 2 s without a call and is relaunched by the next one.
                                    Device-pointer calls are pipelined: rvc_set_sync() is the only completion point
-                                   (the resident kernel is not on rvc_set_stream). Other call patterns fall back to
-                                   ordinary launches. */
+                                   (the resident kernel is not on rvc_set_stream) and d_in must be COMPLETE when the call
+                                   is made -- the resident kernel reads it as soon as the command is pushed, on no stream
+                                   an event could order it behind. Other call patterns, and sets whose workgroups would
+                                   not all be resident at once, fall back to ordinary launches. */
 #define RVC_FLAG_FORCE_TIME_TILING 32u /* testing: time-tile every stage that has partitions to tile, however small
                                    (by default only stages whose per-block sweep is long enough to be bandwidth-bound) */
+#define RVC_FLAG_NO_SUBSETS 512u  /* never serve the set by child sets on their own streams (rvc_set_subsets) */
+#define RVC_FLAG_FORCE_TWO_LEVEL 128u  /* testing: the same with two-level tiles whatever the partition count */
 
 /* ---- lifetime ---------------------------------------------------------------------- */
 
@@ -173,8 +186,17 @@ size_t rvc_set_max_len(const rvc_set *s);
 /* partitions of the zero-latency stage (head + tail0 merged), of the tail stage, and of the wide
  * stage (whole IR at block 16384, used by very long calls; 0 when absent) */
 int rvc_set_partitions(const rvc_set *s, int stage /*0 = head, 1 = tail, 2 = wide*/);
-/* hipStream_t of the foreground stream, as void*; (stage 1: the tail stream) */
+/* blocks per first-level sweep tile of the time-tiled delay line of a stage (0 head, 1 tail): 0 = not tiled, 8 = one level,
+ * 16 / 32 = two levels (RVC_FLAG_NO_TIME_TILING) */
+int rvc_set_tile_rows(const rvc_set *s, int stage);
+/* hipStream_t of the foreground stream, as void*; (which = 1: the tail stream). A set of very many channels may be served
+ * by rvc_set_subsets() child sets with streams of their own: child k's are which = 2 k and 2 k + 1 (NULL beyond the last),
+ * and work on device buffers must be ordered against EVERY child's foreground stream. */
 void *rvc_set_stream(rvc_set *s, int which);
+/* number of child sets (1: the set runs on its own two streams; n > 1: channels [k n_channels/n, (k+1) n_channels/n) are child
+ * k's). Chosen at init for sets of thousands of lock-step channels: the latency-bound ends of one child's per-block launch
+ * overlap the bandwidth-bound middle of another's. RVC_FLAG_NO_SUBSETS turns it off. */
+int rvc_set_subsets(const rvc_set *s);
 int rvc_last_error(const rvc_set *s);
 const char *rvc_last_error_string(const rvc_set *s);
 
@@ -311,11 +333,20 @@ int rvc_send_pre_device(int device, void *stream, const rvc_send_params *p);
 int rvc_debug_rfft(int device, size_t n, int f64, const float *data, float *re, float *im);
 int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re, const float *im);
 
-/* RVC_FLAG_PERSISTENT diagnostics: 100 MHz device timestamps of the resident kernel's last step (doorbell seen, command
- * fetched, accumulator ready, step done) and its sequence number. 1 = ok. */
-int rvc_debug_persist_stamps(rvc_set *s, unsigned long long *out5);
-/* ... and the median host -> resident kernel -> host round trip of n empty commands, microseconds (-1: not persistent). */
+/* RVC_FLAG_PERSISTENT diagnostics: the median host -> resident kernel -> host round trip of n empty commands,
+ * microseconds (-1: not persistent). */
 double rvc_debug_persist_rtt(rvc_set *s, int n);
+
+/* Measurement hook (bench.py, tools/): process-wide schedule knobs, read when a set is initialised. Returns 1 if the
+ * key is known. Keys: "k1" first-level tile of long delay lines (8 = one level, 16 default, 32); "sweep_split" -1 auto /
+ * 0 own-tile / 1 partition-split sweeps; "fft_loop" -1 auto / 0 / 1 row-looping 8192-bin transforms; "subsets" -1 auto /
+ * n children of a many-channel set; "guard" 0 / 1 guard bands around every device allocation (see rvc_debug_guard_check). */
+int rvc_debug_set_tuning(const char *key, int value);
+/* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set
+ * is initialised, every device allocation of the set lies between two 256 KiB guard bands filled with 0xFF and starts out
+ * 0xFF-filled itself (0xFFFFFFFF is a NaN: a value read out of bounds, or never written, and USED shows in the output).
+ * Returns the number of guard bytes that changed (0 = no out-of-bounds write so far), -1 if the set has no guards. */
+long rvc_debug_guard_check(rvc_set *s);
 
 /* Number of visible HIP devices (0 when there is none or the runtime cannot start). */
 int rvc_device_count(void);

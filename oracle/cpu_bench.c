@@ -18,6 +18,7 @@
 typedef void *(*cb_create_fn)(void);
 typedef void (*cb_destroy_fn)(void *);
 typedef int (*cb_init_fn)(void *, size_t, size_t, const float *, size_t);
+typedef int (*cb_init1_fn)(void *, size_t, const float *, size_t);   /* FFTConvolver::init: one block size (tail == 0) */
 typedef void (*cb_process_fn)(void *, const float *, float *, size_t);
 
 typedef struct {
@@ -45,10 +46,11 @@ static void *cb_worker(void *arg) {
   cb_thread *t = (cb_thread *)arg;
   void *conv = t->create();
   float *out = (float *)malloc(sizeof(float) * t->block);
-  t->ok = conv && out && t->init(conv, t->head, t->tail, t->ir, t->ir_len);
+  t->ok = conv && out && (t->tail ? t->init(conv, t->head, t->tail, t->ir, t->ir_len)
+                                  : ((cb_init1_fn)(void (*)(void))t->init)(conv, t->head, t->ir, t->ir_len));
   /* warm-up: one pass over a tail period so that every buffer is touched */
   if (t->ok)
-    for (size_t i = 0; i + t->block <= t->frames && i < 2 * t->tail; i += t->block) t->process(conv, t->in + i, out, t->block);
+    for (size_t i = 0; i + t->block <= t->frames && i < 2 * (t->tail ? t->tail : 8192); i += t->block) t->process(conv, t->in + i, out, t->block);
   pthread_barrier_wait(t->bar);
   const double t0 = now_s();
   unsigned long long done = 0;

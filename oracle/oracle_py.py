@@ -164,9 +164,9 @@ def direct_convolve(x: np.ndarray, ir: np.ndarray) -> np.ndarray:
 
 
 def cpu_bench(which: str, n_threads: int, head: int, tail: int, block: int, irs, ins, seconds: float):
-    """bench.py's CPU baseline (cpu_bench.c): n_threads independent TwoStageFFTConvolver instances of
-    back-end `which` ("ref" = the untouched reference, "orc" = the restatement), one per thread,
-    `block`-frame process() calls back to back for ~`seconds`, no Python in the loop.
+    """bench.py's CPU baseline (cpu_bench.c): n_threads independent TwoStageFFTConvolver instances (tail == 0:
+    FFTConvolver instances of block `head`) of back-end `which` ("ref" = the untouched reference, "orc" = the
+    restatement), one per thread, `block`-frame process() calls back to back for ~`seconds`, no Python in the loop.
     Returns (channel-samples convolved, wall seconds, per-thread samples)."""
     b = backend(which)
     lib = backend("orc").lib
@@ -181,8 +181,9 @@ def cpu_bench(which: str, n_threads: int, head: int, tail: int, block: int, irs,
     inp = (_F32P * len(ins))(*[_fp(a) for a in ins])
     cnt = (C.c_ulonglong * n_threads)()
     addr = lambda name: C.cast(b.fn(name), C.c_void_p)
-    wall = lib.orc_cpu_bench(addr("twostage_create"), addr("twostage_destroy"), addr("twostage_init"),
-                             addr("twostage_process"), n_threads, head, tail, block, irp, len(irs), irs[0].size,
+    kind = "twostage" if tail else "fftconv"
+    wall = lib.orc_cpu_bench(addr(kind + "_create"), addr(kind + "_destroy"), addr(kind + "_init"),
+                             addr(kind + "_process"), n_threads, head, tail, block, irp, len(irs), irs[0].size,
                              inp, len(ins), ins[0].size, float(seconds), cnt)
     if wall <= 0.0:
         raise RuntimeError("orc_cpu_bench failed")

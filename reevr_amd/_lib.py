@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# REEVR_AMD_LIB: development override used by the ablation measurements (tools/abl_build.py)
+# REEVR_AMD_LIB: development override (a scratch build of the library, tools/dev/)
 LIB_PATH = os.environ.get("REEVR_AMD_LIB") or os.path.join(_HERE, "csrc", "libreevr_amd.so")
 
 F32P = C.POINTER(C.c_float)
@@ -21,6 +21,9 @@ RVC_FLAG_FIXED_PARTITIONS = 8
 RVC_FLAG_NO_TIME_TILING = 16
 RVC_FLAG_FORCE_TIME_TILING = 32
 RVC_FLAG_PERSISTENT = 64
+RVC_FLAG_FORCE_TWO_LEVEL = 128
+RVC_FLAG_FFT_F32 = 256
+RVC_FLAG_NO_SUBSETS = 512
 RVC_MAX_BLOCK = 16384
 
 # name -> (restype, argtypes); must list every symbol declared in include/reevr_amd/rvc.h
@@ -46,6 +49,8 @@ SIGNATURES = {
     "rvc_set_max_len": (C.c_size_t, [C.c_void_p]),
     "rvc_set_partitions": (C.c_int, [C.c_void_p, C.c_int]),
     "rvc_set_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "rvc_set_subsets": (C.c_int, [C.c_void_p]),
+    "rvc_set_tile_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "rvc_last_error": (C.c_int, [C.c_void_p]),
     "rvc_last_error_string": (C.c_char_p, [C.c_void_p]),
     "rvc_set_kernel_time": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
@@ -80,8 +85,9 @@ SIGNATURES = {
     "rvc_send_pre_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "rvc_debug_rfft": (C.c_int, [C.c_int, C.c_size_t, C.c_int, F32P, F32P, F32P]),
     "rvc_debug_irfft": (C.c_int, [C.c_int, C.c_size_t, C.c_int, F32P, F32P, F32P]),
-    "rvc_debug_persist_stamps": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "rvc_debug_persist_rtt": (C.c_double, [C.c_void_p, C.c_int]),
+    "rvc_debug_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "rvc_debug_guard_check": (C.c_long, [C.c_void_p]),
     "rvc_device_count": (C.c_int, []),
     "rvc_version": (C.c_char_p, []),
 }

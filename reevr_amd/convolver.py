@@ -33,13 +33,17 @@ class ConvolverSet:
     """n independent mono convolvers sharing one block geometry (one launch per stage)."""
 
     def __init__(self, n_channels: int, device: int = 0, bg_stream: bool = False, timing: bool = False,
-                 fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True, persistent: bool = False):
+                 fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True, persistent: bool = False,
+                 fft_f32: bool = False):
+        """time_tiling: True (by size) / False / "force" (every stage, one level unless long) / "force2" (two levels).
+        fft_f64 / fft_f32: every transform in double / in float (default: rvc.h, RVC_FLAG_FFT_F64)."""
         self._lib = L.lib()
         flags = ((L.RVC_FLAG_BG_STREAM if bg_stream else 0) | (L.RVC_FLAG_TIMING if timing else 0)
-                 | (L.RVC_FLAG_FFT_F64 if fft_f64 else 0)
+                 | (L.RVC_FLAG_FFT_F64 if fft_f64 else 0) | (L.RVC_FLAG_FFT_F32 if fft_f32 else 0)
                  | (L.RVC_FLAG_FIXED_PARTITIONS if fixed_partitions else 0)
                  | (0 if time_tiling else L.RVC_FLAG_NO_TIME_TILING)
                  | (L.RVC_FLAG_FORCE_TIME_TILING if time_tiling == "force" else 0)
+                 | (L.RVC_FLAG_FORCE_TWO_LEVEL if time_tiling == "force2" else 0)
                  | (L.RVC_FLAG_PERSISTENT if persistent else 0))
         self.persistent = bool(persistent)
         self.n_channels = int(n_channels)
@@ -135,22 +139,31 @@ class ConvolverSet:
         return out
 
     def _order_after_torch(self):
-        """The engine runs on its own (non-blocking) HIP stream: make it wait for whatever torch's
-        current stream has queued (the kernels still producing d_in). Returns the wrapped stream."""
+        """The engine runs on its own (non-blocking) HIP streams: make them wait for whatever torch's
+        current stream has queued (the kernels still producing d_in). Returns the wrapped streams (one per child set).
+        Persistent sets: the resident kernel is on no stream an event could hold back and reads d_in as soon as the
+        command is pushed, so torch's current stream is drained on the host first (rvc.h, RVC_FLAG_PERSISTENT)."""
         import torch
-        ptr = self._lib.rvc_set_stream(self._h, 0)
-        if not ptr:
+        if self.persistent:
+            torch.cuda.current_stream(self.device).synchronize()
+        ptrs = [self._lib.rvc_set_stream(self._h, 2 * k) for k in range(max(1, self._lib.rvc_set_subsets(self._h)))]
+        ptrs = [p for p in ptrs if p]
+        if not ptrs:
             return None
-        if getattr(self, "_ext_ptr", None) != ptr:
-            self._ext = torch.cuda.ExternalStream(ptr, device=torch.device("cuda", self.device))
-            self._ext_ptr = ptr
-        self._ext.wait_stream(torch.cuda.current_stream(self.device))
+        if getattr(self, "_ext_ptrs", None) != ptrs:
+            self._ext = [torch.cuda.ExternalStream(p, device=torch.device("cuda", self.device)) for p in ptrs]
+            self._ext_ptrs = ptrs
+        cur = torch.cuda.current_stream(self.device)
+        for e in self._ext:
+            e.wait_stream(cur)
         return self._ext
 
     def _order_torch_after(self, ext):
         import torch
         if ext is not None:
-            torch.cuda.current_stream(self.device).wait_stream(ext)
+            cur = torch.cuda.current_stream(self.device)
+            for e in ext:
+                cur.wait_stream(e)
 
     def process_device(self, d_in, d_out=None, sync: bool = True, order: bool = True):
         """d_in / d_out: torch float32 CUDA tensors (n_channels, len), last dim contiguous.
@@ -223,6 +236,14 @@ class ConvolverSet:
     def partitions(self, stage: int) -> int:
         return int(self._lib.rvc_set_partitions(self._h, stage))
 
+    def tile_rows(self, stage: int) -> int:
+        """blocks per first-level sweep tile of a stage's time-tiled delay line (0: not tiled)"""
+        return int(self._lib.rvc_set_tile_rows(self._h, stage))
+
+    @property
+    def subsets(self) -> int:
+        return int(self._lib.rvc_set_subsets(self._h))
+
     def stream(self, which: int = 0) -> int:
         return int(self._lib.rvc_set_stream(self._h, which) or 0)
 
@@ -250,16 +271,25 @@ class ConvolverSet:
     def kernel_time_reset(self):
         self._lib.rvc_set_kernel_time_reset(self._h)
 
+    def guard_check(self) -> int:
+        """Changed guard bytes around the set's device allocations (rvc_debug_guard_check; -1: no guards)."""
+        return int(self._lib.rvc_debug_guard_check(self._h))
+
 
 KERNEL_NAMES = ["ingest", "fft_fwd_head", "fir_head", "fft_inv_head", "fft_fwd_tail", "fir_tail", "fft_inv_tail",
-                "fused_block", "premultiply", "sweep_head", "sweep_tail"]
+                "fused_block", "premultiply", "sweep_head", "sweep_tail", "sweep2_head", "sweep2_tail"]
+
+
+def set_tuning(key: str, value: int) -> bool:
+    """Process-wide schedule knob, read when a set is initialised (rvc_debug_set_tuning; measurement hook)."""
+    return bool(L.lib().rvc_debug_set_tuning(key.encode(), int(value)))
 
 
 class _Mono:
     """One mono convolver: the reference's per-object surface on a 1-channel set."""
 
-    def __init__(self, device: int = 0, bg_stream: bool = True, fft_f64: bool = False):
-        self._set = ConvolverSet(1, device, bg_stream=bg_stream, fft_f64=fft_f64)
+    def __init__(self, device: int = 0, bg_stream: bool = True, fft_f64: bool = False, fft_f32: bool = False):
+        self._set = ConvolverSet(1, device, bg_stream=bg_stream, fft_f64=fft_f64, fft_f32=fft_f32)
 
     def process(self, input: np.ndarray) -> np.ndarray:
         x = _f32(input).reshape(-1)
@@ -287,8 +317,8 @@ class _Mono:
 class FFTConvolver(_Mono):
     """fftconvolver::FFTConvolver (FFTConvolver.h:52-80)."""
 
-    def __init__(self, device: int = 0, fft_f64: bool = False):
-        super().__init__(device, bg_stream=False, fft_f64=fft_f64)
+    def __init__(self, device: int = 0, fft_f64: bool = False, fft_f32: bool = False):
+        super().__init__(device, bg_stream=False, fft_f64=fft_f64, fft_f32=fft_f32)
 
     def init(self, blockSize: int, ir: np.ndarray, max_len: int = 0) -> bool:
         return self._set.init_uniform(blockSize, [ir], max_len)
@@ -297,8 +327,8 @@ class FFTConvolver(_Mono):
 class TwoStageFFTConvolver(_Mono):
     """fftconvolver::TwoStageFFTConvolver (TwoStageFFTConvolver.h:54-83); tail inline on one stream."""
 
-    def __init__(self, device: int = 0, bg_stream: bool = False, fft_f64: bool = False):
-        super().__init__(device, bg_stream=bg_stream, fft_f64=fft_f64)
+    def __init__(self, device: int = 0, bg_stream: bool = False, fft_f64: bool = False, fft_f32: bool = False):
+        super().__init__(device, bg_stream=bg_stream, fft_f64=fft_f64, fft_f32=fft_f32)
 
     def init(self, headBlockSize: int, tailBlockSize: int, ir: np.ndarray, max_len: int = 0) -> bool:
         return self._set.init(headBlockSize, tailBlockSize, [ir], max_len)

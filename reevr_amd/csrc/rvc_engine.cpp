@@ -24,9 +24,9 @@
 // next call, like FFTConvolver.cpp:164-173. clear() just restarts the clock.
 //
 // Block-synchronous calls (one call per host block, the plug-in's pattern) have two refinements on top of that:
-//   * causal time tiling of the delay lines (tile_A / tile_T, rvc_internal.h kSweepRows): every 8th block a sweep reads a
-//     stage's IR spectra and delay line once and leaves partial sums for 8 blocks, the blocks in between patch in the few
-//     partitions whose input arrived since;
+//   * causal time tiling of the delay lines (Tile tA / tT, rvc_internal.h): every 8th block a sweep reads a stage's IR
+//     spectra and delay line once and leaves partial sums for 8 blocks, the blocks in between patch in the few
+//     partitions whose input arrived since; long delay lines get two levels of it (first-level tiles of 16 / 32 blocks);
 //   * RVC_FLAG_PERSISTENT: the per-block launch is replaced by one resident kernel fed through a command ring in pinned host
 //     memory (pk_* functions below); sweeps and tail jobs stay ordinary launches, issued when a block retires.
 #include <hip/hip_runtime.h>
@@ -38,6 +38,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -48,7 +49,7 @@
 namespace {
 
 constexpr double kPi = 3.14159265358979323846264338327950288;
-constexpr int kNumKernelIds = 11;
+constexpr int kNumKernelIds = 13;
 
 size_t next_pow2(size_t v) {   // Utilities.h:280-289
   size_t p = 1;
@@ -85,9 +86,40 @@ struct TimedLaunch {
   hipEvent_t a, b;
 };
 
+// Causal time tiling of one stage's block-synchronous delay line (rvc_internal.h, "Causal time tiling"): a first-level
+// sweep leaves partial sums for K1 blocks in s1; with K1 > kSweepRows a second-level sweep every kSweepRows blocks adds
+// what arrived since and leaves the partial sums of the next kSweepRows blocks in s2; the blocks in between patch in
+// their few recent partitions.
+struct Tile {
+  bool on = false;
+  int K1 = rvc::kSweepRows;      // blocks per first-level tile: 8 (one level), 16 or 32
+  int rows1 = rvc::kSweepRows;   // rows of s1 per channel (K1; twice that in persistent mode)
+  float2 *s1 = nullptr, *s2 = nullptr;   // [nch][rows1][B], [nch][kSweepRows][B]
+  long long t0 = -1;             // blocks [t0, t0 + K1) have first-level rows; -1: none
+  long long s0 = -1;             // blocks [s0, s0 + kSweepRows), s0 > t0, have second-level rows; -1: none
+  void drop() { t0 = s0 = -1; }
+  // start of the kSweepRows-block group of the current tile that block b (t0 <= b < t0 + K1) lies in
+  long long group(long long b) const { return t0 + (b - t0) / rvc::kSweepRows * rvc::kSweepRows; }
+};
+
+// process-wide measurement knobs (rvc_debug_set_tuning); the defaults are what the engine ships with
+struct Tuning {
+  int k1 = 16;            // first-level tile of delay lines with more than kTwoLevelMinP partitions (16 or 32; 8: one level)
+  int fft_loop = -1;      // row-looping form of the 8192-bin transforms: -1 by size, 0 never, 1 always
+  int subsets = -1;       // children of a many-channel set: -1 by size, else the count
+  int guard = 0;          // 1: NaN-filled guard bands around (and NaN poison inside) every device allocation of a set
+};
+Tuning g_tune;
+
 }  // namespace
 
 struct rvc_set {
+  // A set of very many lock-step channels is served by a few CHILD sets of nch / n channels each (kids; channel c of
+  // child k is channel kid_c0[k] + c of this set): every child has its own streams, so the latency-bound end of one
+  // child's per-block launch (launch floor + the dependent chain of its last channel) runs under the bandwidth-bound
+  // middle of another's. A set with children holds no device state itself; every entry point forwards.
+  std::vector<rvc_set *> kids;
+  std::vector<int> kid_c0;
   int nch = 0;
   int device = 0;
   unsigned flags = 0;
@@ -116,12 +148,9 @@ struct rvc_set {
   // Causal time tiling of the block-synchronous delay lines (rvc_internal.h, kSweepRows): every kSweepRows-th
   // block a sweep reads the stage's IR spectra and delay line ONCE and leaves partial sums for kSweepRows blocks;
   // the blocks in between only add their few missing (recent) partitions.
-  bool tile_A = false, tile_T = false;
-  float2 *sA = nullptr, *sT = nullptr;     // sweep rows [nch][kSweepRows][B], slot = block & (kSweepRows - 1)
-  long long sa_t0 = -1, st_t0 = -1;        // blocks [t0, t0 + kSweepRows) have sweep rows; -1: none
+  Tile tA, tT;                             // zero-latency stage / tail stage
   const float2 *ypre_cur = nullptr;        // where the accumulator of block ypre_block lives: a ypre half or a sweep row
   long long ypre_cur_stride = 0;
-  int sa_rows = 0;                         // rows of sA per channel (kSweepRows; twice that in persistent mode)
   // Persistent block-synchronous kernel (RVC_FLAG_PERSISTENT; rvc_internal.h PkArgs)
   bool pk_enabled = false, pk_running = false, pk_slot = false;
   rvc::PkCtl *pk_ctl = nullptr;            // pinned host: doorbell + command ring
@@ -165,6 +194,11 @@ struct rvc_set {
   size_t out_copy_len = 0;       // host-pointer call in flight: copy d_out -> h_out as soon as the output
   hipEvent_t ev_out = nullptr;   // kernel is enqueued (before the off-critical-path work) and mark it here
 
+  // development net (rvc_debug_set_tuning("guard", 1)): every device allocation of the set sits between two NaN-filled
+  // guard bands and starts out NaN-filled itself; rvc_debug_guard_check counts guard bytes that changed
+  struct GuardRec { char *base; size_t bytes; };
+  std::vector<GuardRec> guards;
+
   bool timing = false;
   std::vector<TimedLaunch> timed[kNumKernelIds];   // event pairs not yet read (folded into the totals every 1024 launches)
   double timed_ms[kNumKernelIds] = {};
@@ -195,6 +229,33 @@ bool use_device(rvc_set *s) {
   return true;
 }
 
+// Device allocations of a set. Guard mode: [256 KiB of 0xFF | payload, 0xFF-filled | 256 KiB of 0xFF] -- an out-of-bounds
+// WRITE lands in a band and is counted by rvc_debug_guard_check; an out-of-bounds or never-written value that is USED
+// is a NaN in the output (0xFFFFFFFF is a quiet NaN), where the unguarded build would read a neighbour's plausible data.
+constexpr size_t kGuardBytes = (size_t)256 << 10;
+hipError_t dev_alloc_raw(rvc_set *s, void **p, size_t bytes) {
+  if (!g_tune.guard) return hipMalloc(p, bytes);
+  char *base = nullptr;
+  hipError_t e = hipMalloc(&base, bytes + 2 * kGuardBytes);
+  if (e != hipSuccess) return e;
+  e = hipMemset(base, 0xFF, bytes + 2 * kGuardBytes);
+  if (e != hipSuccess) { hipFree(base); return e; }
+  *p = base + kGuardBytes;
+  s->guards.push_back({base, bytes});
+  return hipSuccess;
+}
+template <typename T> hipError_t dev_alloc(rvc_set *s, T **p, size_t bytes) { return dev_alloc_raw(s, reinterpret_cast<void **>(p), bytes); }
+void dev_free(rvc_set *s, void *p) {
+  if (!p) return;
+  for (size_t i = 0; i < s->guards.size(); ++i)
+    if (s->guards[i].base + kGuardBytes == (char *)p) {
+      hipFree(s->guards[i].base);
+      s->guards.erase(s->guards.begin() + (long)i);
+      return;
+    }
+  hipFree(p);
+}
+
 bool ensure_streams(rvc_set *s) {
   if (s->streams_ok) return true;
   int count = 0;
@@ -216,9 +277,9 @@ bool ensure_streams(rvc_set *s) {
   return true;
 }
 
-void free_stage(Stage &g) {
-  hipFree(g.H); hipFree(g.X); hipFree(g.Y); hipFree(g.d_ir); hipFree(g.tw); hipFree(g.wsplit);
-  hipFree(g.twd); hipFree(g.wsplitd); hipFree(g.tw8); hipFree(g.tw8d);
+void free_stage(rvc_set *s, Stage &g) {
+  void *all[] = {g.H, g.X, g.Y, g.d_ir, g.tw, g.wsplit, g.twd, g.wsplitd, g.tw8, g.tw8d};
+  for (void *q : all) dev_free(s, q);
   g = Stage();
 }
 
@@ -262,7 +323,7 @@ void free_device_state(rvc_set *s) {
   rvc::FreeGuard guard;              // (other sets' resident kernels stand down while this one frees)
   if (s->pk_ctl) hipHostFree(s->pk_ctl);
   if (s->h_pdone) hipHostFree(s->h_pdone);
-  hipFree(s->pk_ypre_seq); hipFree(s->pk_park); hipFree(s->pk_zero_row); hipFree(s->pk_x_seq);
+  dev_free(s, s->pk_ypre_seq); dev_free(s, s->pk_park); dev_free(s, s->pk_zero_row); dev_free(s, s->pk_x_seq);
   s->pk_ctl = nullptr; s->h_pdone = nullptr; s->pk_ypre_seq = s->pk_park = s->pk_x_seq = nullptr; s->pk_zero_row = nullptr;
   s->pk_enabled = false;
   if (s->streams_ok) {
@@ -272,14 +333,13 @@ void free_device_state(rvc_set *s) {
   }
   drop_jobs(s);
   drop_timing(s);
-  free_stage(s->A);
-  free_stage(s->T);
-  free_stage(s->W);
-  hipFree(s->xring); hipFree(s->tailring); hipFree(s->d_in); hipFree(s->d_out); hipFree(s->ypre);
-  hipFree(s->sA); hipFree(s->sT);
-  s->ypre = nullptr; s->sA = nullptr; s->sT = nullptr;
-  s->tile_A = s->tile_T = false;
-  s->sa_t0 = s->st_t0 = -1;
+  free_stage(s, s->A);
+  free_stage(s, s->T);
+  free_stage(s, s->W);
+  dev_free(s, s->xring); dev_free(s, s->tailring); dev_free(s, s->d_in); dev_free(s, s->d_out); dev_free(s, s->ypre);
+  dev_free(s, s->tA.s1); dev_free(s, s->tA.s2); dev_free(s, s->tT.s1); dev_free(s, s->tT.s2);
+  s->ypre = nullptr;
+  s->tA = Tile(); s->tT = Tile();
   s->ypre_cur = nullptr;
   s->ypre_block = -1;
   if (s->h_in) hipHostFree(s->h_in);
@@ -314,14 +374,14 @@ bool make_twiddles(rvc_set *s, Stage &g) {
     wsd[k] = make_double2(std::cos(ang), std::sin(ang));
     ws[k] = make_float2((float)wsd[k].x, (float)wsd[k].y);
   }
-  RVC_CK(hipMalloc(&g.tw, sizeof(float2) * B));
-  RVC_CK(hipMalloc(&g.wsplit, sizeof(float2) * (nws + 1)));
+  RVC_CK(dev_alloc(s, &g.tw, sizeof(float2) * B));
+  RVC_CK(dev_alloc(s, &g.wsplit, sizeof(float2) * (nws + 1)));
   RVC_CK(hipMemcpy(g.tw, tw.data(), sizeof(float2) * B, hipMemcpyHostToDevice));
   RVC_CK(hipMemcpy(g.wsplit, ws.data(), sizeof(float2) * (nws + 1), hipMemcpyHostToDevice));
   const bool dbl = g.logB <= 13;   // the double transform needs B * 16 bytes of LDS (+pad) <= 136 KiB
   if (dbl) {
-    RVC_CK(hipMalloc(&g.twd, sizeof(double2) * B));
-    RVC_CK(hipMalloc(&g.wsplitd, sizeof(double2) * (nws + 1)));
+    RVC_CK(dev_alloc(s, &g.twd, sizeof(double2) * B));
+    RVC_CK(dev_alloc(s, &g.wsplitd, sizeof(double2) * (nws + 1)));
     RVC_CK(hipMemcpy(g.twd, twd.data(), sizeof(double2) * B, hipMemcpyHostToDevice));
     RVC_CK(hipMemcpy(g.wsplitd, wsd.data(), sizeof(double2) * (nws + 1), hipMemcpyHostToDevice));
   }
@@ -349,10 +409,10 @@ bool make_twiddles(rvc_set *s, Stage &g) {
     }
     if (o != (size_t)n8e) return fail(s, RVC_ERR_HIP, hipSuccess, "twiddle table layout");
     for (size_t i = 0; i < o; ++i) t8[i] = make_float2((float)t8d[i].x, (float)t8d[i].y);
-    RVC_CK(hipMalloc(&g.tw8, sizeof(float2) * o));
+    RVC_CK(dev_alloc(s, &g.tw8, sizeof(float2) * o));
     RVC_CK(hipMemcpy(g.tw8, t8.data(), sizeof(float2) * o, hipMemcpyHostToDevice));
     if (dbl) {
-      RVC_CK(hipMalloc(&g.tw8d, sizeof(double2) * o));
+      RVC_CK(dev_alloc(s, &g.tw8d, sizeof(double2) * o));
       RVC_CK(hipMemcpy(g.tw8d, t8d.data(), sizeof(double2) * o, hipMemcpyHostToDevice));
     }
   }
@@ -364,13 +424,13 @@ bool make_twiddles(rvc_set *s, Stage &g) {
 bool upload_ir_stage(rvc_set *s, Stage &g, const float *const *irs, const std::vector<size_t> &counts, bool on_device) {
   // d_ir: [channel][hrows * B] zero-padded samples; irs[c] may be host or (rvc_set_init_impulse) device memory
   const size_t padded = (size_t)g.hrows() * g.B;
-  if (!g.d_ir) RVC_CK(hipMalloc(&g.d_ir, sizeof(float) * (size_t)s->nch * padded));
+  if (!g.d_ir) RVC_CK(dev_alloc(s, &g.d_ir, sizeof(float) * (size_t)s->nch * padded));
   RVC_CK(hipMemsetAsync(g.d_ir, 0, sizeof(float) * (size_t)s->nch * padded, s->st_main));
   for (int c = 0; c < s->nch; ++c)
     if (counts[c])
       RVC_CK(hipMemcpyAsync(g.d_ir + (size_t)c * padded, irs[c], sizeof(float) * counts[c],
                             on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->st_main));
-  if (!g.H) RVC_CK(hipMalloc(&g.H, sizeof(float2) * (size_t)s->nch * g.hrows() * g.B));
+  if (!g.H) RVC_CK(dev_alloc(s, &g.H, sizeof(float2) * (size_t)s->nch * g.hrows() * g.B));
   rvc::FwdArgs a{};
   a.src = g.d_ir; a.src_chan_stride = (long long)padded; a.src_mask = ~0ull;
   a.seg0 = 0; a.valid_len = (int)g.B; a.lo = 0; a.hi = (long long)padded;
@@ -422,6 +482,12 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   // what is used). A host running 16384- or 32768-frame blocks gets the same samples.
   const size_t hb_req = next_pow2(head_block);
   const bool want64 = (s->flags & RVC_FLAG_FFT_F64) != 0;
+  // Default precision: small sets (the plug-in's 2-4 channels; a transform costs them nothing) run stages with
+  // partitions of 2048 .. 8192 samples in double, like the reference's Ooura transform (AudioFFT.cpp:114-159): a float32
+  // transform of that length leaves ~2e-7 of the LARGEST value in every output sample, which fails the reference's own
+  // known-answer rule (Test.cpp:129-145) on its ramp signals. Large lock-step sets stay float32 (1e-7 relative).
+  const bool auto64 = !want64 && (s->flags & RVC_FLAG_FFT_F32) == 0 && s->nch <= 8;
+  auto stage64 = [&](size_t B) { return want64 || (auto64 && B >= 2048 && B <= (size_t)RVC_MAX_BLOCK / 2); };
   const size_t max_block = want64 ? RVC_MAX_BLOCK / 2 : RVC_MAX_BLOCK;
   const size_t hb = std::min(hb_req, max_block);
   size_t tb = two_stage ? std::min(next_pow2(tail_block), max_block) : 0;
@@ -473,7 +539,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     if (pf > 0 && !upload_ir_stage(s, s->T, irs, len, on_device)) { free_device_state(s); return false; }
     if (pw > 0 && !upload_ir_stage(s, s->W, irs, len, on_device)) { free_device_state(s); return false; }
     s->n = 0; s->tail_fft_done = 0; s->tail_out_done = 2; s->xa_next = 0; s->ypre_block = -1;
-    s->w_next = 0; s->xt_valid_lo = 0; s->sa_t0 = s->st_t0 = -1;
+    s->w_next = 0; s->xt_valid_lo = 0; s->tA.drop(); s->tT.drop();
     return true;
   }
 
@@ -486,21 +552,21 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   s->two_stage = two_stage;
   s->max_len = eff_max_len;
   Stage &A = s->A, &T = s->T;
-  A.B = hb; A.logB = ilog2(hb); A.P = (int)pa; A.delay = 0; A.f64 = want64;
+  A.B = hb; A.logB = ilog2(hb); A.P = (int)pa; A.delay = 0; A.f64 = stage64(hb);
   A.mcap = s->max_len / hb + 2;
   A.rows = next_pow2(pa + A.mcap + 1);
   if (!make_twiddles(s, A)) return false;
   if (!upload_ir_stage(s, A, irs, lenA, on_device)) return false;
-  RVC_CK(hipMalloc(&A.X, sizeof(float2) * (size_t)s->nch * A.rows * A.B));
-  RVC_CK(hipMalloc(&A.Y, sizeof(float2) * (size_t)s->nch * A.mcap * A.B));
+  RVC_CK(dev_alloc(s, &A.X, sizeof(float2) * (size_t)s->nch * A.rows * A.B));
+  RVC_CK(dev_alloc(s, &A.Y, sizeof(float2) * (size_t)s->nch * A.mcap * A.B));
   if (pf > 0) {
-    T.B = tb; T.logB = ilog2(tb); T.P = (int)pt; T.PF = (int)pf; T.delay = 2; T.f64 = want64;
+    T.B = tb; T.logB = ilog2(tb); T.P = (int)pt; T.PF = (int)pf; T.delay = 2; T.f64 = stage64(tb);
     T.mcap = s->max_len / tb + 3;
     T.rows = next_pow2(pf + T.mcap + 2);
     if (!make_twiddles(s, T)) return false;
     if (!upload_ir_stage(s, T, irs, len, on_device)) return false;
-    RVC_CK(hipMalloc(&T.X, sizeof(float2) * (size_t)s->nch * T.rows * T.B));
-    RVC_CK(hipMalloc(&T.Y, sizeof(float2) * (size_t)s->nch * T.mcap * T.B));
+    RVC_CK(dev_alloc(s, &T.X, sizeof(float2) * (size_t)s->nch * T.rows * T.B));
+    RVC_CK(dev_alloc(s, &T.Y, sizeof(float2) * (size_t)s->nch * T.mcap * T.B));
   }
   Stage &W = s->W;
   if (pw > 0) {
@@ -509,8 +575,8 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     W.rows = next_pow2(pw + W.mcap + 2);
     if (!make_twiddles(s, W)) return false;
     if (!upload_ir_stage(s, W, irs, len, on_device)) return false;
-    RVC_CK(hipMalloc(&W.X, sizeof(float2) * (size_t)s->nch * W.rows * W.B));
-    RVC_CK(hipMalloc(&W.Y, sizeof(float2) * (size_t)s->nch * W.mcap * W.B));
+    RVC_CK(dev_alloc(s, &W.X, sizeof(float2) * (size_t)s->nch * W.rows * W.B));
+    RVC_CK(dev_alloc(s, &W.Y, sizeof(float2) * (size_t)s->nch * W.mcap * W.B));
   }
   // input history a long call must leave behind: 2 tail blocks for the tail transforms, P+2 head
   // blocks for a rebuild of the head delay line; with a wide stage also a whole wide / tail delay
@@ -520,27 +586,43 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   if (pw > 0) s->keep = std::max<long long>(s->keep, (long long)(pw + 2) * (long long)wb);
   if (pf > 0 && (pw > 0 || uni_long)) s->keep = std::max<long long>(s->keep, (long long)(pf + 4) * (long long)tb);
   s->ring_cap = next_pow2(s->max_len + (size_t)s->keep + 6 * std::max(span, pw > 0 ? wb : (size_t)0) + 4 * hb);
-  RVC_CK(hipMalloc(&s->xring, sizeof(float) * (size_t)s->nch * s->ring_cap));
-  if (pt > 0) RVC_CK(hipMalloc(&s->tailring, sizeof(float) * (size_t)s->nch * s->ring_cap));
-  RVC_CK(hipMalloc(&s->ypre, sizeof(float2) * 2 * (size_t)s->nch * A.B));
+  RVC_CK(dev_alloc(s, &s->xring, sizeof(float) * (size_t)s->nch * s->ring_cap));
+  if (pt > 0) RVC_CK(dev_alloc(s, &s->tailring, sizeof(float) * (size_t)s->nch * s->ring_cap));
+  RVC_CK(dev_alloc(s, &s->ypre, sizeof(float2) * 2 * (size_t)s->nch * A.B));
   RVC_CK(hipMemset(s->ypre, 0, sizeof(float2) * 2 * (size_t)s->nch * A.B));
   s->ypre_block = -1;
-  s->fold = rvc::fused_fold_supported(A.logB) && !want64;
+  s->fold = rvc::fused_fold_supported(A.logB) && !A.f64;
   // time tiling: where a per-block sweep is long enough to be bandwidth- rather than latency-bound
   {
     const bool tiling = (s->flags & RVC_FLAG_NO_TIME_TILING) == 0;
-    const bool force = tiling && (s->flags & RVC_FLAG_FORCE_TIME_TILING) != 0;   // tests: tile whatever the size
+    const bool force2 = tiling && (s->flags & RVC_FLAG_FORCE_TWO_LEVEL) != 0;   // tests: two levels whatever the size
+    const bool force = force2 || (tiling && (s->flags & RVC_FLAG_FORCE_TIME_TILING) != 0);   // tests: tile whatever the size
     const size_t K = (size_t)rvc::kSweepRows;
-    s->tile_A = tiling && s->fold && A.B >= 64 &&
-                (force ? pa >= 3 : (pa >= 16 && (size_t)s->nch * (pa - 2) * A.B * 16 >= ((size_t)4 << 20)));
-    s->tile_T = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
+    Tile &tA = s->tA, &tT = s->tT;
+    tA = Tile(); tT = Tile();
+    tA.on = tiling && s->fold && A.B >= 64 &&
+            (force ? pa >= 3 : (pa >= 16 && (size_t)s->nch * (pa - 2) * A.B * 16 >= ((size_t)4 << 20)));
+    tT.on = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
     // persistent mode: the resident kernel only ever adds a few recent partitions, so the zero-latency stage is tiled
     bool pk = (s->flags & RVC_FLAG_PERSISTENT) != 0 && tiling && s->fold && rvc::persist_supported(A.logB) && pa >= 3;
+    // (its workgroups spin on each other: the whole grid must be resident at once, else ordinary launches)
+    pk = pk && rvc::persist_workgroups(A.logB, s->nch, nullptr, nullptr) <= rvc::persist_capacity(A.logB);
     if (pk && !s->pk_slot) pk = s->pk_slot = pk_acquire_slot();     // (none left: this set uses ordinary launches)
-    if (pk) s->tile_A = true;
+    if (pk) tA.on = true;
     s->pk_enabled = pk;
-    s->sa_rows = (int)K * (pk ? 2 : 1);
-    if (s->tile_A) RVC_CK(hipMalloc(&s->sA, sizeof(float2) * (size_t)s->nch * (size_t)s->sa_rows * A.B));
+    // one level of 8 blocks, or -- long delay lines -- a first level of 16 / 32 blocks with second-level sweeps every 8
+    auto first_level = [&](size_t P) -> int {
+      const int k1 = (g_tune.k1 == 32 || g_tune.k1 == 16) ? g_tune.k1 : (int)K;
+      return (force2 || (int)P > rvc::kTwoLevelMinP) ? k1 : (int)K;
+    };
+    tA.K1 = pk ? (int)K : first_level(pa);       // (the resident kernel's own tile scheme has one level)
+    tA.rows1 = tA.K1 * (pk ? 2 : 1);
+    tT.K1 = first_level(pt);
+    tT.rows1 = tT.K1;
+    if (tA.on) {
+      RVC_CK(dev_alloc(s, &tA.s1, sizeof(float2) * (size_t)s->nch * (size_t)tA.rows1 * A.B));
+      if (tA.K1 > (int)K) RVC_CK(dev_alloc(s, &tA.s2, sizeof(float2) * (size_t)s->nch * K * A.B));
+    }
     if (pk) {
       if (!s->st_pk) {
         // the resident kernel gets a stream of its own priority class: the runtime multiplexes streams of one class onto a
@@ -556,24 +638,26 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
       std::memset((void *)s->pk_ctl, 0, sizeof(rvc::PkCtl));
       RVC_CK(hipHostMalloc(&s->h_pdone, sizeof(unsigned) * (size_t)s->pk_n_patch, hipHostMallocDefault));
       std::memset(s->h_pdone, 0, sizeof(unsigned) * (size_t)s->pk_n_patch);
-      RVC_CK(hipMalloc(&s->pk_ypre_seq, sizeof(unsigned) * (size_t)s->pk_n_patch));
+      RVC_CK(dev_alloc(s, &s->pk_ypre_seq, sizeof(unsigned) * (size_t)s->pk_n_patch));
       RVC_CK(hipMemset(s->pk_ypre_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_patch));
-      RVC_CK(hipMalloc(&s->pk_x_seq, sizeof(unsigned) * (size_t)s->pk_n_audio));
+      RVC_CK(dev_alloc(s, &s->pk_x_seq, sizeof(unsigned) * (size_t)s->pk_n_audio));
       RVC_CK(hipMemset(s->pk_x_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_audio));
-      RVC_CK(hipMalloc(&s->pk_park, sizeof(unsigned)));
+      RVC_CK(dev_alloc(s, &s->pk_park, sizeof(unsigned)));
       RVC_CK(hipMemset(s->pk_park, 0, sizeof(unsigned)));
-      RVC_CK(hipMalloc(&s->pk_zero_row, sizeof(float2) * (size_t)s->nch * A.B));
+      RVC_CK(dev_alloc(s, &s->pk_zero_row, sizeof(float2) * (size_t)s->nch * A.B));
       RVC_CK(hipMemset(s->pk_zero_row, 0, sizeof(float2) * (size_t)s->nch * A.B));
       s->pk_seq = s->pk_retired = 0;
       s->pk_tile_hi = s->pk_tile_ready = -1;
       s->pk_need_acquire = false;
       s->pk_ypre_from = 0;
     }
-    if (s->tile_T) RVC_CK(hipMalloc(&s->sT, sizeof(float2) * (size_t)s->nch * K * T.B));
-    s->sa_t0 = s->st_t0 = -1;
+    if (tT.on) {
+      RVC_CK(dev_alloc(s, &tT.s1, sizeof(float2) * (size_t)s->nch * (size_t)tT.rows1 * T.B));
+      if (tT.K1 > (int)K) RVC_CK(dev_alloc(s, &tT.s2, sizeof(float2) * (size_t)s->nch * K * T.B));
+    }
   }
-  RVC_CK(hipMalloc(&s->d_in, sizeof(float) * (size_t)s->nch * s->max_len));
-  RVC_CK(hipMalloc(&s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
+  RVC_CK(dev_alloc(s, &s->d_in, sizeof(float) * (size_t)s->nch * s->max_len));
+  RVC_CK(dev_alloc(s, &s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipHostMalloc(&s->h_in, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
   RVC_CK(hipHostMalloc(&s->h_out, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
   RVC_CK(hipHostMalloc(&s->h_flags, sizeof(unsigned) * (size_t)s->nch, hipHostMallocDefault));   // (>= audio workgroups)
@@ -622,6 +706,52 @@ struct Timer {   // brackets one launch with events when timing is on
     if (s->timed[id].size() >= 1024) fold_timing(s, id);   // bounded: streaming use with RVC_FLAG_TIMING does not grow
   }
 };
+
+// ---- causal time tiling: sweep launches shared by both stages -----------------------------------
+// The delay line of a stage as a sweep sees it: the zero-latency stage's whole table with delay 0 (the sweep's x_hi
+// keeps the two newest partitions out), the tail stage's partitions 2.. with delay 2.
+rvc::FirArgs stage_line(rvc_set *s, bool tail) {
+  Stage &g = tail ? s->T : s->A;
+  const long long B = (long long)g.B;
+  rvc::FirArgs r{};
+  if (tail) { r.H = g.H + 2 * B; r.h_chan_stride = (long long)g.PF * B; r.delay = 2; r.tag = 1; }
+  else { r.H = g.H; r.h_chan_stride = (long long)g.P * B; r.delay = 0; r.tag = 0; }
+  r.X = g.X; r.x_chan_stride = (long long)g.rows * B; r.x_row_mask = g.rows - 1;
+  r.P = g.P; r.B = (int)B;
+  return r;
+}
+// first level: blocks [k0, k0 + K1), every partition, the input rows <= x_hi
+rvc::FirArgs sweep1_args(rvc_set *s, bool tail, long long k0, long long x_hi) {
+  const Tile &t = tail ? s->tT : s->tA;
+  rvc::FirArgs r = stage_line(s, tail);
+  r.Y = t.s1; r.y_chan_stride = (long long)t.rows1 * r.B; r.y_row_mask = (unsigned)(t.rows1 - 1);
+  r.k0 = k0; r.M = t.K1; r.x_hi = x_hi;
+  return r;
+}
+// second level: blocks [g0, g0 + 8) of the tile that started at t0: first-level rows + the input rows t0 - 1 .. g0 - 2
+rvc::FirArgs sweep2_args(rvc_set *s, bool tail, long long g0) {
+  const Tile &t = tail ? s->tT : s->tA;
+  const long long K = rvc::kSweepRows;
+  rvc::FirArgs r = stage_line(s, tail);
+  r.Y = t.s2; r.y_chan_stride = K * r.B; r.y_row_mask = (unsigned)(K - 1);
+  r.Ybase = t.s1; r.ybase_chan_stride = (long long)t.rows1 * r.B; r.ybase_row_mask = (unsigned)(t.rows1 - 1);
+  r.k0 = g0; r.M = (int)K; r.x_from = t.t0 - 1; r.x_hi = g0 - 2;
+  // the oldest row that counts (t0 - 1) meets block g0 + 7 in partition g0 + 7 - delay - (t0 - 1)
+  r.P = (int)std::min<long long>(r.P, g0 - t.t0 + K + 1 - r.delay);
+  return r;
+}
+// where the partial sums of block b live -- b inside the current first-level tile, and past its first group only once
+// that group's second-level sweep has run -- and the per-channel stride of those rows
+const float2 *tile_row(const rvc_set *s, bool tail, long long b, long long *stride) {
+  const Tile &t = tail ? s->tT : s->tA;
+  const size_t B = tail ? s->T.B : s->A.B;
+  if (t.K1 > rvc::kSweepRows && t.group(b) != t.t0) {
+    *stride = (long long)rvc::kSweepRows * (long long)B;
+    return t.s2 + (size_t)((unsigned long long)b & (unsigned long long)(rvc::kSweepRows - 1)) * B;
+  }
+  *stride = (long long)t.rows1 * (long long)B;
+  return t.s1 + (size_t)((unsigned long long)b & (unsigned long long)(t.rows1 - 1)) * B;
+}
 
 // ---- tail stage pieces -------------------------------------------------------------------
 // Spectra of the tail blocks a call ending at n1 completed. `src2` = the call's own input when
@@ -675,31 +805,41 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
   r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
   r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
   r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = 2; r.B = (int)tb; r.tag = 1;
-  const long long K = rvc::kSweepRows;
   const float2 *yrows = T.Y;                      // where the inverse transforms read the spectra
-  if (s->tile_T && r.M == 1) {
-    // block-synchronous streaming, time-tiled: output block m_lo either lies in the current sweep tile -- then only
-    // the partitions whose input arrived after the sweep are added to the sweep's row -- or starts a new tile
-    const long long sTstride = K * tb;
-    if (s->st_t0 >= 0 && m_lo > s->st_t0 && m_lo < s->st_t0 + K) {
-      const long long t = m_lo - s->st_t0;         // input rows m_lo-2 .. m_lo-1-t came after the sweep
-      r.P = (int)std::min<long long>(t, T.P);
-      r.Yadd = s->sT + (size_t)((unsigned long long)m_lo & (unsigned long long)(K - 1)) * tb;
-      r.yadd_chan_stride = sTstride;
-      Timer tm(s, 5, st);
-      RVC_CK(rvc::launch_fir(r, s->nch, st));
+  if (s->tT.on && r.M == 1) {
+    // block-synchronous streaming, time-tiled: output block m_lo either lies in the current tile -- then only the
+    // partitions whose input arrived after the (second-level) sweep are added to that sweep's row -- or starts a new tile
+    Tile &t = s->tT;
+    if (t.t0 >= 0 && m_lo > t.t0 && m_lo < t.t0 + t.K1) {
+      const long long g0 = t.group(m_lo);
+      if (g0 != t.t0 && t.s0 != g0) {              // entering the next group of 8: second-level sweep
+        const rvc::FirArgs w = sweep2_args(s, true, g0);
+        Timer tm(s, 12, st);
+        RVC_CK(rvc::launch_fdl_sweep(w, s->nch, st));
+        t.s0 = g0;
+      }
+      long long stride = 0;
+      const float2 *row = tile_row(s, true, m_lo, &stride);
+      const long long recent = m_lo - g0;          // input rows g0-1 .. m_lo-2 came after the sweep
+      if (recent > 0) {
+        r.P = (int)std::min<long long>(recent, T.P);
+        r.Yadd = row; r.yadd_chan_stride = stride;
+        Timer tm(s, 5, st);
+        RVC_CK(rvc::launch_fir(r, s->nch, st));
+      } else {                                     // the group's first block: its sweep row is complete
+        yrows = row; r.y_chan_stride = stride;
+      }
     } else {
-      r.M = (int)K; r.Y = s->sT; r.y_chan_stride = sTstride; r.y_row_mask = (unsigned)(K - 1);
-      r.x_hi = m_lo - 2;                           // newest delay-line row that exists
-      Timer tm(s, 10, st);
-      RVC_CK(rvc::launch_fdl_sweep(r, s->nch, st));
-      s->st_t0 = m_lo;
-      yrows = s->sT + (size_t)((unsigned long long)m_lo & (unsigned long long)(K - 1)) * tb;
-      r.y_chan_stride = sTstride;
-      r.M = 1;
+      const rvc::FirArgs w = sweep1_args(s, true, m_lo, m_lo - 2);   // (m_lo - 2: the newest delay-line row that exists)
+      {
+        Timer tm(s, 10, st);
+        RVC_CK(rvc::launch_fdl_sweep(w, s->nch, st));
+      }
+      t.t0 = m_lo; t.s0 = -1;
+      yrows = tile_row(s, true, m_lo, &r.y_chan_stride);             // (row m_lo is complete)
     }
   } else {
-    s->st_t0 = -1;                                 // several rows at once: plain delay line, any tile is dropped
+    s->tT.drop();                                  // several rows at once: plain delay line, any tile is dropped
     Timer t(s, 5, st);
     RVC_CK(rvc::launch_fir(r, s->nch, st));
   }
@@ -834,35 +974,34 @@ rvc::FirArgs premultiply_args(rvc_set *s, long long kb) {
   return r;
 }
 
-// A sweep of the zero-latency stage for the tile of blocks starting at kb: partial sums of blocks kb .. kb+K-1
-// over the input rows that exist (<= kb - 2); row kb is complete (= sum_{i>=2} H_i X_{kb-i}).
-rvc::FirArgs head_sweep_args(rvc_set *s, long long kb) {
-  Stage &A = s->A;
-  const long long K = rvc::kSweepRows, R = s->sa_rows;
-  rvc::FirArgs r{};
-  r.H = A.H; r.h_chan_stride = (long long)A.P * (long long)A.B;
-  r.X = A.X; r.x_chan_stride = (long long)A.rows * (long long)A.B; r.x_row_mask = A.rows - 1;
-  r.Y = s->sA; r.y_chan_stride = R * (long long)A.B; r.y_row_mask = (unsigned)(R - 1);
-  r.k0 = kb; r.M = (int)K; r.P = A.P; r.delay = 0; r.B = (int)A.B; r.x_hi = kb - 2;
-  return r;
+// A first-level sweep of the zero-latency stage for the tile of blocks starting at kb: partial sums of blocks
+// kb .. kb+K1-1 over the input rows that exist (<= kb - 2); row kb is complete (= sum_{i>=2} H_i X_{kb-i}).
+bool run_head_sweep1(rvc_set *s, long long kb) {
+  const rvc::FirArgs r = sweep1_args(s, false, kb, kb - 2);
+  {
+    Timer t(s, 9, s->st_main);
+    RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
+  }
+  s->tA.t0 = kb; s->tA.s0 = -1;
+  s->ypre_block = kb;
+  s->ypre_cur = tile_row(s, false, kb, &s->ypre_cur_stride);
+  return true;
 }
-const float2 *head_sweep_row(const rvc_set *s, long long k) {
-  return s->sA + (size_t)((unsigned long long)k & (unsigned long long)(s->sa_rows - 1)) * s->A.B;
+// The second-level sweep for the group of 8 blocks starting at g0 inside the current tile; row g0 is complete.
+bool run_head_sweep2(rvc_set *s, long long g0) {
+  const rvc::FirArgs r = sweep2_args(s, false, g0);
+  {
+    Timer t(s, 11, s->st_main);
+    RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
+  }
+  s->tA.s0 = g0;
+  s->ypre_block = g0;
+  s->ypre_cur = tile_row(s, false, g0, &s->ypre_cur_stride);
+  return true;
 }
 
 bool run_premultiply(rvc_set *s, long long kb) {
-  if (s->tile_A) {    // (state was invalidated: a stand-alone sweep starts a new tile at kb)
-    const rvc::FirArgs r = head_sweep_args(s, kb);
-    {
-      Timer t(s, 9, s->st_main);
-      RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
-    }
-    s->sa_t0 = kb;
-    s->ypre_block = kb;
-    s->ypre_cur = head_sweep_row(s, kb);
-    s->ypre_cur_stride = r.y_chan_stride;
-    return true;
-  }
+  if (s->tA.on) return run_head_sweep1(s, kb);    // (state was invalidated: a stand-alone sweep starts a new tile at kb)
   const rvc::FirArgs r = premultiply_args(s, kb);
   if (r.P > 0) {      // (no partitions beyond the folded ones: the accumulator stays zero, as allocated)
     Timer t(s, 8, s->st_main);
@@ -896,7 +1035,7 @@ void mark_long_stage_stale(rvc_set *s, long long n1) {
   if (T.PF > 0 && T.P == 0) {
     s->tail_fft_done = n1 / (long long)T.B;
     s->xt_valid_lo = s->tail_fft_done;
-    s->st_t0 = -1;
+    s->tT.drop();
   }
 }
 
@@ -911,8 +1050,22 @@ constexpr double kPkHostTimeoutS = 5.0;
 // could queue one behind another (and wait for it to park). Further persistent sets use ordinary launches.
 constexpr int kPkMaxResident = 2;
 std::atomic<int> g_pk_resident{0};
-std::atomic<int> g_pk_active{0};      // resident kernels running right now (process-wide)
 std::atomic<int> g_pk_pause{0};       // threads about to free device memory (rvc::free_guard_enter)
+// resident kernels launched and not yet collected by their owner (process-wide). One that has PARKED itself is still
+// listed until its owner's next call, but no longer holds a stream busy: free_guard_enter skips those.
+std::mutex g_pk_mu;
+std::vector<rvc::PkCtl *> g_pk_live;
+void pk_register(rvc::PkCtl *c) { std::lock_guard<std::mutex> l(g_pk_mu); g_pk_live.push_back(c); }
+void pk_unregister(rvc::PkCtl *c) {
+  std::lock_guard<std::mutex> l(g_pk_mu);
+  g_pk_live.erase(std::remove(g_pk_live.begin(), g_pk_live.end(), c), g_pk_live.end());
+}
+int pk_busy_count() {
+  std::lock_guard<std::mutex> l(g_pk_mu);
+  int n = 0;
+  for (rvc::PkCtl *c : g_pk_live) n += (c->parked == 0 && c->error == 0) ? 1 : 0;
+  return n;
+}
 bool pk_paused() { return g_pk_pause.load(std::memory_order_acquire) > 0; }
 
 void pk_push(rvc_set *s, const rvc::PkCmd &c) {
@@ -954,7 +1107,7 @@ bool pk_launch(rvc_set *s, unsigned seq0) {
   if (const char *e = std::getenv("RVC_PERSIST_IDLE_MS")) a.idle_ticks = (long long)(std::atof(e) * 1e5);
   RVC_CK(rvc::launch_persist(A.logB, a, s->nch, s->st_pk));
   s->pk_running = true;
-  g_pk_active.fetch_add(1);
+  pk_register(s->pk_ctl);
   return true;
 }
 
@@ -974,7 +1127,7 @@ bool pk_collect(rvc_set *s) {
   if (!s->pk_running) return true;
   RVC_CK(hipStreamSynchronize(s->st_pk));
   s->pk_running = false;
-  g_pk_active.fetch_sub(1);
+  pk_unregister(s->pk_ctl);
   if (s->pk_ctl->error) {
     char buf[96];
     snprintf(buf, sizeof(buf), "persistent kernel gave up (code 0x%llx)", (unsigned long long)s->pk_ctl->error);
@@ -1010,12 +1163,17 @@ bool pk_wait_flags(rvc_set *s, volatile unsigned *f, int n, unsigned seq) {
   return true;
 }
 
-void pk_launch_sweep(rvc_set *s, long long t0) {   // the tile [t0, t0 + K): partial sums over the rows <= t0 - 2 - lag
-  rvc::FirArgs r = head_sweep_args(s, t0);
-  r.x_hi = t0 - 2 - rvc::kPkLag;
-  (void)rvc::launch_fdl_sweep(r, s->nch, s->st_main);
-  (void)hipEventRecord(s->ev_sweep, s->st_main);
+// the tile [t0, t0 + K) of the resident kernel's (single-level, double-buffered) scheme: partial sums over the rows
+// <= t0 - 2 - lag
+bool pk_launch_sweep(rvc_set *s, long long t0) {
+  const rvc::FirArgs r = sweep1_args(s, false, t0, t0 - 2 - rvc::kPkLag);
+  RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
+  RVC_CK(hipEventRecord(s->ev_sweep, s->st_main));
   s->pk_tile_hi = t0;
+  return true;
+}
+const float2 *pk_sweep_row(const rvc_set *s, long long k) {
+  return s->tA.s1 + (size_t)((unsigned long long)k & (unsigned long long)(s->tA.rows1 - 1)) * s->A.B;
 }
 
 // post-actions of the steps up to `seq`, in order, once their audio workgroups are done: the tail job of a completed
@@ -1030,7 +1188,7 @@ bool pk_retire_upto(rvc_set *s, unsigned seq) {
     if (st.block_done) {
       if (s->T.P > 0 && !run_tail_job(s, st.n0, st.n1, nullptr, 0, /*bg=*/true)) return false;
       const long long t0 = st.k + 2 + rvc::kPkLag;
-      if (t0 % K == 0 && t0 > s->pk_tile_hi) pk_launch_sweep(s, t0);
+      if (t0 % K == 0 && t0 > s->pk_tile_hi && !pk_launch_sweep(s, t0)) return false;
     }
   }
   return true;
@@ -1045,9 +1203,11 @@ bool pk_quiesce(rvc_set *s) {
 
 void pk_stop(rvc_set *s) {
   if (!s->pk_enabled || !s->pk_ctl) return;
+  // Steps that were pushed but not retired must still run and retire (their tail jobs and sweeps are issued on
+  // retirement) -- also when the kernel has parked itself meanwhile: quiescing relaunches it and the steps replay.
+  if (s->pk_retired != s->pk_seq && s->err == RVC_OK && s->streams_ok) (void)pk_quiesce(s);
   if (s->pk_running) {
     if (!(s->pk_ctl->parked || s->pk_ctl->error)) {
-      (void)pk_quiesce(s);
       rvc::PkCmd c{};
       c.flags = rvc::PK_QUIT;
       c.seq = ++s->pk_seq;
@@ -1055,7 +1215,7 @@ void pk_stop(rvc_set *s) {
     }
     hipStreamSynchronize(s->st_pk);
     s->pk_running = false;
-    g_pk_active.fetch_sub(1);
+    pk_unregister(s->pk_ctl);
   }
   s->pk_retired = s->pk_seq;
   // nothing is resident any more: every flag stands at the last sequence number (the quit command is never acknowledged)
@@ -1103,7 +1263,11 @@ bool pk_step(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size
     if (!pk_wait_tail(s, n1)) return false;
     const long long need = (n1 - 1) / (long long)T.B + 1;
     if (s->tail_out_done < need) {                            // (after a clock restart / other call patterns: made now)
+      // Quiescing retires the steps still in flight -- one of them may be the step that completed the tail block this
+      // call reads, and its retirement has just launched that tail job on the second stream: wait for it (the resident
+      // kernel is on no stream an event could hold back) before anything reads the tail ring.
       if (!pk_quiesce(s)) return false;
+      if (!pk_wait_tail(s, n1)) return false;
       if (!tail_rows(s, need, s->st_main)) return false;
       RVC_CK(hipStreamSynchronize(s->st_main));
     }
@@ -1113,7 +1277,7 @@ bool pk_step(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size
   const float2 *ypre = nullptr;
   long long ypre_stride = hb;
   // (an accumulator that ordinary launches left in a sweep row is not taken over: this mode's own sweeps reuse the rows)
-  const bool in_sweep_rows = s->sA && s->ypre_cur >= s->sA && s->ypre_cur < s->sA + (size_t)s->nch * (size_t)s->sa_rows * A.B;
+  const bool in_sweep_rows = s->tA.s1 && s->ypre_cur >= s->tA.s1 && s->ypre_cur < s->tA.s1 + (size_t)s->nch * (size_t)s->tA.rows1 * A.B;
   if (s->ypre_block == k0 && !in_sweep_rows) {
     ypre = s->ypre_cur; ypre_stride = s->ypre_cur_stride; ypre_wait = s->pk_ypre_from;
   } else {
@@ -1140,7 +1304,7 @@ bool pk_step(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size
     const long long kn = k0 + 1, t0 = kn - kn % K;
     if (s->pk_tile_hi < t0) {     // the retire path has not launched this tile's sweep yet: the block it waits for
       if (!pk_retire_upto(s, s->pk_seq)) return false;        // (t0 - 2 - lag) may still be in flight -- drain, then
-      if (s->pk_tile_hi < t0) pk_launch_sweep(s, t0);          // (entry / restart) launch it here
+      if (s->pk_tile_hi < t0 && !pk_launch_sweep(s, t0)) return false;   // (entry / restart) launch it here
     }
     if (s->pk_tile_ready < t0) {
       RVC_CK(hipEventSynchronize(s->ev_sweep));
@@ -1148,8 +1312,8 @@ bool pk_step(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size
     }
     c.patch_P = std::min<long long>(kn - t0 + rvc::kPkLag, (long long)A.P - 2);
     if (c.patch_P < 0) c.patch_P = 0;
-    c.patch_yadd = (unsigned long long)(uintptr_t)head_sweep_row(s, kn);
-    c.patch_yadd_stride = (long long)s->sa_rows * hb;
+    c.patch_yadd = (unsigned long long)(uintptr_t)pk_sweep_row(s, kn);
+    c.patch_yadd_stride = (long long)s->tA.rows1 * hb;
     c.patch_y = (unsigned long long)(uintptr_t)(s->ypre + (size_t)(kn & 1) * (size_t)s->nch * (size_t)hb);
   }
   if (!pk_ensure_running(s)) return false;
@@ -1169,7 +1333,7 @@ bool pk_step(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size
     if (c.patch_P > 0) {
       s->ypre_cur = reinterpret_cast<const float2 *>((uintptr_t)c.patch_y); s->ypre_cur_stride = hb;
     } else {                                                   // (nothing to add: the sweep row is the accumulator)
-      s->ypre_cur = head_sweep_row(s, kn); s->ypre_cur_stride = c.patch_yadd_stride;
+      s->ypre_cur = pk_sweep_row(s, kn); s->ypre_cur_stride = c.patch_yadd_stride;
     }
     s->pk_ypre_from = c.seq;
   }
@@ -1194,7 +1358,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       s->out_copy_len = 0;
       s->flag_count = -1;                // process_end: wait for this step's completion flags
     }
-    s->sa_t0 = -1;                       // (the sweep rows now follow the resident kernel's tile scheme)
+    s->tA.drop();                        // (the sweep rows now follow the resident kernel's tile scheme)
     return pk_step(s, d_in, in_stride, d_out, out_stride, len);
   }
   if (s->pk_enabled) {
@@ -1215,7 +1379,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       if (!head_spectra(s, head_fft_from(s, k0), k0 - 1, n0, nullptr, 0, 0)) return false;
       s->xa_next = k0;
       s->ypre_block = -1;
-      s->sa_t0 = -1;
+      s->tA.drop();
     }
     if (s->ypre_block != k0 && !run_premultiply(s, k0)) return false;
     rvc::FusedArgs g{};
@@ -1246,15 +1410,23 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       // the workgroups appended to this launch prepare block k0+1's accumulator (other half of ypre)
       const long long kn = k0 + 1;
       rvc::FirArgs f = premultiply_args(s, kn);
-      bool new_tile = false;
-      if (s->tile_A && block_done) {
-        const long long K = rvc::kSweepRows;
-        if (s->sa_t0 >= 0 && kn > s->sa_t0 && kn < s->sa_t0 + K) {
-          // inside the current tile: the sweep's row + the partitions whose input arrived after the sweep
-          f.P = (int)std::min<long long>(kn - s->sa_t0, (long long)A.P - 2);
-          f.Yadd = head_sweep_row(s, kn);
-          f.yadd_chan_stride = (long long)s->sa_rows * hb;
-          if (f.P <= 0) { f.P = 0; f.Y = const_cast<float2 *>(f.Yadd); f.y_chan_stride = f.yadd_chan_stride; }   // nothing to add
+      bool new_tile = false, new_group = false;
+      if (s->tA.on && block_done) {
+        Tile &ta = s->tA;
+        if (ta.t0 >= 0 && kn > ta.t0 && kn < ta.t0 + ta.K1) {
+          const long long g0 = ta.group(kn);
+          if (g0 == ta.t0 || ta.s0 == g0) {
+            // inside a group whose sweep rows exist: that row + the partitions whose input arrived after the sweep
+            f.P = (int)std::min<long long>(kn - g0, (long long)A.P - 2);
+            f.Yadd = tile_row(s, false, kn, &f.yadd_chan_stride);
+            if (f.P <= 0) { f.P = 0; f.Y = const_cast<float2 *>(f.Yadd); f.y_chan_stride = f.yadd_chan_stride; }   // nothing to add
+          } else if (kn == g0) {   // the next group of 8 starts: a second-level sweep behind this launch (its row kn is complete)
+            f.P = 0;
+            new_group = true;
+          } else {                 // (cannot happen in block order; be safe: start over)
+            f.P = 0;
+            new_tile = true;
+          }
         } else {      // the tile is used up: a sweep behind this launch starts the next one (its row kn is complete)
           f.P = 0;
           new_tile = true;
@@ -1268,7 +1440,9 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       if (!emit_output_copy(s)) return false;
       if (block_done) {
         if (new_tile) {
-          if (!run_premultiply(s, kn)) return false;     // (sweep launch: sets sa_t0, ypre_block, ypre_cur)
+          if (!run_premultiply(s, kn)) return false;     // (sweep launch: sets the tile, ypre_block, ypre_cur)
+        } else if (new_group) {
+          if (!run_head_sweep2(s, kn)) return false;
         } else {
           s->ypre_block = kn;
           s->ypre_cur = f.Y;
@@ -1375,7 +1549,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     s->xt_valid_lo = s->tail_fft_done;
     const long long done = (n1 % tb == 0) ? (n1 - 1) / tb + 1 : (n1 - 1) / tb;
     if (s->tail_out_done < done) s->tail_out_done = done;
-    s->st_t0 = -1;
+    s->tT.drop();
     s->n = n1;
     return true;
   }
@@ -1441,7 +1615,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       // computed lazily if a later short call continues inside it
       const long long done = (n1 % tb == 0) ? m_last + 1 : m_last;
       if (s->tail_out_done < done) s->tail_out_done = done;
-      s->st_t0 = -1;
+      s->tT.drop();
       s->n = n1;
       return true;
     }
@@ -1453,6 +1627,47 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   mark_long_stage_stale(s, n1);
   s->n = n1;
   return true;
+}
+
+// How many children a set of nch channels gets at this init (1: none). Measured on MI355X (profiles/r3_subsets.txt).
+int subset_count(const rvc_set *s, size_t head_block, size_t max_len) {
+  if ((s->flags & (RVC_FLAG_PERSISTENT | RVC_FLAG_NO_SUBSETS)) != 0) return 1;
+  int n = g_tune.subsets;
+  if (n < 0) n = 1;                     // (auto: see rvc_set_init)
+  if (n > 8) n = 8;
+  while (n > 1 && (s->nch % n != 0 || s->nch / n < 2)) --n;
+  (void)head_block; (void)max_len;
+  return n < 1 ? 1 : n;
+}
+void drop_kids(rvc_set *s) {
+  for (rvc_set *k : s->kids) rvc_set_destroy(k);
+  s->kids.clear();
+  s->kid_c0.clear();
+}
+// (re)build the children for this init; false: the set stays childless
+bool make_kids(rvc_set *s, int n) {
+  if (n <= 1) { drop_kids(s); return false; }
+  if ((int)s->kids.size() == n) return true;
+  drop_kids(s);
+  if (s->streams_ok || s->live) free_device_state(s);
+  const int per = s->nch / n;
+  for (int k = 0; k < n; ++k) {
+    rvc_set *c = rvc_set_create(per, s->device, s->flags | RVC_FLAG_NO_SUBSETS);
+    if (!c) { drop_kids(s); return false; }
+    c->timing = s->timing;
+    s->kids.push_back(c);
+    s->kid_c0.push_back(k * per);
+  }
+  return true;
+}
+// the parent mirrors what its accessors report
+void adopt_kid_geometry(rvc_set *s, bool ok) {
+  const rvc_set *k = s->kids[0];
+  s->head = k->head; s->tail = k->tail; s->max_len = k->max_len; s->two_stage = k->two_stage;
+  s->inited = ok; s->live = false;
+  s->err = RVC_OK; s->errstr.clear();
+  for (const rvc_set *c : s->kids)
+    if (c->err != RVC_OK && s->err == RVC_OK) { s->err = c->err; s->errstr = c->errstr; }
 }
 
 // A failed init must not keep the stages it had already allocated (the sticky error stays readable)
@@ -1480,10 +1695,10 @@ bool zero_device_out(rvc_set *s, float *d_out, size_t out_stride, size_t len) {
 namespace rvc {
 void free_guard_enter() {
   g_pk_pause.fetch_add(1, std::memory_order_acq_rel);
-  // owners stop their resident kernels at their next call; idle kernels park by themselves within 2 s (their count is
-  // only corrected when the owner collects them, hence the bound)
+  // owners stop their resident kernels at their next call; idle kernels park by themselves within 2 s and are not
+  // waited for once they have (a parked kernel has left its stream)
   const auto t0 = std::chrono::steady_clock::now();
-  while (g_pk_active.load(std::memory_order_acquire) > 0 &&
+  while (pk_busy_count() > 0 &&
          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.5)
     std::this_thread::sleep_for(std::chrono::microseconds(200));
 }
@@ -1510,6 +1725,7 @@ rvc_set *rvc_set_create(int n_channels, int device, unsigned flags) {
 
 void rvc_set_destroy(rvc_set *s) {
   if (!s) return;
+  drop_kids(s);
   free_device_state(s);
   if (s->streams_ok) {
     for (int i = 0; i < s->ev_free; ++i) hipEventDestroy(s->ev_pool[i]);
@@ -1526,6 +1742,13 @@ void rvc_set_destroy(rvc_set *s) {
 int rvc_set_init(rvc_set *s, size_t head_block, size_t tail_block, const float *const *irs,
                  const size_t *ir_lens, size_t max_len) {
   if (!s) return 0;
+  if (irs && ir_lens && make_kids(s, subset_count(s, head_block, max_len))) {
+    bool ok = true;
+    for (size_t k = 0; k < s->kids.size(); ++k)
+      ok = rvc_set_init(s->kids[k], head_block, tail_block, irs + s->kid_c0[k], ir_lens + s->kid_c0[k], max_len) != 0 && ok;
+    adopt_kid_geometry(s, ok);
+    return ok ? 1 : 0;
+  }
   const bool ok = do_init(s, head_block, tail_block, true, irs, ir_lens, max_len);
   if (!ok) release_after_failed_init(s);
   return ok ? 1 : 0;
@@ -1534,6 +1757,13 @@ int rvc_set_init(rvc_set *s, size_t head_block, size_t tail_block, const float *
 int rvc_set_init_uniform(rvc_set *s, size_t block, const float *const *irs, const size_t *ir_lens,
                          size_t max_len) {
   if (!s) return 0;
+  if (irs && ir_lens && make_kids(s, subset_count(s, block, max_len))) {
+    bool ok = true;
+    for (size_t k = 0; k < s->kids.size(); ++k)
+      ok = rvc_set_init_uniform(s->kids[k], block, irs + s->kid_c0[k], ir_lens + s->kid_c0[k], max_len) != 0 && ok;
+    adopt_kid_geometry(s, ok);
+    return ok ? 1 : 0;
+  }
   const bool ok = do_init(s, block, 0, false, irs, ir_lens, max_len);
   if (!ok) release_after_failed_init(s);
   return ok ? 1 : 0;
@@ -1542,6 +1772,13 @@ int rvc_set_init_uniform(rvc_set *s, size_t block, const float *const *irs, cons
 int rvc_set_init_impulse(rvc_set *s, size_t head_block, size_t tail_block, rvc_impulse *m, const int *channels,
                          size_t max_len) {
   if (!s) return 0;
+  if (channels && make_kids(s, subset_count(s, head_block, max_len))) {
+    bool ok = true;
+    for (size_t k = 0; k < s->kids.size(); ++k)
+      ok = rvc_set_init_impulse(s->kids[k], head_block, tail_block, m, channels + s->kid_c0[k], max_len) != 0 && ok;
+    adopt_kid_geometry(s, ok);
+    return ok ? 1 : 0;
+  }
   rvc::ImpulseView v{};
   if (!m || !channels || !rvc::impulse_view(m, &v)) {
     s->err = RVC_OK;
@@ -1568,6 +1805,12 @@ int rvc_set_init_impulse(rvc_set *s, size_t head_block, size_t tail_block, rvc_i
 void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out,
                             size_t out_stride, size_t len) {
   if (!s || len == 0) return;
+  if (!s->kids.empty()) {
+    for (size_t k = 0; k < s->kids.size(); ++k)
+      rvc_set_process_device(s->kids[k], d_in + (size_t)s->kid_c0[k] * in_stride, in_stride,
+                             d_out + (size_t)s->kid_c0[k] * out_stride, out_stride, len);
+    return;
+  }
   if (!s->live || s->err != RVC_OK) {   // not initialised / empty IR / failed: zeros
     zero_device_out(s, d_out, out_stride, len);
     return;
@@ -1611,6 +1854,10 @@ void rvc_set_process_host_blocks_timed(rvc_set *s, const float *const *in, float
 
 void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   if (!s) return;
+  if (!s->kids.empty()) {
+    for (size_t k = 0; k < s->kids.size(); ++k) rvc_set_process_begin(s->kids[k], in ? in + s->kid_c0[k] : nullptr, len);
+    return;
+  }
   s->pending_len = len;
   s->pending_ok = false;
   s->flag_count = 0;
@@ -1638,6 +1885,10 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
 
 void rvc_set_process_end(rvc_set *s, float *const *out) {
   if (!s || !out) return;
+  if (!s->kids.empty()) {
+    for (size_t k = 0; k < s->kids.size(); ++k) rvc_set_process_end(s->kids[k], out + s->kid_c0[k]);
+    return;
+  }
   const size_t len = s->pending_len;
   s->pending_len = 0;
   if (len == 0) return;
@@ -1696,7 +1947,9 @@ void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size
 }
 
 void rvc_set_clear(rvc_set *s) {
-  if (!s || !s->live) return;
+  if (!s) return;
+  for (rvc_set *k : s->kids) rvc_set_clear(k);
+  if (!s->live) return;
   // Outstanding tail jobs still write into rings; let them finish, then restart the clock.
   hipSetDevice(s->device);
   (void)pk_quiesce(s);
@@ -1713,24 +1966,30 @@ void rvc_set_clear(rvc_set *s) {
   s->xa_next = 0;
   s->w_next = 0;
   s->xt_valid_lo = 0;
-  s->sa_t0 = s->st_t0 = -1;
+  s->tA.drop(); s->tT.drop();
 }
 
 void rvc_set_reset(rvc_set *s) {
   if (!s) return;
+  drop_kids(s);
   free_device_state(s);
   s->err = RVC_OK;
   s->errstr.clear();
 }
 
 int rvc_set_is_finished(rvc_set *s) {
-  if (!s || !s->live) return 1;
+  if (!s) return 1;
+  for (rvc_set *k : s->kids)
+    if (!rvc_set_is_finished(k)) return 0;
+  if (!s->live) return 1;
   hipSetDevice(s->device);
   return hipStreamQuery(s->st_bg) == hipSuccess ? 1 : 0;
 }
 
 void rvc_set_sync(rvc_set *s) {
-  if (!s || !s->streams_ok) return;
+  if (!s) return;
+  for (rvc_set *k : s->kids) rvc_set_sync(k);
+  if (!s->streams_ok) return;
   hipSetDevice(s->device);
   (void)pk_quiesce(s);
   hipStreamSynchronize(s->st_bg);
@@ -1742,15 +2001,53 @@ size_t rvc_set_head_block(const rvc_set *s) { return s ? s->head : 0; }
 size_t rvc_set_tail_block(const rvc_set *s) { return s ? s->tail : 0; }
 size_t rvc_set_max_len(const rvc_set *s) { return s ? s->max_len : 0; }
 int rvc_set_partitions(const rvc_set *s, int stage) {
+  if (s && !s->kids.empty()) {          // (the largest over the children: channels may carry IRs of different lengths)
+    int p = 0;
+    for (const rvc_set *k : s->kids) p = std::max(p, rvc_set_partitions(k, stage));
+    return p;
+  }
   return !s ? 0 : (stage == 0 ? s->A.P : (stage == 1 ? s->T.P : s->W.P));
 }
-void *rvc_set_stream(rvc_set *s, int which) { return !s ? nullptr : (which == 0 ? (void *)s->st_main : (void *)s->st_bg); }
-int rvc_last_error(const rvc_set *s) { return s ? s->err : RVC_ERR_BAD_ARG; }
-const char *rvc_last_error_string(const rvc_set *s) { return s ? s->errstr.c_str() : "null handle"; }
+int rvc_set_tile_rows(const rvc_set *s, int stage) {
+  if (!s) return 0;
+  if (!s->kids.empty()) return rvc_set_tile_rows(s->kids[0], stage);
+  const Tile &t = stage == 0 ? s->tA : s->tT;
+  return (s->live && t.on) ? t.K1 : 0;
+}
+int rvc_set_subsets(const rvc_set *s) { return !s ? 0 : (s->kids.empty() ? 1 : (int)s->kids.size()); }
+void *rvc_set_stream(rvc_set *s, int which) {
+  if (!s || which < 0) return nullptr;
+  if (!s->kids.empty()) {               // child k's streams are 2 k (foreground) and 2 k + 1 (tail)
+    const size_t k = (size_t)which / 2;
+    return k < s->kids.size() ? rvc_set_stream(s->kids[k], which % 2) : nullptr;
+  }
+  return which == 0 ? (void *)s->st_main : (which == 1 ? (void *)s->st_bg : nullptr);
+}
+int rvc_last_error(const rvc_set *s) {
+  if (!s) return RVC_ERR_BAD_ARG;
+  for (const rvc_set *k : s->kids)
+    if (k->err != RVC_OK) return k->err;
+  return s->err;
+}
+const char *rvc_last_error_string(const rvc_set *s) {
+  if (!s) return "null handle";
+  for (const rvc_set *k : s->kids)
+    if (k->err != RVC_OK) return k->errstr.c_str();
+  return s->errstr.c_str();
+}
 
 long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms) {
   if (total_ms) *total_ms = 0.0;
   if (!s || kernel < 0 || kernel >= kNumKernelIds) return 0;
+  if (!s->kids.empty()) {
+    long n = 0;
+    for (rvc_set *k : s->kids) {
+      double ms = 0.0;
+      n += rvc_set_kernel_time(k, kernel, &ms);
+      if (total_ms) *total_ms += ms;
+    }
+    return n;
+  }
   rvc_set_sync(s);
   fold_timing(s, kernel);
   if (total_ms) *total_ms = s->timed_ms[kernel];
@@ -1759,12 +2056,15 @@ long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms) {
 
 void rvc_set_kernel_time_reset(rvc_set *s) {
   if (!s) return;
+  for (rvc_set *k : s->kids) rvc_set_kernel_time_reset(k);
   rvc_set_sync(s);
   drop_timing(s);
 }
 
 void rvc_set_timing(rvc_set *s, int enable) {
-  if (s) s->timing = enable != 0;
+  if (!s) return;
+  s->timing = enable != 0;
+  for (rvc_set *k : s->kids) k->timing = s->timing;
 }
 
 rvc_set *rvc_create(int device) { return rvc_set_create(1, device, RVC_FLAG_BG_STREAM); }
@@ -1842,7 +2142,7 @@ static int debug_fft(int device, size_t n, int f64, bool inverse, const float *i
   {
     rvc::FreeGuard guard;
     hipFree(d_t); hipFree(d_f);
-    free_stage(g);
+    free_stage(s, g);
   }
   rvc_set_destroy(s);
   return ok ? 1 : 0;
@@ -1855,22 +2155,6 @@ int rvc_debug_rfft(int device, size_t n, int f64, const float *data, float *re, 
 int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re, const float *im) {
   if (!data || !re || !im) return 0;
   return debug_fft(device, n, f64, true, nullptr, data, re, im, nullptr, nullptr);
-}
-
-// diagnostics: 100 MHz timestamps of the resident kernel's last step (doorbell seen, command fetched, accumulator
-// ready, done) and its sequence number
-int rvc_debug_persist_stamps(rvc_set *s, unsigned long long *out5) {
-  if (!s || !s->pk_ctl || !out5) return 0;
-  for (int i = 0; i < 5; ++i) out5[i] = s->pk_ctl->pad[i];
-  if (std::getenv("RVC_PK_PROFILE")) {
-    volatile unsigned long long *p = s->pk_ctl->pad;
-    fprintf(stderr, "pk stamps (us): tables+IR+acc+Xprev %.2f | tail stream %.2f | samples %.2f\n", (double)(p[5] - p[2]) / 100.0,
-            (double)(p[6] - p[5]) / 100.0, (double)(p[8] - p[6]) / 100.0);
-    fprintf(stderr, "pk stamps (us): cmd->loads done %.2f | fwd fft %.2f | split+mac+exchange %.2f | inv fft %.2f | epilogue+flag %.2f\n",
-            (double)(p[8] - p[2]) / 100.0, (double)(p[9] - p[8]) / 100.0, (double)(p[10] - p[9]) / 100.0,
-            (double)(p[11] - p[10]) / 100.0, (double)(p[3] - p[11]) / 100.0);
-  }
-  return 1;
 }
 
 // diagnostics: round trip of n empty commands through the resident kernel (median microseconds), -1 on failure
@@ -1895,6 +2179,43 @@ double rvc_debug_persist_rtt(rvc_set *s, int n) {
   }
   std::sort(us.begin(), us.end());
   return us[us.size() / 2];
+}
+
+long rvc_debug_guard_check(rvc_set *s) {
+  if (!s) return -1;
+  if (!s->kids.empty()) {
+    long bad = 0;
+    for (rvc_set *k : s->kids) {
+      const long b = rvc_debug_guard_check(k);
+      if (b < 0) return -1;
+      bad += b;
+    }
+    return bad;
+  }
+  if (s->guards.empty()) return g_tune.guard ? 0 : -1;
+  hipSetDevice(s->device);
+  rvc_set_sync(s);
+  std::vector<unsigned char> band(kGuardBytes);
+  long bad = 0;
+  for (const rvc_set::GuardRec &g : s->guards)
+    for (int side = 0; side < 2; ++side) {
+      const char *src = side == 0 ? g.base : g.base + kGuardBytes + g.bytes;
+      if (hipMemcpy(band.data(), src, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+      for (unsigned char v : band) bad += v != 0xFF;
+    }
+  return bad;
+}
+
+int rvc_debug_set_tuning(const char *key, int value) {
+  if (!key) return 0;
+  const std::string k(key);
+  if (k == "k1") g_tune.k1 = value;
+  else if (k == "sweep_split") rvc::set_sweep_tuning(value);
+  else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
+  else if (k == "subsets") g_tune.subsets = value;
+  else if (k == "guard") g_tune.guard = value;
+  else return 0;
+  return 1;
 }
 
 int rvc_device_count(void) {

@@ -63,6 +63,13 @@ struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency
   long long yadd_chan_stride;
   long long x_hi;           // sweep: input rows with index > x_hi have not arrived yet and read as zero
   unsigned y_row_mask;      // sweep: output row of block k0 + j is slot (k0 + j) & y_row_mask of Y
+  // Second-level sweep of the two-level tiling (rvc_internal.h, "Causal time tiling"): only the input rows
+  // x_from <= row <= x_hi count (the older ones are in the first-level rows already), and the first-level rows
+  // Ybase (slot (k0 + j) & ybase_row_mask, [channel][rows][B]) are added to the output.
+  long long x_from;         // sweep: input rows with index < x_from read as zero (0: every row since the clock started)
+  const float2 *Ybase;      // sweep: optional rows added to the output rows
+  long long ybase_chan_stride;
+  unsigned ybase_row_mask;
 };
 
 struct InvArgs {            // spectrum row(s) -> last B samples of the inverse transform (overlap-save)
@@ -153,6 +160,8 @@ void set_launch_events(hipEvent_t a, hipEvent_t b);
 void get_launch_events(hipEvent_t *a, hipEvent_t *b);   // (for launchers in other translation units)
 // one-off: raise the dynamic-LDS limit of the large FFT kernels
 hipError_t prepare_kernels();
+// measurement hook (rvc_debug_set_tuning "fft_loop"): -1 row-looping 8192-bin transforms by size, 0 never, 1 whenever legal
+void set_fft_loop_tuning(int mode);
 
 // ---- persistent block-synchronous kernel (RVC_FLAG_PERSISTENT) ------------------------------------------
 // One resident launch serves the plug-in's per-block calls: the host writes a command into a ring in pinned host
@@ -210,6 +219,7 @@ void free_guard_leave();
 struct FreeGuard { FreeGuard() { free_guard_enter(); } ~FreeGuard() { free_guard_leave(); } };
 bool persist_supported(int logB);
 int persist_workgroups(int logB, int channels, int *n_audio, int *patch_bx);
+int persist_capacity(int logB);   // workgroups of k_persist the current device holds at once (with a margin)
 hipError_t launch_persist(int logB, const PkArgs &a, int channels, hipStream_t st);
 
 // radix-8 kernels (logB >= 9): number of entries of their per-pass twiddle table, laid out as
@@ -220,14 +230,26 @@ int fft8_table_entries(int logB);
 // time-tile (output rows per thread) the FIR launcher will pick for M rows
 int fir_time_tile(int M);
 
-// Causal time tiling of the block-synchronous delay line. A "sweep" computes, for the kSweepRows output blocks
-// k0 .. k0 + kSweepRows - 1 at once, the part of  Y_k = sum_i H_i X_{k - delay - i}  whose input rows have already
-// arrived (index <= a.x_hi): every IR row and every delay-line row is read ONCE for kSweepRows blocks instead of once
+// Causal time tiling of the block-synchronous delay line. A "sweep" computes, for the a.M output blocks
+// k0 .. k0 + M - 1 at once, the part of  Y_k = sum_i H_i X_{k - delay - i}  whose input rows have already
+// arrived (index <= a.x_hi): every IR row and every delay-line row is read ONCE for M blocks instead of once
 // per block. What is missing from block k0 + j -- at most j (+ delay-dependent) recent rows -- is added when that
 // block is due (a single-row launch with FirArgs::Yadd = the sweep's row). Rows go to slot (k0 + j) & y_row_mask.
-constexpr int kSweepRows = 8;
+//
+// Two levels for long delay lines (P > kTwoLevelMinP partitions): with P partitions a tile of K blocks costs
+// (2 P + K) / K rows per block for the sweep and ~K + 1 for the patches -- for hundreds of partitions (BASELINE
+// config 3: 350 tail partitions) no single K is good. So a FIRST-level sweep covers K1 = 16 or 32 blocks (all
+// partitions, rows <= t0 - 2), every kSweepRows = 8 blocks inside that tile a SECOND-level sweep adds the rows that
+// arrived since the first-level sweep (at most K1 + 1 partitions: FirArgs::x_from / Ybase) for the next 8 blocks,
+// and the per-block patches still add at most 7 (+ 2 + lag) partitions: 2 P / K1 + K1 / 8 + 12 rows per block.
+constexpr int kSweepRows = 8;     // tile of the level the patches work on (second level, or the only one)
+constexpr int kSweepRowsMax = 32; // largest first-level tile
+constexpr int kTwoLevelMinP = 40; // below this many partitions one level of 8 blocks is as good (P / 4 + 10 rows per block)
 constexpr int kSweepLagMax = 3;   // a sweep may run up to this many blocks before its first row is due (x_hi that much older)
+// M = 8, 16 or 32 output rows
 hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st);
+// measurement hook (rvc_debug_set_tuning): "sweep_split" -1 auto / 0 own-tile form / 1 partition-split form
+void set_sweep_tuning(int split);
 
 // A prepared impulse as rvc_set_init_impulse sees it (rvc_impulse.hip): device pointers of the
 // prepared channels and their lengths with trailing |x| < 1e-6 dropped (TwoStageFFTConvolver.cpp:107-110).

@@ -29,36 +29,12 @@
 //    times per wave and 64 times per workgroup (k_fir_lds stages both operands in LDS).
 //  * The real split pairs bin k with bin B - k: through a wavefront shuffle (lane reversal) where a transform lives in one
 //    wave (blocks of 64 and 512), through LDS otherwise (WaveSplit / wave_partner).
-//  * RVC_ABLATE_* macros (development builds only, -DRVC_DEV_BUILD) knock out one ingredient of a kernel for the
-//    ablation measurements quoted in DESIGN.md; they produce wrong results by design.
+//  * The ablation / timestamp switches behind the measurements quoted in DESIGN.md are not in this file: they live in
+//    tools/dev/instrumentation.patch (apply to a scratch copy; they produce wrong results by design).
 #include "rvc_internal.h"
 #include "rvc_fft_lds.hpp"
 
-// The RVC_ABLATE_* / RVC_PHASE_TIMES measurement switches only exist in development builds
-// (-DRVC_DEV_BUILD, tools/abl_build.py): the shipped library cannot be built with one of them active.
-#if !defined(RVC_DEV_BUILD) && (defined(RVC_PHASE_TIMES) || defined(RVC_ABLATE_NOTW) || defined(RVC_ABLATE_NOBARRIER) || \
-    defined(RVC_ABLATE_CORE_NOLDS) || defined(RVC_ABLATE_FWD_STOP) || defined(RVC_ABLATE_FFT_NOLOAD) ||                   \
-    defined(RVC_ABLATE_FFT_NOCORE) || defined(RVC_ABLATE_FFT_NOSTORE) || defined(RVC_ABLATE_NOLOAD) ||                     \
-    defined(RVC_ABLATE_NOLDSREAD) || defined(RVC_ABLATE_NOSTORE))
-#error "measurement switches (RVC_ABLATE_*, RVC_PHASE_TIMES) need -DRVC_DEV_BUILD: they produce wrong results by design"
-#endif
 
-#ifdef RVC_PHASE_TIMES
-// Development instrumentation (tools/phase_times.py): thread 0 of a few workgroups stamps the shader clock
-// at phase boundaries of the big kernels. Waits are forced at the stamps, so the kernel is slower with it.
-__device__ unsigned long long g_phase[3][16][8];   // [kernel 0 fwd 1 fir 2 inv][sampled workgroup][stamp]
-#define RVC_STAMP(kern, i)                                                                       \
-  do {                                                                                           \
-    __builtin_amdgcn_s_waitcnt(0);                                                               \
-    if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x % 8) == 0 && blockIdx.x / 8 < 16)     \
-      g_phase[kern][blockIdx.x / 8][i] = __builtin_readcyclecounter();                          \
-  } while (0)
-extern "C" int rvc_debug_phase_times(unsigned long long *out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 3 * 16 * 8);
-}
-#else
-#define RVC_STAMP(kern, i) do {} while (0)
-#endif
 
 #include <hip/hip_ext.h>
 
@@ -315,10 +291,30 @@ __device__ __forceinline__ cx<R> wave_partner(const cx<R> *v, const int tid, con
 // Twiddles of one transform, per thread, in registers: they depend on the thread index only, so
 // they are requested at the top of the kernel -- before the input data has even arrived -- and the
 // passes never wait on a twiddle load. Forward and inverse share them (conjugated on use).
-template <int LOGB, typename R> struct Tw8 {
+// HELD (row-looping kernels of the big transforms, k_fft8_*_loop): the three twiddles per pass that fft8_core fetches for
+// a big transform (w^k, w^2k, w^4k; the other four are derived) and the final pass's are loaded ONCE per workgroup and
+// stay in registers for every row the workgroup transforms -- no twiddle traffic inside the loop at all.
+// INLDS: the pass twiddles are parked in the thread's own column of an LDS table ([slot][thread]: written and read by the
+// same thread, so no barrier) and read back one pass ahead -- for the inverse loop kernel, whose register budget they
+// do not fit in (a spilled twiddle is reloaded behind a wait for EVERY outstanding load, the row prefetch included).
+template <int LOGB, typename R, bool HELD_ = false, bool CONJ_ = false, bool INLDS_ = false> struct Tw8 {
   typedef Plan8<LOGB> P;
+  static constexpr bool HELD = HELD_;
+  static constexpr bool CONJ = CONJ_;   // HELD: held conjugated (the inverse kernel: no per-pass negation, no second copy)
+  static constexpr bool INLDS = INLDS_;
+  static constexpr int LDS_SLOTS = (P::N8 > 1 ? P::N8 - 1 : 0) * P::S * 3;
+  cx<R> *ltab = nullptr;     // INLDS: [LDS_SLOTS][NT]
   // eager (register) prefetch only where it fits the 128-VGPR budget of a 1024-thread workgroup
-  static constexpr bool EAGER = sizeof(R) == 4 ? (LOGB <= 12) : (LOGB <= 11);
+  static constexpr bool EAGER = !HELD_ && (sizeof(R) == 4 ? (LOGB <= 12) : (LOGB <= 11));
+  static constexpr int NH = (HELD_ && !INLDS_) ? (P::N8 > 1 ? P::N8 - 1 : 1) : 1;
+  // INLDS: the three twiddles of pass j, slot s
+  __device__ __forceinline__ void held_from_lds(const int j, const int s, cx<R> *w) const {
+    const cx<R> *col = ltab + ((j - 1) * P::S + s) * 3 * P::NT + tid_;
+    w[0] = col[0]; w[1] = col[P::NT]; w[2] = col[2 * P::NT];
+  }
+  static constexpr int NHQ = !HELD_ ? 1 : (P::Q == 4 ? 3 * (P::E / 4) : 1);
+  cx<R> h8[NH][P::S][3];     // HELD: w^k, w^2k, w^4k of radix-8 passes j = 1 .. N8-1
+  cx<R> hq[NHQ];             // HELD: final radix-2 / radix-4 pass
   static constexpr int NP = (EAGER && P::N8 > 1) ? P::N8 - 1 : 1;
   static constexpr int NQ = !EAGER ? 1 : (P::Q == 2 ? P::E / 2 : (P::Q == 4 ? (P::E / 4) * 3 : 1));
   cx<R> t8[NP][P::S][7];     // radix-8 passes j = 1 .. N8-1: w^{r k}, r = 1..7
@@ -327,6 +323,32 @@ template <int LOGB, typename R> struct Tw8 {
   int tid_;
   __device__ __forceinline__ void load(const cx<R> *__restrict__ tw8, const cx<R> *__restrict__ tw, const int tid) {
     p8 = tw8; p1 = tw; tid_ = tid;
+    if constexpr (HELD) {
+#pragma unroll
+      for (int j = 1; j < P::N8; ++j)
+#pragma unroll
+        for (int s = 0; s < P::S; ++s) {
+          const int pj = 1 << (3 * j);
+          const cx<R> *q = tw8 + P::off8(j) + ((tid + s * P::NT) & (pj - 1));
+          cx<R> w1 = q[pj], w2 = q[2 * pj], w4 = q[4 * pj];
+          if constexpr (CONJ) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; }
+          if constexpr (INLDS) {
+            cx<R> *col = ltab + ((j - 1) * P::S + s) * 3 * P::NT + tid;
+            col[0] = w1; col[P::NT] = w2; col[2 * P::NT] = w4;
+          } else {
+            h8[j - 1][s][0] = w1; h8[j - 1][s][1] = w2; h8[j - 1][s][2] = w4;
+          }
+        }
+      if constexpr (P::Q == 2) {
+        hq[0] = tw[tid];       // e^{-2 pi i (tid + jb NT) / B}: the others are a constant turn away (fft8_core)
+        if constexpr (CONJ) hq[0].y = -hq[0].y;
+      } else if constexpr (P::Q == 4) {
+#pragma unroll
+        for (int jb = 0; jb < P::E / 4; ++jb)
+#pragma unroll
+          for (int r = 1; r < 4; ++r) hq[jb * 3 + r - 1] = tw8[P::offq + r * (P::B / 4) + tid + jb * P::NT];
+      }
+    }
     if constexpr (EAGER) {
 #pragma unroll
       for (int j = 1; j < P::N8; ++j) {
@@ -354,17 +376,11 @@ template <int LOGB, typename R> struct Tw8 {
   }
   // twiddle of radix-8 pass j >= 1, butterfly slot s, leg r = 1..7
   __device__ __forceinline__ cx<R> w8(const int j, const int s, const int r) const {
-#ifdef RVC_ABLATE_NOTW
-    return mk<R>((R)(0.5f + 0.01f * r + 0.001f * (tid_ & 3)), (R)(0.25f * (s + 1) + 0.002f * j));
-#endif
     if constexpr (EAGER) return t8[j - 1][s][r - 1];
     else return p8[P::off8(j) + r * (1 << (3 * j)) + ((tid_ + s * P::NT) & ((1 << (3 * j)) - 1))];
   }
   // twiddle of the final pass: butterfly jb, leg r (radix-2: r = 1; radix-4: r = 1..3)
   __device__ __forceinline__ cx<R> wq(const int jb, const int r) const {
-#ifdef RVC_ABLATE_NOTW
-    return mk<R>((R)(0.5f + 0.01f * r + 0.001f * (tid_ & 3)), (R)(0.25f * (jb + 1)));
-#endif
     if constexpr (EAGER) return P::Q == 2 ? tq[jb] : tq[jb * 3 + r - 1];
     else return P::Q == 2 ? p1[tid_ + jb * P::NT] : p8[P::offq + r * (P::B / 4) + tid_ + jb * P::NT];
   }
@@ -376,7 +392,6 @@ template <int LOGB, typename R> struct Tw8 {
 // wave's LDS instructions execute in order, so the exchange needs no s_barrier -- only the compiler must not move the
 // reads above the writes (a workgroup barrier there would wait for the other waves).
 template <bool SOLO> __device__ __forceinline__ void core_sync() {
-#ifndef RVC_ABLATE_NOBARRIER
   if constexpr (SOLO) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -384,20 +399,14 @@ template <bool SOLO> __device__ __forceinline__ void core_sync() {
   } else {
     __syncthreads();
   }
-#endif
 }
-#define RVC_CORE_SYNC() core_sync<SOLO>()
-#ifdef RVC_ABLATE_CORE_NOLDS
-#define RVC_CORE_LDS(stmt) do {} while (0)
-#else
-#define RVC_CORE_LDS(stmt) stmt
-#endif
-template <int LOGB, bool INV, typename R, bool SOLO = false>
-__device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, R> &T, const int tid) {
+template <int LOGB, bool INV, typename R, bool SOLO = false, typename TW = Tw8<LOGB, R>>
+__device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const TW &T, const int tid) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
   constexpr bool kLin = P::kLin;
-  constexpr bool kEager = Tw8<LOGB, R>::EAGER;
+  constexpr bool kEager = TW::EAGER;
+  constexpr bool kHeld = TW::HELD;
   const int lt = lpad(tid);
   // Big transforms (B >= 8192) cannot hold all their twiddles in registers and fetch them from L2 per
   // pass. All waves of a workgroup reach a pass together (barriers), so a fetch issued where it is used
@@ -423,7 +432,28 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
         for (int r = 1; r < 4; ++r) tqn[jb * 3 + r - 1] = T.wq(jb, r);
     }
   };
-  if constexpr (!kEager) {
+  if constexpr (kHeld) {
+    if constexpr (P::Q == 2) {
+      static_assert(P::Q != 2 || (P::E / 2 == 4 && P::S == 1), "eighth turns below");
+      // butterfly jb's twiddle e^{-2 pi i (tid + jb NT) / B} = w0 e^{-i pi jb / 4}
+      // (held conjugated for the inverse: the turns are conjugated too)
+      const C w0 = T.hq[0];
+      const R h = (R)0.70710678118654752440;
+      tqn[0] = w0;
+      if constexpr (TW::CONJ) {
+        tqn[1 % NQW] = mk<R>(h * (w0.x - w0.y), h * (w0.y + w0.x));
+        tqn[2 % NQW] = mk<R>(-w0.y, w0.x);
+        tqn[3 % NQW] = mk<R>(-h * (w0.x + w0.y), h * (w0.x - w0.y));
+      } else {
+        tqn[1 % NQW] = mk<R>(h * (w0.x + w0.y), h * (w0.y - w0.x));
+        tqn[2 % NQW] = mk<R>(w0.y, -w0.x);
+        tqn[3 % NQW] = mk<R>(h * (w0.y - w0.x), -h * (w0.x + w0.y));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NQW; ++i) tqn[i] = T.hq[i];
+    }
+  } else if constexpr (!kEager) {
     if constexpr (P::N8 > 1) fetch8(1); else fetchq();
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -431,7 +461,21 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
   for (int j = 0; j < P::N8; ++j) {
     const int p = 1 << (3 * j);
     C cur[P::S][3];
-    if constexpr (!kEager) {
+    if constexpr (kHeld && TW::INLDS) {
+      if (j > 0) {
+#pragma unroll
+        for (int s = 0; s < P::S; ++s) { cur[s][0] = nxt[s][0]; cur[s][1] = nxt[s][1]; cur[s][2] = nxt[s][2]; }
+      }
+      if (j + 1 < P::N8) {           // the next pass's, read back now: the latency hides behind this pass
+#pragma unroll
+        for (int s = 0; s < P::S; ++s) T.held_from_lds(j + 1, s, nxt[s]);
+      }
+    } else if constexpr (kHeld) {
+      if (j > 0) {
+#pragma unroll
+        for (int s = 0; s < P::S; ++s) { cur[s][0] = T.h8[j - 1][s][0]; cur[s][1] = T.h8[j - 1][s][1]; cur[s][2] = T.h8[j - 1][s][2]; }
+      }
+    } else if constexpr (!kEager) {
       if (j > 0) {
 #pragma unroll
         for (int s = 0; s < P::S; ++s) { cur[s][0] = nxt[s][0]; cur[s][1] = nxt[s][1]; cur[s][2] = nxt[s][2]; }
@@ -454,7 +498,7 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
           // Fetch w^k, w^2k, w^4k only and build the other four with one complex multiply each: the seven
           // twiddles of a butterfly are more bytes than its data (twiddle error <= 2 roundings instead of 1).
           C w1 = cur[s][0], w2 = cur[s][1], w4 = cur[s][2];
-          if (INV) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; }
+          if (INV && !TW::CONJ) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; }
           const C w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4);
           const C w7 = cmul(w3, w4);
           a[1] = cmul(a[1], w1); a[2] = cmul(a[2], w2); a[3] = cmul(a[3], w3); a[4] = cmul(a[4], w4);
@@ -463,35 +507,29 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
       }
       dft8<R, INV>(a);
     }
-#ifdef RVC_PHASE_TIMES
-    if (!INV && LOGB == 14 && j < 4) RVC_STAMP(1, 2 * j);
-#endif
     const bool last8 = (j == P::N8 - 1);
     if (!(last8 && P::Q == 1)) {
-      if (j > 0) RVC_CORE_SYNC();               // previous exchange fully read before overwriting
+      if (j > 0) core_sync<SOLO>();               // previous exchange fully read before overwriting
 #pragma unroll
       for (int s = 0; s < P::S; ++s) {
         const int i = tid + s * P::NT;
         const int k = i & (p - 1);
         const int wb = lpad(((i - k) << 3) + k);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) RVC_CORE_LDS(lds[wb + lpad_leg(p, r)] = v[8 * s + r]);
+        for (int r = 0; r < 8; ++r) lds[wb + lpad_leg(p, r)] = v[8 * s + r];
       }
-      RVC_CORE_SYNC();
+      core_sync<SOLO>();
       if (!last8) {
 #pragma unroll
         for (int s = 0; s < P::S; ++s) {
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
-            if constexpr (kLin) RVC_CORE_LDS(v[8 * s + r] = lds[lt + lpad_c(s * P::NT + r * P::T)]);
-            else RVC_CORE_LDS(v[8 * s + r] = lds[lpad(tid + s * P::NT + r * P::T)]);
+            if constexpr (kLin) v[8 * s + r] = lds[lt + lpad_c(s * P::NT + r * P::T)];
+            else v[8 * s + r] = lds[lpad(tid + s * P::NT + r * P::T)];
           }
         }
       }
     }
-#ifdef RVC_PHASE_TIMES
-    if (!INV && LOGB == 14 && j < 4) RVC_STAMP(1, 2 * j + 1);
-#endif
   }
   if constexpr (P::Q > 1) {                      // final radix-2 / radix-4 pass, p = B/Q, k = i
     constexpr int NBF = P::E / P::Q;
@@ -502,12 +540,12 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const Tw8<LOGB, 
       C *b = v + jb * P::Q;
 #pragma unroll
       for (int r = 0; r < P::Q; ++r) {
-        if constexpr (kLin) RVC_CORE_LDS(b[r] = lds[lt + lpad_c(jb * P::NT + r * ST)]);
-        else RVC_CORE_LDS(b[r] = lds[lpad(i + r * ST)]);
+        if constexpr (kLin) b[r] = lds[lt + lpad_c(jb * P::NT + r * ST)];
+        else b[r] = lds[lpad(i + r * ST)];
       }
       if constexpr (P::Q == 2) {
         C w = kEager ? T.wq(jb, 1) : tqn[jb];    // e^{-2 pi i k / B}
-        if (INV) w.y = -w.y;
+        if (INV && !TW::CONJ) w.y = -w.y;
         const C x1 = cmul(b[1], w);
         const C x0 = b[0];
         b[0] = cadd(x0, x1); b[1] = csub(x0, x1);
@@ -554,10 +592,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   const C *tw8 = reinterpret_cast<const C *>(a.tw8);
   const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
 
-  RVC_STAMP(0, 0);
-#if defined(RVC_ABLATE_FWD_STOP) && RVC_ABLATE_FWD_STOP == 0
-  if (a.rows > 0) return;
-#endif
   Tw8<LOGB, R> T;
   T.load(tw8, tw, tid);
   C v[P::E];
@@ -589,11 +623,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       const unsigned m = (unsigned)P::in_idx(tid, e);
-#ifdef RVC_ABLATE_FFT_NOLOAD
-      const float2 x = make_float2(1e-3f * (float)(m & 1023), (float)(m & 7) + (b0 == nullptr ? 1.f : 0.f));
-#else
       const float2 x = ((e & 7) < 4 ? b0 : b1)[m];
-#endif
       v[e] = mk<R>((R)x.x, (R)x.y);
       if ((e & 7) >= 4 && keep_hist) {
         const long long n = seg + 2 * (long long)m;
@@ -642,18 +672,8 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
     for (int e = 0; e < P::E; ++e)
       if (P::out_is_low(e)) ws[q++] = wsplit[(unsigned)P::out_idx(tid, e)];
   };
-#if defined(RVC_ABLATE_FWD_STOP) && RVC_ABLATE_FWD_STOP == 1
-  if (a.rows > 0) { if (v[0].x == (R)12345.678) a.dst[0] = make_float2((float)v[1].x, (float)v[P::E - 1].y); return; }
-#endif
   load_ws();   // requested before the transform: the latency hides behind it
-  RVC_STAMP(0, 1);
-#ifndef RVC_ABLATE_FFT_NOCORE
   fft8_core<LOGB, false, R>(v, lds, T, tid);
-#endif
-  RVC_STAMP(0, 2);
-#if defined(RVC_ABLATE_FWD_STOP) && RVC_ABLATE_FWD_STOP == 2
-  if (a.rows > 0) { if (v[0].x == (R)12345.678) a.dst[0] = make_float2((float)v[1].x + (float)ws[0].x, (float)v[P::E - 1].y); return; }
-#endif
 
   constexpr bool kLin = P::kLin;
   const int lt = lpad(tid), ln = lpad_neg(tid);
@@ -667,7 +687,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
 #pragma unroll
     for (int e = 0; e < P::E; ++e)
       if (P::out_is_low(e)) Zp[q++] = wave_partner<LOGB, R>(v, tid, e);
-    RVC_STAMP(0, 3);
     if (!live) return;
   } else {
   __syncthreads();
@@ -678,10 +697,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
       else lds[lpad(P::out_idx(tid, e))] = v[e];
     }
   __syncthreads();
-  RVC_STAMP(0, 3);
-#if defined(RVC_ABLATE_FWD_STOP) && RVC_ABLATE_FWD_STOP == 3
-  if (a.rows > 0) { if (v[0].x == (R)12345.678) a.dst[0] = make_float2((float)v[1].x + (float)ws[0].x, (float)v[P::E - 1].y); return; }
-#endif
   if (!live) return;                                   // (after the last barrier)
   // all partner reads first (back to back, one wait), then the arithmetic. k == 0 exists only for
   // (tid, e) = (0, 0); its partner slot is redirected to a valid address and its result replaced below.
@@ -703,9 +718,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   for (int e = 0; e < P::E; ++e) {
     const unsigned k = (unsigned)P::out_idx(tid, e);
     const C A = v[e];
-#ifdef RVC_ABLATE_FFT_NOSTORE
-    if (A.x != (R)12345.678) continue;
-#endif
     if (P::out_is_low(e)) {
       const C w = ws[q];
       const C Bc = cconj(Zp[q]);                       // conj Z[B - k]
@@ -723,7 +735,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
       dst[k] = make_float2((float)A.x, (float)-A.y);   // X[B/2] = conj(Z[B/2]) (its own partner)
     }
   }
-  RVC_STAMP(0, 4);
 }
 
 template <int LOGB, typename R>
@@ -749,7 +760,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   // thread's indices are "low" (k < B/2). For each low k it loads Y[k], Y[B-k] and one twiddle and
   // forms BOTH Z[k] = E + iO (kept) and Z[B-k] = conj(E) + i conj(O) (handed to its owner through
   // LDS). One exchange instead of loading every Y twice and every twiddle once per bin.
-  RVC_STAMP(2, 0);
   Tw8<LOGB, R> T;
   T.load(tw8, tw, tid);
   C v[P::E];
@@ -762,11 +772,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   for (int e = 0; e < P::E; ++e) {
     if ((e & 7) < 4) {                                   // in_idx(tid, e) < B/2
       const unsigned k = (unsigned)P::in_idx(tid, e);
-#ifdef RVC_ABLATE_FFT_NOLOAD
-      const float2 yk = make_float2(1e-3f * (float)(k & 1023), (float)(k & 7) + (Y == nullptr ? 1.f : 0.f));
-#else
       const float2 yk = Y[k];
-#endif
       if (k == 0) {
         v[e] = mk<R>(sc * ((R)yk.x + (R)yk.y), sc * ((R)yk.x - (R)yk.y));
         const float2 yh = Y[B / 2];                      // and the self-paired bin B/2: Z = conj(Y) / B
@@ -774,11 +780,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
         if constexpr (WaveSplit<LOGB>::ok) zcs[e & 3] = zhalf;
         else lds[lpad(B / 2)] = zhalf;
       } else {
-#ifdef RVC_ABLATE_FFT_NOLOAD
-        const float2 yc = make_float2(2e-3f * (float)(k & 511), (float)(k & 3));
-#else
         const float2 yc = Y[(unsigned)B - k];
-#endif
         const C Yk = mk<R>((R)yk.x, (R)yk.y), Yc = mk<R>((R)yc.x, -(R)yc.y);
         const C Ev = mk<R>(sc * (Yk.x + Yc.x), sc * (Yk.y + Yc.y));
         const C D = mk<R>(sc * (Yk.x - Yc.x), sc * (Yk.y - Yc.y));
@@ -812,11 +814,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
     }
   __syncthreads();                                       // the transform's first exchange overwrites the buffer
   }
-  RVC_STAMP(2, 1);
-#ifndef RVC_ABLATE_FFT_NOCORE
   fft8_core<LOGB, true, R>(v, lds, T, tid);
-#endif
-  RVC_STAMP(2, 2);
 
   // z[m] = (s[2m], s[2m+1]); the overlap-save output is s[B..2B) = z[B/2..B): 8-byte stores
   float *dst = a.dst + (long long)c * a.dst_chan_stride;
@@ -839,23 +837,16 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
     for (int e = 0; e < P::E; ++e) {
       if (!P::out_is_low(e)) {
         const unsigned m = (unsigned)P::out_idx(tid, e);
-#ifdef RVC_ABLATE_FFT_NOSTORE
-        if (v[e].x != (R)12345.678) continue;
-#endif
         float2 o = make_float2((float)v[e].x, (float)v[e].y);
         if (ab) { const float2 t = ab[m]; o.x += t.x; o.y += t.y; }
         ob[m] = o;
       }
     }
-    RVC_STAMP(2, 3);
     return;
   }
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int m = P::out_idx(tid, e);
-#ifdef RVC_ABLATE_FFT_NOSTORE
-    if (v[e].x != (R)12345.678) continue;
-#endif
     if (m >= B / 2) {
       const int p0 = 2 * m - B;
       const long long n = nblk + p0;
@@ -887,6 +878,215 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
         if (n + 1 >= a.lo && n + 1 < a.hi) dst[(unsigned long long)(n + 1 - a.dst_origin) & a.dst_mask] = t1;
       }
     }
+  }
+}
+
+// e^{-i pi q / 8}, q = 0 .. 3 (compile-time after unrolling)
+template <typename R> __device__ __forceinline__ cx<R> eighth_turn(const int q) {
+  return q == 0 ? mk<R>((R)1, (R)0)
+       : q == 1 ? mk<R>((R)0.92387953251128675613, (R)-0.38268343236508977173)
+       : q == 2 ? mk<R>((R)0.70710678118654752440, (R)-0.70710678118654752440)
+                : mk<R>((R)0.38268343236508977173, (R)-0.92387953251128675613);
+}
+
+// ----------------------------------------------------------------------------------------
+// Row-looping forms of the big transforms (B = 8192: every BASELINE configuration's tail block) for launches of many rows
+// -- the tail jobs of many lock-step channels. One row per workgroup, as k_fft8_fwd / _inv launch them, leaves every
+// workgroup of a round in the same phase: all of them load, then all of them run their barrier-separated passes, then all
+// of them store -- memory and LDS / VALU take turns (measured with 4096 rows: 3.3 / 3.9 TB/s although the kernels move
+// exactly their bytes). Here a workgroup STAYS and loops over rows: the loads of row i+1 are requested before the passes
+// of row i start (16 more registers; the workgroup is alone on its CU anyway once it holds them) and the stores of row i
+// drain under the passes of row i+1; the twiddles are loaded once per workgroup and held in registers (Tw8 HELD) -- the
+// loop body touches memory for samples and spectra only. Launched only when every row is a whole one (launch_fft_fwd /
+// _inv check: no zero padding, no validity window cutting a row, no second source), everything else keeps the one-row form.
+// grid = workgroups the device holds at once (fft_loop_workgroups), item = row + rows * channel, strided over the grid.
+// ----------------------------------------------------------------------------------------
+// (All global addresses inside the loops are a wave-uniform pointer -- scalar registers, recomputed per row for free --
+//  plus ONE of two per-thread byte offsets, 8 * tid and 8 * (NT - 1 - tid), plus a compile-time constant: per-value
+//  64-bit address registers would be hoisted out of the row loop, outgrow the 128-register budget of a 1024-thread
+//  workgroup and spill -- and a spill reload waits for EVERY load in flight, the prefetch included.)
+// (the empty asm pins base + constant into a scalar register pair: left alone, the compiler re-associates to
+//  base + (constant + offset) and hoists one 64-bit VGPR pair per constant out of the loop -- exactly the registers
+//  this is meant to save)
+__device__ __forceinline__ float2 ldg_u(const void *ubase, const long long const_bytes, const unsigned voff) {
+  const char *b = reinterpret_cast<const char *>(ubase) + const_bytes;
+  asm volatile("" : "+s"(b));
+  return *reinterpret_cast<const float2 *>(b + voff);
+}
+__device__ __forceinline__ void stg_u(void *ubase, const long long const_bytes, const unsigned voff, const float2 v) {
+  char *b = reinterpret_cast<char *>(ubase) + const_bytes;
+  asm volatile("" : "+s"(b));
+  *reinterpret_cast<float2 *>(b + voff) = v;
+}
+
+template <int LOGB>
+__global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd_loop(const FwdArgs a, const int items) {
+  typedef Plan8<LOGB> P;
+  typedef float R;
+  typedef cx<R> C;
+  static_assert(P::TPW == 1 && P::S == 1 && P::Q == 2 && P::E == 8 && !WaveSplit<LOGB>::ok, "big single-transform workgroups only");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int B = P::B, NT = P::NT;
+  const int tid = threadIdx.x;
+  const unsigned up = (unsigned)tid * 8u, down = (unsigned)(NT - 1 - tid) * 8u;
+  C *lds = reinterpret_cast<C *>(smem_raw);
+  Tw8<LOGB, R, true> T;
+  T.load(reinterpret_cast<const C *>(a.tw8), reinterpret_cast<const C *>(a.tw), tid);
+  // split twiddles e^{-i pi k / B} of the thread's low bins k = tid + q * B/8: one held, the others a constant turn away
+  const C ws0 = reinterpret_cast<const C *>(a.wsplit)[tid];
+  constexpr bool kLin = P::kLin;
+  const int lt = lpad(tid), ln = lpad_neg(tid);
+  // z[m] = (x[2m], x[2m+1]), m = in_idx(tid, e) = tid + e * NT. Both halves of a row's segment (block k-1 | block k) lie
+  // contiguously in the ring (block-aligned, power-of-two ring): values e < 4 come from the first, e >= 4 from the second.
+  auto request = [&](const int item, float2 *x) {
+    const int c = __builtin_amdgcn_readfirstlane(item / a.rows);   // (integer division runs on the vector ALU:
+    const int r_ = item - c * a.rows;                             //  tell the compiler the result is wave-uniform)
+    const float *src = a.src + (long long)c * a.src_chan_stride;
+    const long long seg = a.seg0 + (long long)r_ * B;
+    const float *h0 = src + ((unsigned long long)seg & a.src_mask), *h1 = src + ((unsigned long long)(seg + B) & a.src_mask);
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) x[e] = ldg_u(e < 4 ? h0 : h1, (long long)(e & 3) * NT * 8, up);
+  };
+  float2 x[P::E];
+  int item = blockIdx.x;
+  if (item < items) request(item, x);
+#pragma unroll 1
+  for (; item < items; item += gridDim.x) {
+    C v[P::E];
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) v[e] = mk<R>(x[e].x, x[e].y);
+    __builtin_amdgcn_sched_barrier(0);
+    const int next = item + gridDim.x;
+    if (next < items) request(next, x);                      // in flight during this row's passes
+    __builtin_amdgcn_sched_barrier(0);
+    fft8_core<LOGB, false, R, false, Tw8<LOGB, R, true>>(v, lds, T, tid);
+    // real split in pairs (see k_fft8_fwd): the high half goes through LDS to the thread that holds the partner
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < P::E; ++e)
+      if (!P::out_is_low(e)) {
+        if constexpr (kLin) lds[lt + lpad_c(P::out_c(e))] = v[e];
+        else lds[lpad(P::out_idx(tid, e))] = v[e];
+      }
+    __syncthreads();
+    C Zp[P::E / 2];
+    {
+      int q = 0;
+#pragma unroll
+      for (int e = 0; e < P::E; ++e)
+        if (P::out_is_low(e)) {
+          int idx;
+          if constexpr (kLin) idx = ln + lpad_c(B - P::out_c(e));
+          else idx = lpad(B - P::out_idx(tid, e));
+          if (e == 0) idx = tid == 0 ? lpad(B / 2) : idx;
+          Zp[q++] = lds[idx];
+        }
+    }
+    const int c = __builtin_amdgcn_readfirstlane(item / a.rows);   // (integer division runs on the vector ALU:
+    const int r_ = item - c * a.rows;                             //  tell the compiler the result is wave-uniform)
+    float2 *drow = a.dst + (long long)c * a.dst_chan_stride + (long long)(((unsigned long long)(a.row0 + r_)) & a.row_mask) * B;
+    // low bins k = tid + q NT (values e = 2q) and their mirrors B - k = (B - q NT - (NT - 1)) + (NT - 1 - tid)
+#pragma unroll
+    for (int q = 0; q < P::E / 2; ++q) {
+      const C A = v[2 * q];
+      const C w = cmul(ws0, eighth_turn<R>(q));
+      const C Bc = cconj(Zp[q]);
+      const C Ev = mk<R>(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
+      const C D = mk<R>(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
+      const C wO = cmul(w, mk<R>(D.y, -D.x));
+      float2 x0 = make_float2(Ev.x + wO.x, Ev.y + wO.y);
+      const float2 x1 = make_float2(Ev.x - wO.x, wO.y - Ev.y);
+      const bool dc = (q == 0) && tid == 0;
+      if (dc) x0 = make_float2(A.x + A.y, A.x - A.y);          // packed (DC, Nyquist)
+      stg_u(drow, (long long)q * NT * 8, up, x0);
+      if (!dc) stg_u(drow, (long long)(B - q * NT - (NT - 1)) * 8, down, x1);
+    }
+    if (tid == 0) drow[B / 2] = make_float2(v[1].x, -v[1].y);  // X[B/2] = conj(Z[B/2]): value e = 1 of thread 0
+    __syncthreads();                                          // the next row's first exchange overwrites the buffer
+  }
+}
+
+template <int LOGB>
+__global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv_loop(const InvArgs a, const int items) {
+  typedef Plan8<LOGB> P;
+  typedef float R;
+  typedef cx<R> C;
+  static_assert(P::TPW == 1 && P::S == 1 && P::Q == 2 && P::E == 8 && !WaveSplit<LOGB>::ok, "big single-transform workgroups only");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int B = P::B, NT = P::NT;
+  const int tid = threadIdx.x;
+  const unsigned up = (unsigned)tid * 8u, down = (unsigned)(NT - 1 - tid) * 8u;
+  // mirrors of the bins k = tid (q = 0), counted from bin B/2: B - tid = B/2 + (B/2 - tid). Thread 0's bin 0 is the packed
+  // (DC, Nyquist) one and pairs with nothing: that slot fetches the self-paired bin B/2 itself
+  const unsigned down0 = tid == 0 ? 0u : (unsigned)(B / 2 - tid) * 8u;
+  C *lds = reinterpret_cast<C *>(smem_raw);
+  Tw8<LOGB, R, true, true, true> T;
+  T.ltab = lds + P::LDS_ELEMS;                                 // (behind the exchange buffer: fft_loop_lds_bytes)
+  T.load(reinterpret_cast<const C *>(a.tw8), reinterpret_cast<const C *>(a.tw), tid);
+  const C ws0 = reinterpret_cast<const C *>(a.wsplit)[tid];    // (see k_fft8_fwd_loop)
+  constexpr bool kLin = P::kLin;
+  const int lt = lpad(tid), ln = lpad_neg(tid);
+  const R sc = (R)0.5 / (R)B;
+  static_assert((1 << LOGB) / 2 >= Plan8<LOGB>::NT, "down0 is a non-negative offset");
+  // a thread's low bins k = tid + q NT (values e = q < 4) and their mirrors B - k
+  auto request = [&](const int item, float2 *yk, float2 *yc) {
+    const int c = __builtin_amdgcn_readfirstlane(item / a.rows);   // (integer division runs on the vector ALU:
+    const int r_ = item - c * a.rows;                             //  tell the compiler the result is wave-uniform)
+    const float2 *Y = a.Y + (long long)c * a.y_chan_stride + (long long)r_ * B;
+#pragma unroll
+    for (int q = 0; q < P::E / 2; ++q) {
+      yk[q] = ldg_u(Y, (long long)q * NT * 8, up);
+      yc[q] = q == 0 ? ldg_u(Y, (long long)(B / 2) * 8, down0) : ldg_u(Y, (long long)(B - q * NT - (NT - 1)) * 8, down);
+    }
+  };
+  float2 yk[P::E / 2], yc[P::E / 2];
+  int item = blockIdx.x;
+  if (item < items) request(item, yk, yc);
+#pragma unroll 1
+  for (; item < items; item += gridDim.x) {
+    C v[P::E];
+#pragma unroll
+    for (int q = 0; q < P::E / 2; ++q) {
+      const float2 a0 = yk[q], a1 = yc[q];
+      const C Yk = mk<R>(a0.x, a0.y), Yc = mk<R>(a1.x, -a1.y);
+      const C Ev = mk<R>(sc * (Yk.x + Yc.x), sc * (Yk.y + Yc.y));
+      const C D = mk<R>(sc * (Yk.x - Yc.x), sc * (Yk.y - Yc.y));
+      const C O = cmul(cconj(cmul(ws0, eighth_turn<R>(q))), D);
+      C zk = mk<R>(Ev.x - O.y, Ev.y + O.x);                               // Z[k]   = E + iO
+      C zc = mk<R>(Ev.x + O.y, O.x - Ev.y);                               // Z[B-k] = conj(E) + i conj(O)
+      int zi;
+      if constexpr (kLin) zi = ln + lpad_c(B - P::in_c(q));
+      else zi = lpad(B - P::in_idx(tid, q));
+      if (q == 0) {      // thread 0: the packed bin (DC, Nyquist), and in the partner slot Z[B/2] = conj(Y[B/2]) / B (selects)
+        const bool pk = tid == 0;
+        zk = pk ? mk<R>(sc * (a0.x + a0.y), sc * (a0.x - a0.y)) : zk;
+        zc = pk ? mk<R>(2.f * sc * a1.x, -2.f * sc * a1.y) : zc;
+        zi = pk ? lpad(B / 2) : zi;
+      }
+      v[q] = zk;
+      lds[zi] = zc;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int next = item + gridDim.x;
+    if (next < items) request(next, yk, yc);                  // in flight during this row's passes
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+#pragma unroll
+    for (int e = 4; e < P::E; ++e) {
+      if constexpr (kLin) v[e] = lds[lt + lpad_c(P::in_c(e))];
+      else v[e] = lds[lpad(P::in_idx(tid, e))];
+    }
+    __syncthreads();
+    fft8_core<LOGB, true, R, false, Tw8<LOGB, R, true, true, true>>(v, lds, T, tid);
+    // the block's samples: z[B/2 .. B) as sample pairs = values e odd, z index B/2 + tid + (e/2) NT: one contiguous
+    // 8-byte aligned run of the destination ring
+    const int c = __builtin_amdgcn_readfirstlane(item / a.rows);   // (integer division runs on the vector ALU:
+    const int r_ = item - c * a.rows;                             //  tell the compiler the result is wave-uniform)
+    const long long nblk = (a.blk0 + r_) * (long long)B;
+    float *blk = a.dst + (long long)c * a.dst_chan_stride + ((unsigned long long)(nblk - a.dst_origin) & a.dst_mask);
+#pragma unroll
+    for (int e = 1; e < P::E; e += 2) stg_u(blk, (long long)(e / 2) * NT * 8, up, make_float2(v[e].x, v[e].y));
+    __syncthreads();
   }
 }
 
@@ -935,25 +1135,12 @@ __device__ __forceinline__ void xk_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, kXkAux);
 }
 
-#if defined(RVC_DEV_BUILD) && defined(RVC_BLOCK_STAMPS)
-// development builds: per-workgroup timestamps of the LAST one-block launch (tools/block_stamps.py)
-__device__ unsigned long long g_block_stamps[4096 * 16];
-extern "C" int rvc_debug_block_stamps(unsigned long long *out, int n) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 1 : 0;
-}
-#define RVC_AUDIO_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (!PK && (threadIdx.x & 63) == 0 && wg < 4096) g_block_stamps[wg * 16 + (i)] = (unsigned long long)wall_clock64(); } while (0)
-#elif defined(RVC_PK_STAMPS)
-#define RVC_AUDIO_STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); if (PK && a.dbg && wg == 0 && threadIdx.x == 0) a.dbg[i] = (unsigned long long)wall_clock64(); } while (0)
-#else
-#define RVC_AUDIO_STAMP(i) do {} while (0)
-#endif
 template <int LOGB, bool FOLD, bool PK = false, bool SOLO = false>
 __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, const int wg) {
-  static_assert(!SOLO || (WaveSplit<LOGB>::ok && Plan8<LOGB>::WG == 64), "SOLO: the whole transform in one wave");
+  static_assert(!SOLO || Plan8<LOGB>::WG == 64, "SOLO: the workgroup's transform(s) live in one wave");
   typedef Plan8<LOGB> P;
   typedef cx<float> C;
   constexpr int B = P::B;
-  RVC_AUDIO_STAMP(4);
   const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;
   C *lds = reinterpret_cast<C *>(smem_raw) + sub * P::LDS_ELEMS;
   const int c_raw = wg * P::TPW + sub;
@@ -993,7 +1180,6 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       xp[e] = Xp[P::out_idx(tid, e)];
     }
   }
-  RVC_AUDIO_STAMP(5);       // (everything requested so far has arrived: twiddles, IR rows, accumulator, previous spectrum)
   // 1. load the segment: history from the ring, this call's samples from `in` (and append them
   //    to the ring), zero for the not-yet-played rest of block k and for time < 0
   // (persistent kernel: calls on even sample positions with 8-byte aligned buffers move sample PAIRS per access. Single
@@ -1030,7 +1216,6 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
         }
     }
   }
-  RVC_AUDIO_STAMP(6);       // (+ the tail stream)
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     // unconditional loads from an always legal address, then selects: loads under a branch would be
@@ -1098,9 +1283,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   }
   // 2. forward transform, real split; X_k goes to the delay line and, times H0 plus the
   //    pre-multiplied accumulator, becomes Y_k
-  RVC_AUDIO_STAMP(8);
   fft8_core<LOGB, false, float, SOLO>(v, lds, T, tid);
-  RVC_AUDIO_STAMP(9);
   // The real split pairs bin k with bin B - k. Head blocks of 64 / 512: the whole transform lives in one wave and the
   // partner arrives through a lane reversal (wave_partner: ds_bpermute, no LDS round trip, no barrier); else through LDS.
   constexpr bool kWS = WaveSplit<LOGB>::ok;
@@ -1109,10 +1292,10 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
 #pragma unroll
     for (int e = 0; e < P::E; ++e) part[e] = wave_partner<LOGB, float>(v, tid, e);
   } else {
-    __syncthreads();
+    core_sync<SOLO>();
 #pragma unroll
     for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = v[e];
-    __syncthreads();
+    core_sync<SOLO>();
   }
   float2 *Xrow = a.Xrow + (long long)c * a.x_chan_stride + (long long)((unsigned long long)a.k & a.x_row_mask) * B;
   C y[P::E];
@@ -1146,10 +1329,10 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
 #pragma unroll
     for (int e = 0; e < P::E; ++e) part[e] = wave_partner<LOGB, float>(y, tid, e);
   } else {
-    __syncthreads();
+    core_sync<SOLO>();
 #pragma unroll
     for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = y[e];
-    __syncthreads();
+    core_sync<SOLO>();
   }
   const float sc = 0.5f / (float)B;
 #pragma unroll
@@ -1170,10 +1353,8 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       v[e] = mk<float>(Ev.x - O.y, Ev.y + O.x);
     }
   }
-  if constexpr (!kWS) __syncthreads();
-  RVC_AUDIO_STAMP(10);
+  if constexpr (!kWS) core_sync<SOLO>();
   fft8_core<LOGB, true, float, SOLO>(v, lds, T, tid);
-  RVC_AUDIO_STAMP(11);
   // 4. the block's samples are z[B/2 .. B); only [n0, n1) is wanted; add the tail contribution
   float *out = a.out + (long long)c * a.out_chan_stride;
   const float *add = a.add ? a.add + (long long)c * a.add_chan_stride : nullptr;
@@ -1224,7 +1405,6 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       }
     }
   }
-  RVC_AUDIO_STAMP(12);
   if (a.done_flag) {   // output is in (host-visible) memory: tell the polling host, do not make it wait for kernel end
     if constexpr (PK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores: landed when acknowledged
     else __threadfence_system();
@@ -1378,17 +1558,11 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
   // cooperative loader: thread -> (row lr of a group of 8, bins lc, lc+1), 16 bytes
   const int lr = tid >> 5, lc = (tid & 31) * 2;
   auto gX = [&](long long row) -> float4 {               // rows before time 0 are zero
-#ifdef RVC_ABLATE_NOLOAD
-    return make_float4((float)row, 1.f, 2.f, 3.f);
-#endif
     const long long rr = row < 0 ? 0 : row;
     const float4 v = *reinterpret_cast<const float4 *>(Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B + lc);
     return row >= 0 ? v : zero4;
   };
   auto gH = [&](int i) -> float4 {                        // clamped: rows >= P are never used
-#ifdef RVC_ABLATE_NOLOAD
-    return make_float4((float)i, 1.f, 2.f, 3.f);
-#endif
     const int ii = i < P ? i : P - 1;
     return *reinterpret_cast<const float4 *>(Hc + (long long)ii * B + lc);
   };
@@ -1443,12 +1617,8 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
     // rows cbase-8j-1-u, u = 0..7, are slots g*8 + (7-u) of group g = (2*wave - j) & 7
     const float2 *xgrp = &sX[((2 * wave - j) & 7) * CH][0] + lane;
     auto operands = [&](const int u, float2 &hh, float2 &xin) {
-#ifdef RVC_ABLATE_NOLDSREAD
-      hh = make_float2(1.f + u, 0.5f); xin = make_float2(0.25f * u, 1.f);
-#else
       hh = sH[PH][u][lane];
       xin = xgrp[(CH - 1 - u) * 64];
-#endif
     };
     auto fmas = [&](const float2 hh, const float2 xin, const int u16) {
       // (h.re, h3, hz): ordinary bin (re, re, im); packed bin 0 (DC gain, Nyquist gain, 0)
@@ -1487,11 +1657,7 @@ __global__ void __launch_bounds__(256, 4) k_fir_lds(const FirArgs a) {
     if (j + 1 < nchunks) chunk(j + 1, std::integral_constant<int, 1>{});
   }
 
-#ifdef RVC_ABLATE_NOSTORE
-  if (t0 < a.M && acc[0].x == 123.456f) {
-#else
   if (t0 < a.M) {
-#endif
     float2 *Y = a.Y + (long long)c * a.y_chan_stride + t0 * B + bin;
 #pragma unroll
     for (int t = 0; t < TK; ++t)
@@ -1662,20 +1828,34 @@ k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int 
   }
 }
 
-// The same patch by ONE wave for a whole 512-entry row (head block 512): 4 x (64 lanes x 2 bins) per row, the partitions
-// in rounds of three (24 requests of 16 bytes per lane in flight).
-__device__ __forceinline__ void fdl_patch_wave512(const FirArgs &a, const int c) {
+// The same patch by ONE wave for the channel(s) of one audio workgroup (head blocks of 128 / 256 / 512: 4 / 2 / 1 channels
+// per workgroup, 512 row entries in all): 4 x (64 lanes x 2 bins), the partitions in rounds of three (24 requests of
+// 16 bytes per lane in flight).
+template <int LOGB>
+__device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, const int channels) {
+  typedef Plan8<LOGB> P8;
+  static_assert(P8::B * P8::TPW == 512 && P8::B >= 128, "one wave patches 512 row entries");
   constexpr int NQ = 4, CH = 3;
+  constexpr int QPC = P8::B / 128;                        // 128-bin pieces per channel
   const int lane = (int)threadIdx.x & 63;
   const long long B = a.B;
-  const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride + lane * 2;
-  const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride + lane * 2;
   const long long cbase = a.k0 - a.delay;
+  // piece q: channel wg * TPW + q / QPC (clamped: a dead piece shadows the last channel and stores nothing), bins
+  // (q % QPC) * 128 + 2 * lane
+  const float2 *Hq[NQ], *Xq[NQ];
+  float2 *Yq[NQ];
+  bool liveq[NQ];
   float4 y[NQ];
-  {
-    const float2 *yr = a.Yadd + (long long)c * a.yadd_chan_stride + lane * 2;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) y[q] = *reinterpret_cast<const float4 *>(yr + q * 128);
+  for (int q = 0; q < NQ; ++q) {
+    const int c_raw = wg * P8::TPW + q / QPC;
+    liveq[q] = c_raw < channels;
+    const int c = liveq[q] ? c_raw : channels - 1;
+    const int off = (q % QPC) * 128 + lane * 2;
+    Hq[q] = a.H + (long long)c * a.h_chan_stride + off;
+    Xq[q] = a.X + (long long)c * a.x_chan_stride + off;
+    Yq[q] = a.Y + (long long)c * a.y_chan_stride + off;
+    y[q] = *reinterpret_cast<const float4 *>(a.Yadd + (long long)c * a.yadd_chan_stride + off);
   }
   for (int i0 = 0; i0 < a.P; i0 += CH) {                 // (uniform)
     float4 hv[CH][NQ], xv[CH][NQ];
@@ -1683,12 +1863,11 @@ __device__ __forceinline__ void fdl_patch_wave512(const FirArgs &a, const int c)
     for (int u = 0; u < CH; ++u) {                       // clamped addresses: every load is issued, unused ones dropped below
       const int ii = i0 + u < a.P ? i0 + u : a.P - 1;
       const long long row = cbase - ii, rr = row < 0 ? 0 : row;
-      const float2 *hr = Hc + (long long)ii * B;
-      const float2 *xr = Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B;
+      const long long ho = (long long)ii * B, xo = (long long)((unsigned long long)rr & a.x_row_mask) * B;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        hv[u][q] = *reinterpret_cast<const float4 *>(hr + q * 128);
-        xv[u][q] = *reinterpret_cast<const float4 *>(xr + q * 128);
+        hv[u][q] = *reinterpret_cast<const float4 *>(Hq[q] + ho);
+        xv[u][q] = *reinterpret_cast<const float4 *>(Xq[q] + xo);
       }
     }
 #pragma unroll
@@ -1697,7 +1876,7 @@ __device__ __forceinline__ void fdl_patch_wave512(const FirArgs &a, const int c)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const float4 h = hv[u][q], x = xv[u][q];
-          const bool packed = (q == 0 && lane == 0);     // entry 0 of the row: (DC, Nyquist), two real products
+          const bool packed = (q % QPC == 0 && lane == 0);   // entry 0 of a row: (DC, Nyquist), two real products
           const float hz = packed ? 0.f : h.y;
           const float h3 = packed ? h.y : h.x;
           y[q].x = fmaf(h.x, x.x, y[q].x);
@@ -1712,30 +1891,22 @@ __device__ __forceinline__ void fdl_patch_wave512(const FirArgs &a, const int c)
       }
     }
   }
-  float2 *yo = a.Y + (long long)c * a.y_chan_stride + lane * 2;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) *reinterpret_cast<float4 *>(yo + q * 128) = y[q];
+  for (int q = 0; q < NQ; ++q)
+    if (liveq[q]) *reinterpret_cast<float4 *>(Yq[q]) = y[q];
 }
 
-// Head block 512, time-tiled delay line: ONE workgroup of two waves per channel -- wave 0 runs block k's audio path,
-// wave 1 patches block k+1's accumulator. At 2 waves per SIMD (the audio path's registers) a CU then holds the four
-// channels it is given ALL AT ONCE, and the launch dispatches a quarter of the waves k_fused_block2 does (256-thread
-// audio workgroups of which three waves retire at once + separate 256-thread patch workgroups, one resident per CU).
-// Measured for 1024 channels: 17.4 -> 17.0 us per launch; where the rest goes: DESIGN.md section 7, tools/block_stamps.py.
+// Head blocks of 128 / 256 / 512 with a time-tiled delay line: ONE workgroup of two waves per 4 / 2 / 1 channels -- wave 0
+// runs block k's audio path (the whole transform(s) live in that wave: its LDS exchanges need no s_barrier, core_sync),
+// wave 1 patches block k+1's accumulator(s). At 2 waves per SIMD (the audio path's registers) a CU then holds what it is
+// given ALL AT ONCE, and the launch dispatches a quarter of the waves k_fused_block2 does (256-thread audio workgroups of
+// which three waves retire at once + separate 256-thread patch workgroups, one resident per CU).
+// Measured for 1024 channels at head 512: 17.4 -> 17.0 us per launch; where the rest goes: DESIGN.md section 7.
 template <int LOGB>
 __global__ void __launch_bounds__(128) k_fused_block2w(const FusedArgs a, const FirArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (threadIdx.x < 64) fused_audio<LOGB, true, false, true>(a, smem_raw, blockIdx.x);
-  else if (f.P > 0) {
-#if defined(RVC_DEV_BUILD) && defined(RVC_BLOCK_STAMPS)
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_block_stamps[blockIdx.x * 16 + 0] = (unsigned long long)wall_clock64();
-#endif
-    fdl_patch_wave512(f, blockIdx.x);
-#if defined(RVC_DEV_BUILD) && defined(RVC_BLOCK_STAMPS)
-    __builtin_amdgcn_s_waitcnt(0);
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096) g_block_stamps[blockIdx.x * 16 + 1] = (unsigned long long)wall_clock64();
-#endif
-  }
+  else if (f.P > 0) fdl_patch_wave<LOGB>(f, blockIdx.x, a.channels);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1816,12 +1987,6 @@ __global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256
     }
     __syncthreads();
     if (s_exit) return;
-#ifdef RVC_PK_STAMPS
-    const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
-#else
-    constexpr bool stamp = false;
-#endif
-    if (stamp) ctl->pad[0] = (unsigned long long)wall_clock64();
     // the command, as wave-uniform (scalar) values: what comes back from LDS is a vector register to the compiler, and
     // buffer resources / row pointers built from those would be waterfall-looped and 64-bit vector arithmetic
     PkCmd cmd;
@@ -1836,7 +2001,6 @@ __global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256
       }
     }
     const unsigned flags = cmd.flags;
-    if (stamp) ctl->pad[1] = (unsigned long long)wall_clock64();
     if (flags & PK_QUIT) return;
     if ((flags & PK_ACQUIRE) || ((flags & PK_IO_HOST) && is_audio)) {   // ordinary launches rewrote buffers this workgroup reads with
                                            // plain loads / the host rewrote the staging buffer it reads with plain loads
@@ -1868,18 +2032,13 @@ __global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256
         __syncthreads();
         if (s_exit) return;
       }
-      if (stamp) ctl->pad[2] = (unsigned long long)wall_clock64();
       FusedArgs fa = pa.fa;
       fa.in = reinterpret_cast<const float *>(cmd.in); fa.in_chan_stride = cmd.in_stride;
       fa.out = reinterpret_cast<float *>(cmd.out); fa.out_chan_stride = cmd.out_stride;
       fa.n0 = cmd.n0; fa.n1 = cmd.n1; fa.k = cmd.k;
       fa.Ypre = reinterpret_cast<const float2 *>(cmd.ypre); fa.ypre_chan_stride = cmd.ypre_stride;
       fa.done_flag = nullptr; fa.seq = seq; fa.io_host = (flags & PK_IO_HOST) ? 1 : 0;   // (completion: published above, next pass)
-#ifdef RVC_PK_STAMPS
-      fa.dbg = const_cast<unsigned long long *>(ctl->pad);
-#endif
       fused_audio<LOGB, true, true>(fa, smem_raw, blockIdx.x);
-      if (stamp) { ctl->pad[3] = (unsigned long long)wall_clock64(); ctl->pad[4] = seq; }
       __syncthreads();                                               // s_cmd / the exchange buffer are reused next step
     } else {
       if ((flags & PK_BLOCK_DONE) && cmd.patch_P > 0) {
@@ -1919,6 +2078,26 @@ int persist_workgroups(int logB, int channels, int *n_audio, int *patch_bx) {
   if (n_audio) *n_audio = na;
   if (patch_bx) *patch_bx = pb;
   return na + pb * channels;
+}
+
+// how many workgroups of k_persist the device holds at once (every one of them spins on the others: the whole grid
+// must be resident); a margin of one workgroup per CU is kept (the occupancy query can be one high, MI355X_MICROARCH.md)
+template <int LOGB> static int persist_capacity_t() {
+  typedef Plan8<LOGB> P;
+  constexpr int kThreads = P::WG > 256 ? P::WG : 256;
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_persist<LOGB>, kThreads, sizeof(cx<float>) * P::LDS_ELEMS * P::TPW) != hipSuccess) return 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return per_cu > 1 ? (per_cu - 1) * cus : 0;
+}
+int persist_capacity(int logB) {
+  switch (logB) {
+    case 9: return persist_capacity_t<9>();
+    case 10: return persist_capacity_t<10>();
+    case 11: return persist_capacity_t<11>();
+    case 12: return persist_capacity_t<12>();
+    default: return 0;
+  }
 }
 
 template <int LOGB>
@@ -2019,8 +2198,59 @@ int fft8_table_entries(int logB) {   // entries of the tw8 table the radix-8 ker
     case 12: return FN<12, R>(__VA_ARGS__);                \
     case 13: return FN<13, R>(__VA_ARGS__);
 
+// ---- row-looping big transforms: when, and on how many workgroups --------------------------------------------
+static int g_fft_loop = -1;                      // -1: by size, 0: never, 1: whenever the rows qualify
+void set_fft_loop_tuning(int mode) { g_fft_loop = mode; }
+constexpr int kLoopLogB = 13;
+static size_t fft_loop_lds_bytes(bool inverse) {   // exchange buffer (+ the inverse kernel's twiddle table)
+  typedef Plan8<kLoopLogB> P;
+  return sizeof(cx<float>) * (P::LDS_ELEMS + (inverse ? Tw8<kLoopLogB, float, true, true, true>::LDS_SLOTS * P::NT : 0));
+}
+// workgroups the current device holds at once (cached per device; 0: unknown -> one-row kernels)
+static int fft_loop_workgroups(bool inverse) {
+  static int cache[2][16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  int &slot = cache[inverse ? 1 : 0][dev];
+  if (slot == 0) {
+    typedef Plan8<kLoopLogB> P;
+    int per_cu = 0, cus = 0;
+    const size_t lds = fft_loop_lds_bytes(inverse);
+    const hipError_t e = inverse ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft8_inv_loop<kLoopLogB>, P::WG, lds)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_fft8_fwd_loop<kLoopLogB>, P::WG, lds);
+    if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) slot = -1;
+    else slot = per_cu * cus > 0 ? per_cu * cus : -1;
+  }
+  return slot > 0 ? slot : 0;
+}
+static bool fwd_rows_loopable(const FwdArgs &a, int rows) {
+  constexpr long long B = 1ll << kLoopLogB;
+  const long long cap = (long long)(a.src_mask + 1ull);
+  return a.src2 == nullptr && a.ring_out == nullptr && a.valid_len == 2 * B && a.src_mask != ~0ull && cap % B == 0 &&
+         a.seg0 % B == 0 && a.seg0 >= a.lo && a.seg0 + (rows + 1) * B <= a.hi && a.seg0 >= 0 &&
+         (reinterpret_cast<uintptr_t>(a.src) & 7u) == 0 && (a.src_chan_stride & 1) == 0;
+}
+static bool inv_rows_loopable(const InvArgs &a, int rows) {
+  constexpr long long B = 1ll << kLoopLogB;
+  const long long n0 = a.blk0 * B, cap = (long long)(a.dst_mask + 1ull);
+  return a.add == nullptr && a.lo <= n0 && n0 + rows * B <= a.hi && a.dst_mask != ~0ull && cap % B == 0 &&
+         (n0 - a.dst_origin) % B == 0 && (reinterpret_cast<uintptr_t>(a.dst) & 7u) == 0 && (a.dst_chan_stride & 1) == 0;
+}
+
 hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int channels, hipStream_t st) {
   if (rows <= 0 || channels <= 0) return hipSuccess;
+  if (logB == kLoopLogB && !f64 && g_fft_loop != 0 && fwd_rows_loopable(a, rows)) {
+    const int nwg = fft_loop_workgroups(false);
+    const long long items = (long long)rows * channels;
+    if (nwg > 0 && items < (1ll << 30) && (g_fft_loop > 0 || items >= 4ll * nwg)) {   // (a few rows per workgroup, else the loop is all prologue)
+      typedef Plan8<kLoopLogB> P;
+      FwdArgs b = a;
+      b.rows = rows;
+      const int grid = (int)(items < nwg ? items : nwg);
+      RVC_LAUNCH((k_fft8_fwd_loop<kLoopLogB>), dim3(grid), dim3(P::WG), fft_loop_lds_bytes(false), st, b, (int)items);
+      return hipGetLastError();
+    }
+  }
   if (f64) {
     switch (logB) { RVC_CASES_0_13(launch_fwd_t, double, a, rows, channels, st) default: return hipErrorInvalidValue; }
   }
@@ -2032,6 +2262,18 @@ hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int ch
 }
 hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int channels, hipStream_t st) {
   if (rows <= 0 || channels <= 0) return hipSuccess;
+  if (logB == kLoopLogB && !f64 && g_fft_loop != 0 && inv_rows_loopable(a, rows)) {
+    const int nwg = fft_loop_workgroups(true);
+    const long long items = (long long)rows * channels;
+    if (nwg > 0 && items < (1ll << 30) && (g_fft_loop > 0 || items >= 4ll * nwg)) {
+      typedef Plan8<kLoopLogB> P;
+      InvArgs b = a;
+      b.rows = rows;
+      const int grid = (int)(items < nwg ? items : nwg);
+      RVC_LAUNCH((k_fft8_inv_loop<kLoopLogB>), dim3(grid), dim3(P::WG), fft_loop_lds_bytes(true), st, b, (int)items);
+      return hipGetLastError();
+    }
+  }
   if (f64) {
     switch (logB) { RVC_CASES_0_13(launch_inv_t, double, a, rows, channels, st) default: return hipErrorInvalidValue; }
   }
@@ -2066,14 +2308,12 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
   b.channels = channels;
   const int n_audio = (channels + P::TPW - 1) / P::TPW;
   const bool patch = f.Yadd != nullptr && f.P <= kPatchMax && f.P >= 1;
-#if !(defined(RVC_NO_BLOCK2W) && defined(RVC_DEV_BUILD))   // (A/B switch of development builds, tools/abl_build.py)
-  if constexpr (LOGB == 9) {
+  if constexpr (LOGB >= 7 && LOGB <= 9) {     // the audio workgroup is ONE wave: audio wave + patch wave per workgroup
     if (patch || f.P <= 0) {
-      RVC_LAUNCH((k_fused_block2w<LOGB>), dim3(channels), dim3(128), lds, st, b, f);
+      RVC_LAUNCH((k_fused_block2w<LOGB>), dim3(n_audio), dim3(128), lds, st, b, f);
       return hipGetLastError();
     }
   }
-#endif
   const int fir_bx = patch ? (P::B + 511) / 512 : (P::B + 63) / 64;
   const int n_fir = f.P > 0 ? fir_bx * channels : 0;
   constexpr int kThreads = P::WG > 256 ? P::WG : 256;
@@ -2180,12 +2420,15 @@ hipError_t prepare_kernels() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 139264);
     if (e != hipSuccess) return e;
   }
-  const void *big[] = {reinterpret_cast<const void *>(k_fft8_fwd<13, float>), reinterpret_cast<const void *>(k_fft8_inv<13, float>),
+  const void *big[] = {reinterpret_cast<const void *>(k_fft8_fwd_loop<kLoopLogB>), reinterpret_cast<const void *>(k_fft8_inv_loop<kLoopLogB>),
+                       reinterpret_cast<const void *>(k_fft8_fwd<13, float>), reinterpret_cast<const void *>(k_fft8_inv<13, float>),
                        reinterpret_cast<const void *>(k_fft8_fwd<14, float>), reinterpret_cast<const void *>(k_fft8_inv<14, float>),
                        reinterpret_cast<const void *>(k_fft8_fwd<12, double>), reinterpret_cast<const void *>(k_fft8_inv<12, double>),
                        reinterpret_cast<const void *>(k_fft8_fwd<13, double>), reinterpret_cast<const void *>(k_fft8_inv<13, double>)};
   for (const void *f : big) {
-    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 139264);
+    // (the inverse loop kernel: 68 KiB exchange buffer + 72 KiB twiddle table)
+    hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       f == reinterpret_cast<const void *>(k_fft8_inv_loop<kLoopLogB>) ? (int)fft_loop_lds_bytes(true) : 139264);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;

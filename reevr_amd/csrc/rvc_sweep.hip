@@ -1,15 +1,14 @@
-// rvc_sweep.hip -- the sweep kernel of the time-tiled block-synchronous delay line (gfx950).
+// rvc_sweep.hip -- the sweep kernels of the time-tiled block-synchronous delay line (gfx950).
 //
-// Replaces, for kSweepRows consecutive blocks at once, the reference's per-block loop over the partitions
+// Replaces, for K consecutive blocks at once, the reference's per-block loop over the partitions
 // (FFTConvolver.cpp:176-187 calling ComplexMultiplyAccumulate, Utilities.cpp:62-111): see rvc_internal.h.
 //
 // Own translation unit because it is compiled with -fno-slp-vectorize (reevr_amd/build.py): the SLP vectoriser
 // turns the 4*K independent FMA chains of a step into v_pk_fma_f32 with shuffled operands and then needs
-// ~450 spilled VGPRs at the 128-register budget; the kernel is HBM-bound (16 B read per 8*K flops), scalar FMAs
-// at ~1/3 VALU utilisation cost nothing.
+// ~450 spilled VGPRs at the 128-register budget; the kernels are HBM-bound (16 B read per 8*K flops: 4 flop/B at
+// K = 8, 16 flop/B at K = 32 against a ridge of ~25), scalar FMAs cost nothing.
 #include <hip/hip_ext.h>
 
-#include <cstdlib>
 #include <type_traits>
 
 #include "rvc_internal.h"
@@ -53,7 +52,7 @@ __device__ __forceinline__ void sweep_mac(float4 &acc, const float4 h, const flo
   acc.w = fmaf(h.w, x.z, acc.w);
 }
 
-// K output blocks k0 .. k0+K-1 at once from the input rows that have arrived (<= a.x_hi). Pure streaming: a wave owns
+// K output blocks k0 .. k0+K-1 at once from the input rows x_from <= row <= x_hi. Pure streaming: a wave owns
 // 32 * LW bins (LW floats = LW/2 bins per lane), walks the partitions once with D row pairs requested ahead, keeps the K
 // accumulators and a K-row sliding window of the delay line in registers: one IR row + one delay-line row fetched
 // per step feed K complex MACs per bin.
@@ -84,14 +83,17 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
   const long long cbase = a.k0 - a.delay - p0;     // input row meeting this wave's first partition for output row 0
   const bool packed = (bin == 0);                  // the lane's FIRST bin is the packed (DC, Nyquist) one
   const V zero = sweep_zero(V());
+  // rows that count: lo <= row <= x_hi (wave-uniform); everything else is requested from a clamped address inside
+  // that range -- a row this sweep reads anyway, so the request is a cache hit -- and dropped by a select
+  const long long lo = a.x_from > 0 ? a.x_from : 0;
+  const long long safe = a.x_hi >= lo ? a.x_hi : lo;
 
-  auto loadX = [&](long long row) -> V {           // clamped address, the caller selects
-    long long rr = row < 0 ? 0 : row;
-    rr = rr > a.x_hi ? (a.x_hi < 0 ? 0 : a.x_hi) : rr;
+  auto validX = [&](long long row) -> bool { return row >= lo && row <= a.x_hi; };
+  auto loadX = [&](long long row) -> V {
+    const long long rr = validX(row) ? row : safe;
     const char *rp = reinterpret_cast<const char *>(Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B);
     return sweep_ld<NT>(reinterpret_cast<const V *>(rp + boff));
   };
-  auto validX = [&](long long row) -> bool { return row >= 0 && row <= a.x_hi; };   // wave-uniform
   auto loadH = [&](int i) -> V {
     const int ii = i < P ? i : (P > 0 ? P - 1 : 0);
     const char *rp = reinterpret_cast<const char *>(Hc + (long long)ii * B);
@@ -147,21 +149,21 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
   };
   // (a wave without partitions -- fewer partitions than waves -- requests nothing: its clamped IR row would be the row
   //  BEHIND the channel's last partition, for the last channel behind the allocation)
-#if defined(RVC_SWEEP_NOREV) && defined(RVC_DEV_BUILD)   // A/B switch of development builds (tools/abl_build.py)
-  if (P > 0) walk(std::false_type());
-#else
   if (P > 0) {
     if (SPLIT != 1 && (wave & 1) == 0) walk(std::true_type());
     else walk(std::false_type());
   }
-#endif
 
   float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
+  const float2 *Yb = a.Ybase ? a.Ybase + (long long)c * a.ybase_chan_stride + bin : nullptr;   // second level: + first-level rows
   if constexpr (SPLIT == 1) {
     if (active) {
 #pragma unroll
-      for (int t = 0; t < K; ++t)
-        *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = acc[t];
+      for (int t = 0; t < K; ++t) {
+        V r = acc[t];
+        if (Yb) sweep_add(r, *reinterpret_cast<const V *>(Yb + (long long)((unsigned)(a.k0 + t) & a.ybase_row_mask) * B));
+        *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
+      }
     }
   } else {
 #pragma unroll
@@ -173,6 +175,7 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
         V r = red[0][t][lane];
 #pragma unroll
         for (int v = 1; v < SPLIT; ++v) sweep_add(r, red[v][t][lane]);
+        if (Yb) sweep_add(r, *reinterpret_cast<const V *>(Yb + (long long)((unsigned)(a.k0 + t) & a.ybase_row_mask) * B));
         *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
       }
     }
@@ -180,51 +183,53 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
 }
 
 // grid (bin tiles, channels), block 256. STAGE names the instantiation for profilers (0 head, 1 tail).
-template <int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
+template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
 __global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a) {
   typedef typename SweepVec<LW>::T V;
-  __shared__ V red[SPLIT == 1 ? 1 : SPLIT][kSweepRows][SPLIT == 1 ? 1 : 64];
-  fdl_sweep_body<kSweepRows, D, SPLIT, LW, NT>(a, reinterpret_cast<V (*)[kSweepRows][64]>(red), blockIdx.x, blockIdx.y);
+  __shared__ V red[SPLIT == 1 ? 1 : SPLIT][K][SPLIT == 1 ? 1 : 64];
+  fdl_sweep_body<K, D, SPLIT, LW, NT>(a, reinterpret_cast<V (*)[K][64]>(red), blockIdx.x, blockIdx.y);
 }
 
-template <int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
+template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
 static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
   const int tiles = (a.B + 32 * LW - 1) / (32 * LW);
   const dim3 grid(SPLIT == 1 ? (tiles + 3) / 4 : tiles, channels), block(256);
   hipEvent_t ea, eb;
   get_launch_events(&ea, &eb);
-  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep<SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, ea, eb, 0, a);
-  else hipLaunchKernelGGL((k_fdl_sweep<SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a);
+  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, ea, eb, 0, a);
+  else hipLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a);
 }
+
+static int g_sweep_split = -1;
+void set_sweep_tuning(int split) { g_sweep_split = split; }
 
 template <int STAGE>
 static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
-  // few waves (a stereo pair's tail stage: 2 x 64 tiles of 128 bins): split the partitions over the waves of a workgroup
-  // ... and for large partitions (the tail stage): measured 10 % faster there on MI355X, 15 % slower on 512-bin rows
-  const bool split = (long long)((a.B + 127) / 128) * channels < 2048 || a.B >= 2048;
-  // 16 B per lane, 4 row pairs ahead, <= 168 VGPRs (3 waves per SIMD), non-temporal loads on the own-tile form; measured
-  // against 8 B per lane, deeper queues, 2 / 4 waves per SIMD on MI355X (profiles/r2_sweep_variants.txt)
-#ifdef RVC_DEV_BUILD   // tuning knob of development builds only (tools/abl_build.py)
-  static const int variant = std::getenv("RVC_SWEEP_VARIANT") ? std::atoi(std::getenv("RVC_SWEEP_VARIANT")) : 0;
-  if (split && variant == 0) { launch_variant<4, STAGE, 4, 4, 3, false>(a, channels, st); return; }
-  switch (variant) {
-    case 1: launch_variant<1, STAGE, 4, 4, 3, true>(a, channels, st); return;    // + non-temporal loads
-    case 2: launch_variant<1, STAGE, 2, 8, 4, false>(a, channels, st); return;   // 8 B per lane, 8 ahead, 4 waves/SIMD
-    case 3: launch_variant<1, STAGE, 2, 8, 4, true>(a, channels, st); return;
-    case 4: launch_variant<4, STAGE, 4, 4, 3, false>(a, channels, st); return;   // partitions split over the 4 waves
-    case 5: launch_variant<4, STAGE, 4, 4, 3, true>(a, channels, st); return;
-    case 6: launch_variant<4, STAGE, 2, 8, 4, false>(a, channels, st); return;
-    case 7: launch_variant<4, STAGE, 2, 8, 4, true>(a, channels, st); return;
-    default: break;
+  // Partition-split form: few waves otherwise (a stereo pair's tail stage: 2 x 64 tiles of 128 bins), and large rows with
+  // many partitions (the tail stage: measured 10 % faster there on MI355X, 15 % slower on 512-bin rows). Not for second-
+  // level sweeps and long tiles: every wave of the split form reads K rows of window besides its share of the partitions.
+  const long long waves1 = (long long)((a.B + 127) / 128) * channels;
+  bool split = a.M == kSweepRows && a.Ybase == nullptr && (waves1 < 2048 || a.B >= 2048);
+  if (a.M > kSweepRows) split = (long long)((a.B + 63) / 64) * channels < 2048 && a.P >= 4 * a.M;
+  if (g_sweep_split >= 0) split = g_sweep_split != 0;
+  // K = 8: 16 B per lane, 4 row pairs ahead, <= 168 VGPRs (3 waves per SIMD), non-temporal loads on the own-tile form;
+  // measured against 8 B per lane, deeper queues, 2 / 4 waves per SIMD on MI355X (profiles/r2_sweep_variants.txt).
+  // K = 16 / 32 (first level of long delay lines): 8 B per lane -- 2 K registers of accumulators, 2 K of window.
+  if (a.M == 32) {
+    if (split) launch_variant<32, 4, STAGE, 2, 4, 2, false>(a, channels, st);
+    else launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);
+  } else if (a.M == 16) {
+    if (split) launch_variant<16, 4, STAGE, 2, 4, 3, false>(a, channels, st);
+    else launch_variant<16, 1, STAGE, 2, 4, 3, true>(a, channels, st);
+  } else {
+    if (split) launch_variant<8, 4, STAGE, 4, 4, 3, false>(a, channels, st);
+    else launch_variant<8, 1, STAGE, 4, 4, 3, true>(a, channels, st);
   }
-#else
-  if (split) { launch_variant<4, STAGE, 4, 4, 3, false>(a, channels, st); return; }
-#endif
-  launch_variant<1, STAGE, 4, 4, 3, true>(a, channels, st);
 }
 
 hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st) {
   if (channels <= 0 || a.P <= 0) return hipSuccess;
+  if (a.M != 8 && a.M != 16 && a.M != 32) return hipErrorInvalidValue;
   if (a.tag == 0) launch_stage<0>(a, channels, st);
   else launch_stage<1>(a, channels, st);
   return hipGetLastError();

@@ -37,9 +37,9 @@ def gather_batches(local, dist=None):
     """all_gather of equally-shaped per-rank output batches -> (world, *local.shape).
     `local` is a torch tensor (CUDA with nccl/RCCL, CPU with gloo)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return local.unsqueeze(0)
-    world = dist.get_world_size()
+    world = dist.get_world_size()          # (a group of one rank still runs the collective)
     local = local.contiguous()
     if local.is_cuda and dist.get_backend() == "nccl":      # RCCL: one collective straight into the stacked tensor
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
@@ -55,10 +55,11 @@ def gather_batches_async(local, out, dist=None):
     `out` (world, *local.shape); returns a work handle (`.wait()`), or None when there is nothing to communicate.
     With RCCL the collective is ordered behind the caller's current CUDA stream and runs on the communicator's own
     stream, so the next batch's kernels (on another stream) overlap it."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         out[0].copy_(local)
         return None
-    world = dist.get_world_size()
+    world = dist.get_world_size()                         # (a group of ONE rank still runs the collective: the RCCL path
+                                                          #  -- communicator, stream hand-off, buffer reuse -- on a 1-GPU box)
     assert out.shape[0] == world and tuple(out.shape[1:]) == tuple(local.shape) and local.is_contiguous()
     if local.is_cuda and dist.get_backend() == "nccl":
         return dist.all_gather_into_tensor(out.view(world * local.shape[0], *local.shape[1:]), local, async_op=True)

@@ -50,24 +50,29 @@ def test_gpu_present():
 KATS = [("fftconv", t) for t in cases.KAT_FFTCONV] + [("twostage", t) for t in cases.KAT_TWOSTAGE]
 
 
-@pytest.mark.parametrize("mode", ["f32", "f64"])
+def gpu32_factory(kind):
+    """RVC_FLAG_FFT_F32: float transforms whatever the set size (the default of large lock-step sets)."""
+    return (reevr_amd.FFTConvolver(fft_f32=True) if kind == "fftconv"
+            else reevr_amd.TwoStageFFTConvolver(fft_f32=True))
+
+
+@pytest.mark.parametrize("mode", ["default", "f64", "f32"])
 @pytest.mark.parametrize("kind,tup", KATS, ids=[cases.kat_name(k, t) for k, t in KATS])
 def test_kat_vs_golden_and_reference_rule(golden, kind, tup, mode):
-    """The reference's 58 known-answer cases (Test.cpp:256-329) in both precision modes.
-    Parity bar (north_star): RMS error <= 1e-5 of the output RMS -- both modes, all cases.
-    The reference's own pass rule (Test.cpp:129-145, margin < 1): all 58 cases in f64 mode
-    (which scores like the reference, <= 0.07); in the default f32 mode all cases with
-    partitions below 2048. With 2048-sample partitions of a 0.1*(i+1) ramp the first ~100
-    outputs (values 1..1700) share a 4096-point transform with values of 1.5e7, and a float32
-    FFT's 2e-7 relative noise is then ~1.3 absolute against the rule's 1.234: margin 1.01 /
-    0.71 measured on MI355X. That is the float32 transform, not a defect; it is bounded here."""
-    out = cases.run_kat(gpu_factory if mode == "f32" else gpu64_factory, kind, tup)
+    """The reference's 58 known-answer cases (Test.cpp:256-329) in the three precision modes.
+    Parity bar (north_star): RMS error <= 1e-5 of the output RMS -- every mode, all cases.
+    The reference's own pass rule (Test.cpp:129-145, margin < 1): all 58 cases in the DEFAULT mode (sets of up to 8
+    channels run stages with partitions of 2048 .. 8192 samples in double, rvc.h RVC_FLAG_FFT_F64) and with every
+    transform in double. With float transforms throughout (RVC_FLAG_FFT_F32, what large lock-step sets run) the rule
+    holds for partitions below 2048; with 2048-sample partitions of a 0.1*(i+1) ramp the first ~100 outputs (values
+    1..1700) share a 4096-point transform with values of 1.5e7, and a float32 FFT's 2e-7 relative noise is then ~1.3
+    absolute against the rule's 1.234: margin 1.01 .. 1.10 measured on MI355X -- bounded here at 1.15."""
+    factory = {"default": gpu_factory, "f64": gpu64_factory, "f32": gpu32_factory}[mode]
+    out = cases.run_kat(factory, kind, tup)
     cases.compare_to_fixture(out, fixture_of(golden["kat"], cases.kat_name(kind, tup)), TOL)
     exact = O.direct_convolve(synth.ramp(tup[0]), synth.ramp(tup[1]))
     margin = cases.kat_margin(out, exact, tup[1])
-    block = tup[4]
-    # (bounded tightly: measured 0.71 ... 1.10 on MI355X for the four cases concerned; INTEGRATION.md lists this as
-    #  the one known divergence of the default precision, RVC_FLAG_FFT_F64 removes it)
+    block = tup[4]          # (two-stage cases: IR < 2 x tail block, every partition is head-sized)
     limit = 1.15 if (mode == "f32" and block >= 2048) else 1.0
     assert margin < limit, f"margin {margin:.3f}"
     if limit == 1.0:
@@ -531,13 +536,14 @@ def _random_schedule(rng, total, head, tail):
     return out
 
 
-@pytest.mark.parametrize("tiling", ["default", "force"])
+@pytest.mark.parametrize("tiling", ["default", "force", "force2"])
 @pytest.mark.parametrize("seed", list(range(48)))
 def test_fuzz_geometry_and_call_pattern(seed, tiling):
     """Seeded fuzz: random head/tail sizes (incl. non powers of two), IR lengths around the
     stage boundaries, 1-3 channels of different lengths, flags, and call patterns; every run is
     compared with the oracle sample by sample. tiling = force: the causal time tiling of the
-    block-synchronous delay lines (RVC_FLAG_FORCE_TIME_TILING) whatever the stage size."""
+    block-synchronous delay lines (RVC_FLAG_FORCE_TIME_TILING) whatever the stage size; force2: with two-level
+    tiles (RVC_FLAG_FORCE_TWO_LEVEL: first-level sweeps of 16 blocks, second-level sweeps every 8)."""
     rng = np.random.RandomState(1000 + seed)
     head = int(rng.choice([1, 3, 8, 24, 64, 100, 256, 512, 1024]))
     tail = int(rng.choice([max(head, 16), 2 * max(head, 8), 128, 512, 2048, 8192]))
@@ -557,7 +563,7 @@ def test_fuzz_geometry_and_call_pattern(seed, tiling):
     bg = bool(rng.randint(0, 2))
     fixed = bool(rng.randint(0, 2))
     x = np.stack([synth.synth_input(total, 5 * seed + c) for c in range(nch)])
-    s = reevr_amd.ConvolverSet(nch, bg_stream=bg, fixed_partitions=fixed, time_tiling=True if tiling == "default" else "force")
+    s = reevr_amd.ConvolverSet(nch, bg_stream=bg, fixed_partitions=fixed, time_tiling=True if tiling == "default" else tiling)
     assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
     clear_at = int(rng.randint(0, len(sched))) if rng.randint(0, 3) == 0 else -1
     got = np.empty_like(x)
@@ -584,7 +590,7 @@ def test_fuzz_geometry_and_call_pattern(seed, tiling):
                                   f"bg {bg} fixed {fixed} clear {clear_at}: rel rms {err / ref:.3e}")
 
 
-@pytest.mark.parametrize("tiling", [True, False, "force"])
+@pytest.mark.parametrize("tiling", [True, False, "force", "force2", "force2_k32"])
 @pytest.mark.parametrize("seed", list(range(24)) + [226])   # 226: 3 tail partitions on 4 sweep waves (a wave without work)
 def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     """The plug-in's calling pattern -- one call per host block, now and then a ragged one, several calls inside one
@@ -617,8 +623,15 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
         done += n
     bg = bool(rng.randint(0, 2))
     x = np.stack([synth.synth_input(total, 11 * seed + c) for c in range(nch)])
-    s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling=tiling)
-    assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
+    if tiling == "force2_k32":                 # two levels with first-level tiles of 32 blocks (the default is 16)
+        reevr_amd.set_tuning("k1", 32)
+    try:
+        s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling="force2" if tiling == "force2_k32" else tiling)
+        assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
+    finally:
+        reevr_amd.set_tuning("k1", 16)
+    if str(tiling).startswith("force2"):
+        assert s.tile_rows(1) == (32 if tiling == "force2_k32" else 16)
     clear_at = int(rng.randint(len(sched) // 4, len(sched))) if rng.randint(0, 3) == 0 else -1
     got = np.empty_like(x)
     pos = start = 0
@@ -717,7 +730,7 @@ def test_lockstep_4096_channels_impulse_identity():
         assert bool((same == ref.unsqueeze(0)).all()), c
 
 
-@pytest.mark.parametrize("tiling", [False, True, "force"])
+@pytest.mark.parametrize("tiling", [False, True, "force", "force2"])
 @pytest.mark.parametrize("head,tail,parts,nch", [(64, 128, 5, 3), (64, 1024, 3, 2), (256, 512, 12, 2), (512, 8192, 2, 4),
                                                   (128, 2048, 20, 1)])
 def test_device_block_loop_tail_on_second_stream(head, tail, parts, nch, tiling):
@@ -884,3 +897,187 @@ def test_device_entry_with_misaligned_views_and_strides():
         got = big_out[:, off_out:off_out + frames].cpu().numpy()
         for c in range(2):
             assert rel_rms(got[c], want[c]) <= TOL
+
+
+def test_two_level_tiling_at_config3_geometry():
+    """BASELINE configs[2]'s geometry with the time tiling FORCED on both stages and many channels: head 256 / tail 8192,
+    a 30 s @ 96 kHz IR on channel 0 (P_A = 64 zero-latency partitions, P_T = 350 tail partitions -> two-level tiles on
+    both stages), 64 lock-step channels with IRs of different lengths, one process() per 256-frame block through the
+    device entry until every tail partition carries signal; three channels against the oracle."""
+    import torch
+    nch, head, tail = 64, 256, 8192
+    lens = [2880000] + [int(2880000 * (0.2 + 0.8 * ((7 * c) % nch) / nch)) for c in range(1, nch)]
+    base = synth.synth_ir(2880000, 2, 0)
+    irs = [base[c % 2][:lens[c]].copy() for c in range(nch)]
+    nblk = (352 + 24) * (tail // head)                       # all 350 tail partitions in use, then a few tiles more
+    x = np.stack([synth.synth_input(head * nblk, 200 + c % 5) for c in range(nch)])
+    s = reevr_amd.ConvolverSet(nch, time_tiling="force")
+    assert s.init(head, tail, irs, max_len=head), s.last_error_string
+    assert s.partitions(0) == 64 and s.partitions(1) == 350
+    assert s.tile_rows(0) > 8 and s.tile_rows(1) > 8         # two levels on both stages
+    got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
+    assert s.last_error == 0, s.last_error_string
+    s.close()
+    assert np.isfinite(got).all()
+    for c in (0, 1, nch - 1):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(got[c], o.process(x[c])) <= TOL, c
+
+
+@pytest.mark.parametrize("kids", [2, 4])
+def test_child_sets_match_single_set(kids):
+    """A set served by child sets on their own streams (rvc_set_subsets) gives, bit for bit, what the same set gives
+    alone -- per-block device calls, a multi-block call, a host-pointer call, clear() -- and matches the oracle."""
+    import torch
+    nch, head, tail, nblk = 8, 128, 512, 120
+    irs = [synth.synth_ir(2 * tail + 5 * tail - 31 * c, 1, 900 + c)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 50 + c) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    outs = []
+    for n in (1, kids):
+        reevr_amd.set_tuning("subsets", n)
+        try:
+            s = reevr_amd.ConvolverSet(nch, bg_stream=True, time_tiling="force")
+            assert s.init(head, tail, irs, max_len=4 * head), s.last_error_string
+        finally:
+            reevr_amd.set_tuning("subsets", -1)
+        assert s.subsets == n
+        a = s.process_device_blocks(dx[:, :head * 100].contiguous(), head).cpu().numpy()
+        b = s.process_device(dx[:, head * 100:head * 104].contiguous()).cpu().numpy()      # a multi-block call
+        c = s.process(x[:, head * 104:head * 105])                                         # host pointers
+        s.clear()
+        d = s.process_device_blocks(dx[:, :head * 20].contiguous(), head).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        s.close()
+        outs.append((a, b, c, d))
+    for u, v in zip(*outs):
+        assert np.array_equal(u, v)
+    whole = np.concatenate(outs[1][:3], axis=1)
+    for c in (0, nch - 1):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(whole[c], o.process(x[c, :head * 105])) <= TOL, c
+
+
+def test_row_looping_transforms_match_one_row_kernels():
+    """The row-looping 8192-bin transform kernels (k_fft8_fwd_loop / _inv_loop: many lock-step channels' tail jobs) against
+    the one-row kernels on the same set, and against the oracle: 600 channels (more rows than resident workgroups, so
+    workgroups really loop and prefetch), head 512 / tail 8192, short IRs with a tail stage."""
+    import torch
+    nch, head, tail, nblk = 600, 512, 8192, 16 * 7
+    irs = [synth.synth_ir(2 * tail + 3 * tail - 101 * (c % 7), 1, 40 + c % 11)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 300 + c % 9) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    outs = {}
+    for mode in (0, 1):
+        reevr_amd.set_tuning("fft_loop", mode)
+        try:
+            s = reevr_amd.ConvolverSet(nch)
+            assert s.init(head, tail, irs, max_len=head), s.last_error_string
+            outs[mode] = s.process_device_blocks(dx, head).cpu().numpy()
+            assert s.last_error == 0, s.last_error_string
+            s.close()
+        finally:
+            reevr_amd.set_tuning("fft_loop", -1)
+    assert np.isfinite(outs[1]).all()
+    for c in range(nch):
+        assert rel_rms(outs[1][c], outs[0][c]) <= 2e-6, c
+    for c in (0, 299, 599):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(outs[1][c], o.process(x[c])) <= TOL, c
+
+
+@pytest.mark.parametrize("seed", [0, 3, 7, 11, 226])
+def test_guard_bands_stay_intact_and_outputs_finite(seed):
+    """Out-of-bounds net (rvc_debug_guard_check): every device allocation of the set between NaN-filled guard bands and
+    NaN-poisoned itself. A block-synchronous fuzz run with forced two-level tiling, ragged / multi-block / long calls and a
+    clear(): no guard byte may change (no out-of-bounds write), every output must be finite and match the oracle (a value
+    read out of bounds or never written and USED would be a NaN: the 0ca535d bug class fails here, not by seed luck)."""
+    rng = np.random.RandomState(9100 + seed)
+    head = int(rng.choice([64, 128, 256, 512]))
+    tail = int(rng.choice([2 * head, 4 * head, 16 * head]))
+    nch = int(rng.randint(1, 4))
+    parts = 3 if seed == 226 else int(rng.choice([1, 3, 9, 20]))
+    base = 2 * tail + parts * tail - int(rng.randint(0, tail // 2))
+    irs = [synth.synth_ir(max(1, base - c * int(rng.randint(0, tail))), 1, 800 + 3 * seed + c)[0] for c in range(nch)]
+    total = int(min(max(40 * tail, 30 * 8 * head), 200000))
+    total -= total % head
+    sched, done = [], 0
+    while done < total:
+        r = rng.randint(0, 30)
+        n = (int(rng.randint(1, head)) if r == 0 else (head - done % head) if (r == 1 and done % head) else
+             int(rng.randint(2, 6)) * head if r == 2 else int(rng.randint(5, 9)) * tail if r == 3 else
+             (head if done % head == 0 else head - done % head))
+        n = max(1, min(n, total - done))
+        sched.append(n)
+        done += n
+    x = np.stack([synth.synth_input(total, 13 * seed + c) for c in range(nch)])
+    reevr_amd.set_tuning("guard", 1)
+    try:
+        s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1), time_tiling="force2")
+        assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
+    finally:
+        reevr_amd.set_tuning("guard", 0)
+    assert s.guard_check() == 0
+    got = np.empty_like(x)
+    pos = 0
+    for n in sched:
+        got[:, pos:pos + n] = s.process(x[:, pos:pos + n])
+        pos += n
+    assert s.last_error == 0, s.last_error_string
+    assert s.guard_check() == 0, "a kernel wrote outside its allocation"
+    assert np.isfinite(got).all(), "a kernel used a value it read out of bounds / that nobody wrote"
+    for c in range(nch):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(got[c], o.process(x[c])) <= TOL, c
+    s.close()
+
+
+def test_guard_mode_lockstep_many_channels():
+    """The same net on the lock-step regime's kernels: 96 channels, head 512 / tail 8192 (2-wave per-block kernel, sweeps,
+    patches, tail transforms), default tiling by size + forced; guards intact, outputs finite, three channels vs the oracle."""
+    import torch
+    nch, head, tail, nblk = 96, 512, 8192, 16 * 6
+    irs = [synth.synth_ir(2 * tail + 19 * tail - 977 * (c % 5), 1, 600 + c)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 20 + c % 7) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    for tiling in (True, "force2"):
+        reevr_amd.set_tuning("guard", 1)
+        try:
+            s = reevr_amd.ConvolverSet(nch, time_tiling=tiling)
+            assert s.init(head, tail, irs, max_len=head), s.last_error_string
+        finally:
+            reevr_amd.set_tuning("guard", 0)
+        got = s.process_device_blocks(dx, head).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        assert s.guard_check() == 0
+        assert np.isfinite(got).all()
+        for c in (0, 47, 95):
+            o = O.TwoStageFFTConvolver("orc")
+            assert o.init(head, tail, irs[c])
+            assert rel_rms(got[c], o.process(x[c])) <= TOL, (tiling, c)
+        s.close()
+
+
+@pytest.mark.parametrize("head,block", [(128, 128), (256, 256), (128, 100)])
+def test_two_wave_block_kernel_small_heads(head, block):
+    """Head blocks of 128 / 256: 4 / 2 channels share one audio wave and its patch wave (k_fused_block2w<7>, <8>); channel
+    counts that leave a workgroup partly empty; tiled by force, against the oracle."""
+    import torch
+    tail = 8 * head
+    for nch in (1, 3, 5):
+        irs = [synth.synth_ir(2 * tail + 6 * tail - 13 * c, 1, 70 + c)[0] for c in range(nch)]
+        nblk = 200
+        x = np.stack([synth.synth_input(block * nblk, 80 + c) for c in range(nch)])
+        s = reevr_amd.ConvolverSet(nch, time_tiling="force")
+        assert s.init(block, tail, irs, max_len=block), s.last_error_string
+        got = s.process_device_blocks(torch.from_numpy(x).cuda(), block).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        s.close()
+        for c in range(nch):
+            o = O.TwoStageFFTConvolver("orc")
+            assert o.init(block, tail, irs[c])
+            assert rel_rms(got[c], o.process(x[c])) <= TOL, (nch, c)

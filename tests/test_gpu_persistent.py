@@ -242,3 +242,58 @@ def test_stereo_convolver_shim_persistent_cpp():
     r0 = subprocess.run([exe, "512", "600", "1", "100", "0"], capture_output=True, text=True, timeout=60)
     rec0 = json.loads(r0.stdout.strip().splitlines()[-1])
     assert abs(rec["checksum"] - rec0["checksum"]) <= 1e-3 * max(1.0, abs(rec0["checksum"]))    # same audio either way
+
+
+@pytest.mark.parametrize("head,tail", [(512, 1024), (512, 512), (4096, 8192)])
+def test_fresh_set_pipelined_device_blocks_tail_hand_off(head, tail):
+    """Pipelined device-pointer block calls on a FRESH persistent set (no host pass before, every buffer NaN-poisoned by
+    the guard mode) with tail <= 2 x head: the step that completes a tail block can still be in flight when its output is
+    first needed; the fallback that then produces the tail block on the second stream must be waited for before the
+    resident kernel adds it (a stale or half-written tail ring shows as NaN / a parity miss here)."""
+    import torch
+    nch = 2
+    irs = [synth.synth_ir(2 * tail + 3 * tail - 50 * c, 1, 760 + c)[0] for c in range(nch)]
+    nblk = max(48, 12 * tail // head)
+    x = np.stack([synth.synth_input(head * nblk, 33 + c) for c in range(nch)])
+    want = oracle(irs, x, head, tail)
+    for rep in range(2):
+        reevr_amd.set_tuning("guard", 1)
+        try:
+            s = reevr_amd.ConvolverSet(nch, persistent=True, fft_f32=True)
+            assert s.init(head, tail, irs, max_len=head), s.last_error_string
+        finally:
+            reevr_amd.set_tuning("guard", 0)
+        got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        assert s.guard_check() == 0
+        s.close()
+        assert np.isfinite(got).all()
+        for c in range(nch):
+            assert rel_rms(got[c], want[c]) <= TOL, (rep, c)
+
+
+def test_freeing_while_another_sets_kernel_is_parked_does_not_stall():
+    """A resident kernel that has PARKED itself (idle owner) must not make other threads' frees wait out the guard's
+    timeout: destroying an unrelated set and an impulse object takes milliseconds, not seconds."""
+    head, tail = 512, 8192
+    irs = [synth.synth_ir(30000, 1, 5)[0]]
+    os.environ["RVC_PERSIST_IDLE_MS"] = "50"
+    try:
+        s = reevr_amd.ConvolverSet(1, persistent=True)
+        assert s.init(head, tail, irs, max_len=head)
+        x = synth.synth_input(head * 4, 0)[None, :]
+        for i in range(4):
+            s.process(x[:, i * head:(i + 1) * head])
+        time.sleep(0.5)                               # the resident kernel parks itself; its owner does not call again
+        t0 = time.perf_counter()
+        for _ in range(3):
+            o = reevr_amd.ConvolverSet(2)
+            assert o.init(64, 256, [irs[0][:2000], irs[0][:1500]])
+            o.close()
+        dt = time.perf_counter() - t0
+        assert dt < 2.0, f"three create/init/destroy rounds took {dt:.2f} s beside a parked kernel"
+        y = s.process(x[:, :head])                    # the owner comes back: relaunch, still correct
+        assert s.last_error == 0 and np.isfinite(y).all()
+        s.close()
+    finally:
+        os.environ.pop("RVC_PERSIST_IDLE_MS", None)

@@ -102,6 +102,49 @@ def _rccl_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def test_rccl_one_rank_bench_gather():
+    """The RCCL code path of bench.py on ONE device: under torch.distributed.run with a single rank the process group is
+    created with backend nccl (= RCCL) and device_id, every step's output batch goes through an asynchronous
+    all_gather_into_tensor ordered behind the set's streams, the batch buffers are reused only after their gather has
+    completed -- and the gathered batch of the last step must equal the set's own output; the impulse probe must hold."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for extra in (["--config", "2", "--channels", "40", "--blocks-per-step", "32", "--gather", "2"],
+                  ["--config", "2", "--channels", "40", "--blocks-per-step", "32"],
+                  ["--config", "4", "--blocks-per-step", "32"]):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1",
+               "--cpu-seconds", "0", "--side", "0", "--watchdog", "120"] + extra
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert rec["n_gpus"] == 1 and rec["config"]["gather"] is True
+        assert rec["config"]["gather_matches_output"] is True
+        assert rec["probe"]["ok"] is True, rec["probe"]
+
+
+def test_rccl_gather_one_rank_against_oracle():
+    """shard.gather_batches / reassemble / max_over_ranks through RCCL with a group of one rank, real engine, vs the oracle."""
+    import torch.multiprocessing as mp
+    from oracle import oracle_py as O
+    from reevr_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    rank, full, slow = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and slow == 1.0 and full.shape == (4, 2, 4096)
+    for u in range(4):
+        irs = synth.synth_ir(3000, 2, inst=u)
+        for c in range(2):
+            o = O.TwoStageFFTConvolver("orc")
+            assert o.init(64, 256, irs[c])
+            want = o.process(synth.synth_input(4096, 2 * u + c))
+            err = np.sqrt(np.mean((full[u, c].astype(np.float64) - want) ** 2)) / np.sqrt(np.mean(want.astype(np.float64) ** 2))
+            assert err <= 1e-5, (u, c, err)
+
+
 def test_rccl_gather_two_devices():
     if _ndev() < 2:
         pytest.skip("needs two visible devices")

@@ -52,11 +52,6 @@ def main():
     lat = []
     for i in range(nblk):
         t = time.perf_counter(); s.process(x[:, i * head:(i + 1) * head]); lat.append(time.perf_counter() - t)
-    import ctypes as C
-    st = (C.c_ulonglong * 5)()
-    s._lib.rvc_debug_persist_stamps(s._h, st)
-    print("device stamps of the last step (us): fetch %.2f  accumulator wait %.2f  audio %.2f" %
-          ((st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0), flush=True)
     lat = np.array(lat[50:]) * 1e6
     print("host call us: median %.1f p10 %.1f p99 %.1f (python ctypes overhead included)" % (np.median(lat), np.percentile(lat, 10), np.percentile(lat, 99)), flush=True)
     big = torch.from_numpy(np.stack([synth.synth_input(head * 4000, c) for c in range(2)])).cuda()
