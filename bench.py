@@ -206,6 +206,9 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
         exe["sweep2_head"] = sweep2_rows(KA, PA, 0) * row_h
     else:                                                    # zero-latency stage not tiled: every block reads all of it
         exe["fused_block"] = 5 * row_h + io_blk + (2.0 * max(PA - 2, 0) + 1) * row_h
+        # (many channels with a large head block: the per-block call is transform / delay line / inverse launches)
+        exe.update({"ingest": float(n1 * 8 * host_block), "fft_fwd_head": float(n1 * (4 * 2 * head + 8 * head)),
+                    "fir_head": (2.0 * PA + 1) * row_h, "fft_inv_head": float(n1 * (8 * head + 12 * head))})
     exe["premultiply"] = 2.0 * max(PA - 2, 0) * row_h + row_h
     if tail and PT:
         if KT:
@@ -323,16 +326,21 @@ class Lockstep:
                 "ok": bool(err <= 1e-5 * max(ref, 1e-12) + 1e-9)}
 
     def kernel_times(self, KERNEL_NAMES):
-        """per-kernel durations of ONE step, live, with HIP events on the streams the kernels run on"""
+        """per-kernel durations, live, with HIP events on the streams the kernels run on -- over as many steps as one
+        first-level sweep tile of the tail stage spans (so that every kernel family occurs), reported per step"""
+        span = self.tail if self.tail else self.head
+        k1 = self.conv.tile_rows(1 if self.tail else 0) or 1
+        nsteps = 1 if self.long_call else max(1, -(-k1 * span // self.frames_step))
         self.conv.set_timing(True)
         self.conv.kernel_time_reset()
-        self.step()
+        for _ in range(nsteps):
+            self.step()
         self.conv.sync()
         kern = {}
         for kid, name in enumerate(KERNEL_NAMES):
             n, ms = self.conv.kernel_time(kid)
             if n:
-                kern[name] = {"launches_per_step": float(n), "avg_ms": ms / n}
+                kern[name] = {"launches_per_step": float(n) / nsteps, "avg_ms": ms / n}
         self.conv.set_timing(False)
         self.conv.kernel_time_reset()
         return kern
@@ -448,6 +456,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the headline's CPU baseline leg (0 = skip)")
     ap.add_argument("--config-cpu-seconds", type=float, default=8.0, help="budget of each other configuration's CPU leg")
     ap.add_argument("--side", type=int, default=1, help="0: skip the side measurements")
+    ap.add_argument("--distinct", type=int, default=0, help="synthesise only this many different stereo IRs and cycle them (0: all different; config 3: 128)")
     ap.add_argument("--tune", type=str, default="", help="rvc_debug_set_tuning knobs, e.g. k1=32,subsets=2 (measurement hook)")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a stuck run dumps every thread's stack and exits (0: off)")
@@ -519,7 +528,7 @@ def main():
         raise SystemExit("--blocks-per-step must cover whole tail periods (a multiple of %d)" % ((tail or head) // host_block))
 
     ls = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, bool(args.time_tiling), bool(args.bg_stream), blocks,
-                  long_call=long_call, distinct=128 if wcfg == 3 else 0)
+                  long_call=long_call, distinct=args.distinct or (128 if wcfg == 3 else 0))
     conv, nch, frames_step, nbuf, ir_len = ls.conv, ls.nch, ls.frames_step, ls.nbuf, ls.ir_len
     do_gather = bool(args.gather and dist is not None)
     # The output batch of every step is gathered with ONE all_gather, overlapped with the next step's compute:

@@ -145,6 +145,9 @@ struct rvc_set {
   unsigned flag_seq = 0;         // value the next flagged launch publishes
   int flag_count = 0;            // flags the pending call waits for (0: wait for ev_out instead)
   bool fold = false;             // one launch per block: H_1 X_{k-1} folded into the fused kernel, ypre = sum_{i>=2}
+  bool block_general = false;    // per-block calls take the general path (transform / delay line / inverse launches): many
+                                 // channels with a LARGE head block, where the one-workgroup-per-channel latency kernel
+                                 // (one resident workgroup per CU at 4096 bins) is several times slower than they are
   // Causal time tiling of the block-synchronous delay lines (rvc_internal.h, kSweepRows): every kSweepRows-th
   // block a sweep reads the stage's IR spectra and delay line ONCE and leaves partial sums for kSweepRows blocks;
   // the blocks in between only add their few missing (recent) partitions.
@@ -238,7 +241,10 @@ hipError_t dev_alloc_raw(rvc_set *s, void **p, size_t bytes) {
   char *base = nullptr;
   hipError_t e = hipMalloc(&base, bytes + 2 * kGuardBytes);
   if (e != hipSuccess) return e;
-  e = hipMemset(base, 0xFF, bytes + 2 * kGuardBytes);
+  // (on the set's own stream and waited for: the set's streams are non-blocking ones, a fill on the null stream could
+  //  land AFTER the first writes of the buffer's owner and poison valid data)
+  e = s->streams_ok ? hipMemsetAsync(base, 0xFF, bytes + 2 * kGuardBytes, s->st_main) : hipMemset(base, 0xFF, bytes + 2 * kGuardBytes);
+  if (e == hipSuccess) e = s->streams_ok ? hipStreamSynchronize(s->st_main) : hipDeviceSynchronize();
   if (e != hipSuccess) { hipFree(base); return e; }
   *p = base + kGuardBytes;
   s->guards.push_back({base, bytes});
@@ -589,9 +595,10 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   RVC_CK(dev_alloc(s, &s->xring, sizeof(float) * (size_t)s->nch * s->ring_cap));
   if (pt > 0) RVC_CK(dev_alloc(s, &s->tailring, sizeof(float) * (size_t)s->nch * s->ring_cap));
   RVC_CK(dev_alloc(s, &s->ypre, sizeof(float2) * 2 * (size_t)s->nch * A.B));
-  RVC_CK(hipMemset(s->ypre, 0, sizeof(float2) * 2 * (size_t)s->nch * A.B));
+  RVC_CK(hipMemsetAsync(s->ypre, 0, sizeof(float2) * 2 * (size_t)s->nch * A.B, s->st_main));
   s->ypre_block = -1;
   s->fold = rvc::fused_fold_supported(A.logB) && !A.f64;
+  s->block_general = A.logB >= 11 && (size_t)s->nch * A.B >= ((size_t)1 << 20);   // (measured: BASELINE config 5's geometry, 4096 channels)
   // time tiling: where a per-block sweep is long enough to be bandwidth- rather than latency-bound
   {
     const bool tiling = (s->flags & RVC_FLAG_NO_TIME_TILING) == 0;
@@ -600,7 +607,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     const size_t K = (size_t)rvc::kSweepRows;
     Tile &tA = s->tA, &tT = s->tT;
     tA = Tile(); tT = Tile();
-    tA.on = tiling && s->fold && A.B >= 64 &&
+    tA.on = tiling && s->fold && !s->block_general && A.B >= 64 &&
             (force ? pa >= 3 : (pa >= 16 && (size_t)s->nch * (pa - 2) * A.B * 16 >= ((size_t)4 << 20)));
     tT.on = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
     // persistent mode: the resident kernel only ever adds a few recent partitions, so the zero-latency stage is tiled
@@ -639,13 +646,13 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
       RVC_CK(hipHostMalloc(&s->h_pdone, sizeof(unsigned) * (size_t)s->pk_n_patch, hipHostMallocDefault));
       std::memset(s->h_pdone, 0, sizeof(unsigned) * (size_t)s->pk_n_patch);
       RVC_CK(dev_alloc(s, &s->pk_ypre_seq, sizeof(unsigned) * (size_t)s->pk_n_patch));
-      RVC_CK(hipMemset(s->pk_ypre_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_patch));
+      RVC_CK(hipMemsetAsync(s->pk_ypre_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_patch, s->st_main));
       RVC_CK(dev_alloc(s, &s->pk_x_seq, sizeof(unsigned) * (size_t)s->pk_n_audio));
-      RVC_CK(hipMemset(s->pk_x_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_audio));
+      RVC_CK(hipMemsetAsync(s->pk_x_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_audio, s->st_main));
       RVC_CK(dev_alloc(s, &s->pk_park, sizeof(unsigned)));
-      RVC_CK(hipMemset(s->pk_park, 0, sizeof(unsigned)));
+      RVC_CK(hipMemsetAsync(s->pk_park, 0, sizeof(unsigned), s->st_main));
       RVC_CK(dev_alloc(s, &s->pk_zero_row, sizeof(float2) * (size_t)s->nch * A.B));
-      RVC_CK(hipMemset(s->pk_zero_row, 0, sizeof(float2) * (size_t)s->nch * A.B));
+      RVC_CK(hipMemsetAsync(s->pk_zero_row, 0, sizeof(float2) * (size_t)s->nch * A.B, s->st_main));
       s->pk_seq = s->pk_retired = 0;
       s->pk_tile_hi = s->pk_tile_ready = -1;
       s->pk_need_acquire = false;
@@ -1370,7 +1377,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     s->pk_tile_hi = s->pk_tile_ready = -1;
     s->pk_ypre_from = 0;
   }
-  if (k0 == k1 && rvc::fused_supported(A.logB, A.f64)) {
+  if (k0 == k1 && !s->block_general && rvc::fused_supported(A.logB, A.f64)) {
     if (has_tail) {
       if (bg) { if (!wait_tail_jobs(s, n1)) return false; }
       else if (!tail_rows(s, (n1 - 1) / (long long)T.B + 1, s->st_main)) return false;
@@ -1870,7 +1877,7 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   // buffers are device-visible, the kernel reads its 2 KB per channel over PCIe and writes the
   // result straight back; the host waits for the event behind that kernel. Longer calls use DMA.
   const long long hb = (long long)s->A.B;
-  s->zero_copy = rvc::fused_supported(s->A.logB, s->A.f64) && (s->n / hb) == ((s->n + (long long)len - 1) / hb);
+  s->zero_copy = !s->block_general && rvc::fused_supported(s->A.logB, s->A.f64) && (s->n / hb) == ((s->n + (long long)len - 1) / hb);
   bool ok = true;
   if (!s->zero_copy)
     ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * len * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
@@ -2211,6 +2218,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   const std::string k(key);
   if (k == "k1") g_tune.k1 = value;
   else if (k == "sweep_split") rvc::set_sweep_tuning(value);
+  else if (k == "sweep_lw") rvc::set_sweep_lane_width(value);
   else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
   else if (k == "subsets") g_tune.subsets = value;
   else if (k == "guard") g_tune.guard = value;

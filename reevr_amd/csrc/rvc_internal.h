@@ -250,6 +250,7 @@ constexpr int kSweepLagMax = 3;   // a sweep may run up to this many blocks befo
 hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st);
 // measurement hook (rvc_debug_set_tuning): "sweep_split" -1 auto / 0 own-tile form / 1 partition-split form
 void set_sweep_tuning(int split);
+void set_sweep_lane_width(int lw);   // "sweep_lw": 4 = 16-byte lanes for the 16-block first-level sweeps (default 8-byte)
 
 // A prepared impulse as rvc_set_init_impulse sees it (rvc_impulse.hip): device pointers of the
 // prepared channels and their lengths with trailing |x| < 1e-6 dropped (TwoStageFFTConvolver.cpp:107-110).

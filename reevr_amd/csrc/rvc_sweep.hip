@@ -200,8 +200,9 @@ static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
   else hipLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a);
 }
 
-static int g_sweep_split = -1;
+static int g_sweep_split = -1, g_sweep_lw = 0;
 void set_sweep_tuning(int split) { g_sweep_split = split; }
+void set_sweep_lane_width(int lw) { g_sweep_lw = lw; }
 
 template <int STAGE>
 static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
@@ -219,7 +220,10 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
     if (split) launch_variant<32, 4, STAGE, 2, 4, 2, false>(a, channels, st);
     else launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);
   } else if (a.M == 16) {
-    if (split) launch_variant<16, 4, STAGE, 2, 4, 3, false>(a, channels, st);
+    if (g_sweep_lw == 4) {            // (measurement: 16 B per lane, 2 waves per SIMD)
+      if (split) launch_variant<16, 4, STAGE, 4, 4, 2, false>(a, channels, st);
+      else launch_variant<16, 1, STAGE, 4, 4, 2, true>(a, channels, st);
+    } else if (split) launch_variant<16, 4, STAGE, 2, 4, 3, false>(a, channels, st);
     else launch_variant<16, 1, STAGE, 2, 4, 3, true>(a, channels, st);
   } else {
     if (split) launch_variant<8, 4, STAGE, 4, 4, 3, false>(a, channels, st);
