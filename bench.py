@@ -340,7 +340,16 @@ class Lockstep:
         for kid, name in enumerate(KERNEL_NAMES):
             n, ms = self.conv.kernel_time(kid)
             if n:
-                kern[name] = {"launches_per_step": float(n) / nsteps, "avg_ms": ms / n}
+                # launches of child sets overlap in time: the union of the family's intervals is the time it kept the
+                # device busy (= the sum of the durations when the set has no children)
+                iv = self.conv.kernel_intervals(kid)
+                busy, end = 0.0, -1e30
+                for a, b in iv[np.argsort(iv[:, 0])]:
+                    if b > end:
+                        busy += b - max(a, end)
+                        end = b
+                kern[name] = {"launches_per_step": float(n) / nsteps, "avg_ms": ms / n,
+                              "busy_ms_per_step": (busy if len(iv) == n else ms) / nsteps}
         self.conv.set_timing(False)
         self.conv.kernel_time_reset()
         return kern
@@ -363,16 +372,24 @@ class Lockstep:
 
 
 def roofline_tables(kern: dict, exe: dict, traffic: dict):
+    """Per kernel family: bytes of the executed structure over the time the family kept the device busy. A set without
+    children: busy time = launches x average duration (the contract's per-launch figure). With child sets two launches of
+    a family share the device: per-launch durations (`avg_launch_ms`, what a profiler lists) count that shared time
+    twice, so `frac` is taken over the UNION of the family's launch intervals and `frac_per_launch` is the literal
+    bytes-per-launch / average-duration figure; `concurrency` = sum of durations / union."""
     roof_all, exe_bytes_step = {}, 0.0
     for k, v in kern.items():
         if k not in exe or exe[k] <= 0:
             continue
-        gbs = exe[k] / (v["avg_ms"] * 1e-3) / 1e9
-        exe_bytes_step += exe[k] * v["launches_per_step"]
+        tot = exe[k] * v["launches_per_step"]
+        busy = v.get("busy_ms_per_step", v["avg_ms"] * v["launches_per_step"])
+        gbs = tot / (busy * 1e-3) / 1e9
+        lit = exe[k] / (v["avg_ms"] * 1e-3) / 1e9
+        exe_bytes_step += tot
         roof_all[k] = {"launches_per_step": v["launches_per_step"], "avg_launch_ms": round(v["avg_ms"], 5),
-                       "ms_per_step": round(v["avg_ms"] * v["launches_per_step"], 5),
+                       "ms_per_step": round(busy, 5), "concurrency": round(v["avg_ms"] * v["launches_per_step"] / busy, 3),
                        "bytes_per_launch": exe[k], "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                       "traffic": traffic.get(k)}
+                       "frac_per_launch": round(lit / HBM_PEAK_GBS, 4), "traffic": traffic.get(k)}
     return roof_all, exe_bytes_step
 
 
@@ -619,6 +636,9 @@ def main():
         roof = {"bound": "hbm", "kernel": dominant, "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": r["frac"], "traffic": r["traffic"], "bytes_per_launch": r["bytes_per_launch"],
                 "avg_launch_ms": r["avg_launch_ms"], "traffic_source": tsrc,
+                # child sets: two launches of the family run side by side on their own streams -- `achieved` is bytes over
+                # the UNION of the launch intervals (HIP events, one clock); the per-launch literal is frac_per_launch
+                "concurrency": r["concurrency"], "frac_per_launch": r["frac_per_launch"], "busy_ms_per_step": r["ms_per_step"],
                 # SURVEY.md 8d's numerator (1497 B per channel-sample of the REFERENCE's loop nest): as a fraction of the
                 # peak only where the executed schedule moves those bytes (reference_schedule, filled in below); with
                 # time tiling the same figure x this run's rate is a throughput EQUIVALENT (> 1 is not an efficiency)

@@ -207,6 +207,11 @@ const char *rvc_last_error_string(const rvc_set *s);
  * Synchronises the set. Returns launches. */
 long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms);
 void rvc_set_kernel_time_reset(rvc_set *s);
+/* With timing on: (start, end) of every timed launch of one kernel family since the last rvc_set_kernel_time_reset, in
+ * milliseconds after that reset, all child sets on one clock; at most `cap` pairs are written, the count is returned.
+ * Launches of the children of a set overlap in time: the UNION of a family's intervals is the time the family kept the
+ * device busy (bench.py reports bytes over that union; per-launch durations alone would count the shared device twice). */
+long rvc_set_kernel_intervals(rvc_set *s, int kernel, double *start_ms, double *end_ms, long cap);
 /* Switch per-launch event timing on/off at run time (same as creating with RVC_FLAG_TIMING). */
 void rvc_set_timing(rvc_set *s, int enable);
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "rvc_last_error_string": (C.c_char_p, [C.c_void_p]),
     "rvc_set_kernel_time": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "rvc_set_kernel_time_reset": (None, [C.c_void_p]),
+    "rvc_set_kernel_intervals": (C.c_long, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_long]),
     "rvc_set_timing": (None, [C.c_void_p, C.c_int]),
     "rvc_create": (C.c_void_p, [C.c_int]),
     "rvc_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, F32P, C.c_size_t]),

@@ -271,6 +271,17 @@ class ConvolverSet:
     def kernel_time_reset(self):
         self._lib.rvc_set_kernel_time_reset(self._h)
 
+    def kernel_intervals(self, kernel: int):
+        """(n, 2) array of (start, end) in ms since the last reset of every timed launch of one kernel family
+        (all child sets on one clock)."""
+        n = int(self._lib.rvc_set_kernel_intervals(self._h, kernel, None, None, 0))
+        a = np.zeros(n, np.float64)
+        b = np.zeros(n, np.float64)
+        if n:
+            dp = C.POINTER(C.c_double)
+            self._lib.rvc_set_kernel_intervals(self._h, kernel, a.ctypes.data_as(dp), b.ctypes.data_as(dp), n)
+        return np.stack([a, b], axis=1)
+
     def guard_check(self) -> int:
         """Changed guard bytes around the set's device allocations (rvc_debug_guard_check; -1: no guards)."""
         return int(self._lib.rvc_debug_guard_check(self._h))

@@ -206,6 +206,11 @@ struct rvc_set {
   std::vector<TimedLaunch> timed[kNumKernelIds];   // event pairs not yet read (folded into the totals every 1024 launches)
   double timed_ms[kNumKernelIds] = {};
   long timed_n[kNumKernelIds] = {};
+  // (start, end) of every timed launch since the last reset, in ms after `timed_base` (rvc_set_kernel_intervals; child
+  // sets measure against their parent's base event, so that the intervals of all children share one clock)
+  hipEvent_t timed_base = nullptr;
+  rvc_set *timed_parent = nullptr;
+  std::vector<std::pair<float, float>> timed_iv[kNumKernelIds];
 };
 
 namespace {
@@ -304,7 +309,13 @@ void fold_timing(rvc_set *s, int id) {
   hipEventSynchronize(v.back().b);
   for (auto &t : v) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { s->timed_ms[id] += ms; ++s->timed_n[id]; }
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+      s->timed_ms[id] += ms; ++s->timed_n[id];
+      const hipEvent_t base = s->timed_parent ? s->timed_parent->timed_base : s->timed_base;
+      float st = 0.f;
+      if (base && s->timed_iv[id].size() < ((size_t)1 << 16) && hipEventElapsedTime(&st, base, t.a) == hipSuccess)
+        s->timed_iv[id].push_back({st, st + ms});
+    }
     hipEventDestroy(t.a); hipEventDestroy(t.b);
   }
   v.clear();
@@ -316,6 +327,7 @@ void drop_timing(rvc_set *s) {
     s->timed[id].clear();
     s->timed_ms[id] = 0.0;
     s->timed_n[id] = 0;
+    s->timed_iv[id].clear();
   }
 }
 
@@ -1640,7 +1652,10 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
 int subset_count(const rvc_set *s, size_t head_block, size_t max_len) {
   if ((s->flags & (RVC_FLAG_PERSISTENT | RVC_FLAG_NO_SUBSETS)) != 0) return 1;
   int n = g_tune.subsets;
-  if (n < 0) n = 1;                     // (auto: see rvc_set_init)
+  // auto: two children for sets of thousands of lock-step channels served block by block (measured on MI355X,
+  // BASELINE config 2: 4096 channels 13.2 -> 14.3 Gsamples/s, 8192 channels 13.1 -> 13.8; four children lose again:
+  // profiles/r3_tuning.txt); long calls gain nothing from it
+  if (n < 0) n = (s->nch >= 2048 && max_len <= 2 * next_pow2(head_block ? head_block : 1)) ? 2 : 1;
   if (n > 8) n = 8;
   while (n > 1 && (s->nch % n != 0 || s->nch / n < 2)) --n;
   (void)head_block; (void)max_len;
@@ -1734,6 +1749,7 @@ void rvc_set_destroy(rvc_set *s) {
   if (!s) return;
   drop_kids(s);
   free_device_state(s);
+  if (s->timed_base) hipEventDestroy(s->timed_base);
   if (s->streams_ok) {
     for (int i = 0; i < s->ev_free; ++i) hipEventDestroy(s->ev_pool[i]);
     hipEventDestroy(s->ev_ingest);
@@ -2063,9 +2079,36 @@ long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms) {
 
 void rvc_set_kernel_time_reset(rvc_set *s) {
   if (!s) return;
-  for (rvc_set *k : s->kids) rvc_set_kernel_time_reset(k);
+  for (rvc_set *k : s->kids) { k->timed_parent = s; rvc_set_kernel_time_reset(k); }
+  if (!s->timed_parent) {          // the clock of rvc_set_kernel_intervals starts here
+    hipStream_t st = s->kids.empty() ? s->st_main : s->kids[0]->st_main;
+    if (st && hipSetDevice(s->device) == hipSuccess) {
+      if (!s->timed_base) hipEventCreate(&s->timed_base);
+      if (s->timed_base) { hipEventRecord(s->timed_base, st); hipEventSynchronize(s->timed_base); }
+    }
+  }
   rvc_set_sync(s);
   drop_timing(s);
+}
+
+long rvc_set_kernel_intervals(rvc_set *s, int kernel, double *start_ms, double *end_ms, long cap) {
+  if (!s || kernel < 0 || kernel >= kNumKernelIds) return 0;
+  long n = 0;
+  if (!s->kids.empty()) {
+    for (rvc_set *k : s->kids) {
+      const long got = rvc_set_kernel_intervals(k, kernel, start_ms ? start_ms + n : nullptr, end_ms ? end_ms + n : nullptr,
+                                                cap > n ? cap - n : 0);
+      n += got;
+    }
+    return n;
+  }
+  rvc_set_sync(s);
+  fold_timing(s, kernel);
+  for (const auto &iv : s->timed_iv[kernel]) {
+    if (n < cap && start_ms && end_ms) { start_ms[n] = iv.first; end_ms[n] = iv.second; }
+    ++n;
+  }
+  return n;
 }
 
 void rvc_set_timing(rvc_set *s, int enable) {
