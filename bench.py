@@ -77,7 +77,7 @@ WORKLOADS = {
             text="mono, 1 s IR @ 48 kHz, block=512, single FFTConvolver"),
     2: dict(ir_len=480000, host_block=512, single=False, channels=4096, blocks=256,
             text="stereo, 10 s IR @ 48 kHz, block=512 (head 512 / tail 8192), TwoStage convolver"),
-    3: dict(ir_len=2880000, host_block=256, single=False, channels=1024, blocks=256,
+    3: dict(ir_len=2880000, host_block=256, single=False, channels=2048, blocks=256,
             text="stereo, 30 s IR @ 96 kHz, block=256 (head 256 / tail 8192; 64 + 350 partitions), TwoStage convolver"),
     5: dict(ir_len=240000, host_block=4096, single=False, channels=4096, blocks=32,
             text="mono channels, 5 s IR @ 48 kHz, block=4096 (head 4096 / tail 8192), TwoStage convolver"),

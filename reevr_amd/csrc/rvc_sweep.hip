@@ -220,7 +220,9 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
     if (split) launch_variant<32, 4, STAGE, 2, 4, 2, false>(a, channels, st);
     else launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);
   } else if (a.M == 16) {
-    if (g_sweep_lw == 4) {            // (measurement: 16 B per lane, 2 waves per SIMD)
+    // 16 B per lane (2 waves per SIMD) on the long rows of a tail stage, 8 B per lane (4 waves) on short ones: measured on
+    // MI355X, config 2's 57 x 8192-bin tail: 0.63 vs 0.60 of the HBM peak (profiles/r3_tuning.txt)
+    if (g_sweep_lw == 4 || (g_sweep_lw == 0 && a.B >= 1024)) {
       if (split) launch_variant<16, 4, STAGE, 4, 4, 2, false>(a, channels, st);
       else launch_variant<16, 1, STAGE, 4, 4, 2, true>(a, channels, st);
     } else if (split) launch_variant<16, 4, STAGE, 2, 4, 3, false>(a, channels, st);

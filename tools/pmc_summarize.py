@@ -20,15 +20,22 @@ import re
 CALIB_BYTES = 4 * (1 << 28)      # tools/pmc_calib.py copies 1 GiB per dispatch: this many bytes read AND as many written
 
 
+K1 = {"0": 8, "1": 8}      # blocks per first-level sweep tile of the head / tail stage (--k1-head / --k1-tail)
+
+
 def family(name: str, head_log: int, tail_log: int):
     if "k_fused_block" in name or "k_block_step" in name:
         return "fused_block"
+    m = re.search(r"k_fdl_sweep<(\d+), \d+, (\d)", name)          # <K, SPLIT, STAGE, ...>
+    if m:
+        st = "head" if m.group(2) == "0" else "tail"
+        return ("sweep_" if int(m.group(1)) == K1[m.group(2)] else "sweep2_") + st
+    m = re.search(r"k_fft8_(fwd|inv)_loop<(\d+)>", name)
+    if m:
+        return f"fft_{m.group(1)}_tail"
     m = re.search(r"k_fir_row<(\d)>", name)
     if m:
         return "premultiply" if m.group(1) == "0" else "fir_tail"
-    m = re.search(r"k_fdl_sweep<\d+, (\d)", name)          # <SPLIT, STAGE, ...>
-    if m:
-        return "sweep_head" if m.group(1) == "0" else "sweep_tail"
     m = re.search(r"k_fdl_patch<(\d)>", name)
     if m:
         return "premultiply" if m.group(1) == "0" else "fir_tail"
@@ -78,14 +85,19 @@ def main():
     ap.add_argument("--channels", type=int, default=4096)
     ap.add_argument("--time-tiling", type=int, default=1)
     ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--k1-head", type=int, default=8)
+    ap.add_argument("--k1-tail", type=int, default=16)
+    ap.add_argument("--subsets", type=int, default=2, help="child sets: every launch covers channels / subsets")
     ap.add_argument("--command", default="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --side 0")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
+    K1["0"], K1["1"] = a.k1_head, a.k1_tail
     fe = per_family(a.fetch_csv, a.head_log, a.tail_log)
     wr = per_family(a.write_csv, a.head_log, a.tail_log)
     ff, fk = calib_factor(a.calib_fetch, 2.0)
     fw, wk = calib_factor(a.calib_write, 1.0)
-    out = {"command": a.command, "channels": a.channels, "config": a.config, "time_tiling": a.time_tiling,
+    out = {"command": a.command, "channels": a.channels, "channels_per_launch": a.channels // max(1, a.subsets),
+           "config": a.config, "time_tiling": a.time_tiling,
            "unit": "bytes per launch (mean over the second half of each family's dispatches)",
            "correction": {"fetch_factor": round(ff, 4), "write_factor": round(fw, 4),
                           "calibration": "1 GiB device copy (tools/pmc_calib.py): FETCH_SIZE %s KiB, WRITE_SIZE %s KiB per dispatch "
@@ -96,7 +108,7 @@ def main():
         w = fw * wr.get(k, (0.0, 0))[0] * 1024.0
         out["kernels"][k] = {"fetch_bytes": f, "write_bytes": w, "traffic_bytes": f + w,
                              "dispatches_seen": max(fe.get(k, (0, 0))[1], wr.get(k, (0, 0))[1])}
-    json.dump(out, open(a.out, "w"), indent=1)
+    json.dump({"config%d" % a.config: out}, open(a.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -10,10 +10,12 @@ OUT=$(realpath -m "${1:-gpurun_out/prof}"); shift || true
 ROOT=$(pwd)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --side 0 $*"
+ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --side 0 --distinct 64 $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
 find "$OUT/kt" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
+# launches of the two child sets overlap: per family, the UNION of the dispatch intervals of the trace (tools/trace_union.py)
+find "$OUT/kt" -name '*kernel_trace.csv' -exec python "$ROOT/tools/trace_union.py" {} \; > "$OUT/kernel_union.txt" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o pmc -- python "$ROOT/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_$c.err"
   find "$OUT/pmc_$c" -name '*counter_collection.csv' -exec cp {} "$OUT/$c.csv" \;
