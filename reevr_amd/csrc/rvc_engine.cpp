@@ -2264,6 +2264,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   else if (k == "sweep_lw") rvc::set_sweep_lane_width(value);
   else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
   else if (k == "subsets") g_tune.subsets = value;
+  else if (k == "fft_stagger") rvc::set_fft_stagger_tuning(value);
   else if (k == "guard") g_tune.guard = value;
   else return 0;
   return 1;
