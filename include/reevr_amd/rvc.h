@@ -345,7 +345,8 @@ double rvc_debug_persist_rtt(rvc_set *s, int n);
 /* Measurement hook (bench.py, tools/): process-wide schedule knobs, read when a set is initialised. Returns 1 if the
  * key is known. Keys: "k1" first-level tile of long delay lines (8 = one level, 16 default, 32); "sweep_split" -1 auto /
  * 0 own-tile / 1 partition-split sweeps; "fft_loop" -1 auto / 0 / 1 row-looping 8192-bin transforms; "subsets" -1 auto /
- * n children of a many-channel set; "guard" 0 / 1 guard bands around every device allocation (see rvc_debug_guard_check). */
+ * n children of a many-channel set; "guard" 0 / 1 guard bands around every device allocation (see rvc_debug_guard_check) / 2 every
+ * allocation END-aligned against an unmapped address range (an out-of-bounds access faults: tools/fence_fuzz.py only). */
 int rvc_debug_set_tuning(const char *key, int value);
 /* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set
  * is initialised, every device allocation of the set lies between two 256 KiB guard bands filled with 0xFF and starts out

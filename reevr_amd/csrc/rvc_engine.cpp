@@ -199,7 +199,12 @@ struct rvc_set {
 
   // development net (rvc_debug_set_tuning("guard", 1)): every device allocation of the set sits between two NaN-filled
   // guard bands and starts out NaN-filled itself; rvc_debug_guard_check counts guard bytes that changed
-  struct GuardRec { char *base; size_t bytes; };
+  struct GuardRec {
+    char *base; size_t bytes;
+    // fence mode (guard = 2): the payload ends exactly where its mapping ends, behind it -- and before the mapping -- lie
+    // address ranges that are reserved but NOT mapped: the first byte read or written out of bounds faults
+    bool fenced; void *va; size_t va_bytes, mapped; hipMemGenericAllocationHandle_t handle; char *payload;
+  };
   std::vector<GuardRec> guards;
 
   bool timing = false;
@@ -241,8 +246,44 @@ bool use_device(rvc_set *s) {
 // WRITE lands in a band and is counted by rvc_debug_guard_check; an out-of-bounds or never-written value that is USED
 // is a NaN in the output (0xFFFFFFFF is a quiet NaN), where the unguarded build would read a neighbour's plausible data.
 constexpr size_t kGuardBytes = (size_t)256 << 10;
+// guard = 2, the "electric fence": [unmapped | mapping, payload END-aligned | unmapped]. An out-of-bounds READ -- also one
+// whose value a select then drops, the clamped-loader class of bug -- past the end of an allocation is a GPU memory fault
+// (the process aborts: run under tools/fence_fuzz.py, never inside the test-suite). Under-runs land in the 0xFF slack in
+// front of the payload (or, beyond it, in the lower unmapped range).
+hipError_t fence_alloc(rvc_set *s, void **p, size_t bytes) {
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = s->device;
+  size_t gran = 0;
+  hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+  if (e != hipSuccess || gran == 0) return e != hipSuccess ? e : hipErrorNotSupported;
+  const size_t want = (bytes + 255) & ~(size_t)255;              // (keeps the payload 256-byte aligned)
+  const size_t mapped = (want + gran - 1) / gran * gran;
+  rvc_set::GuardRec r{};
+  r.fenced = true; r.bytes = bytes; r.mapped = mapped; r.va_bytes = mapped + 2 * gran;
+  e = hipMemAddressReserve(&r.va, r.va_bytes, gran, nullptr, 0);
+  if (e != hipSuccess) return e;
+  e = hipMemCreate(&r.handle, mapped, &prop, 0);
+  if (e != hipSuccess) { hipMemAddressFree(r.va, r.va_bytes); return e; }
+  r.base = (char *)r.va + gran;
+  e = hipMemMap(r.base, mapped, 0, r.handle, 0);
+  hipMemAccessDesc acc{};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if (e == hipSuccess) e = hipMemSetAccess(r.base, mapped, &acc, 1);
+  if (e == hipSuccess) e = hipMemsetAsync(r.base, 0xFF, mapped, s->st_main);
+  if (e == hipSuccess) e = hipStreamSynchronize(s->st_main);
+  if (e != hipSuccess) { hipMemUnmap(r.base, mapped); hipMemRelease(r.handle); hipMemAddressFree(r.va, r.va_bytes); return e; }
+  r.payload = r.base + (mapped - want);
+  *p = r.payload;
+  s->guards.push_back(r);
+  return hipSuccess;
+}
+
 hipError_t dev_alloc_raw(rvc_set *s, void **p, size_t bytes) {
   if (!g_tune.guard) return hipMalloc(p, bytes);
+  if (g_tune.guard == 2 && s->streams_ok) return fence_alloc(s, p, bytes);
   char *base = nullptr;
   hipError_t e = hipMalloc(&base, bytes + 2 * kGuardBytes);
   if (e != hipSuccess) return e;
@@ -252,15 +293,19 @@ hipError_t dev_alloc_raw(rvc_set *s, void **p, size_t bytes) {
   if (e == hipSuccess) e = s->streams_ok ? hipStreamSynchronize(s->st_main) : hipDeviceSynchronize();
   if (e != hipSuccess) { hipFree(base); return e; }
   *p = base + kGuardBytes;
-  s->guards.push_back({base, bytes});
+  rvc_set::GuardRec r{};
+  r.base = base; r.bytes = bytes; r.payload = base + kGuardBytes;
+  s->guards.push_back(r);
   return hipSuccess;
 }
 template <typename T> hipError_t dev_alloc(rvc_set *s, T **p, size_t bytes) { return dev_alloc_raw(s, reinterpret_cast<void **>(p), bytes); }
 void dev_free(rvc_set *s, void *p) {
   if (!p) return;
   for (size_t i = 0; i < s->guards.size(); ++i)
-    if (s->guards[i].base + kGuardBytes == (char *)p) {
-      hipFree(s->guards[i].base);
+    if (s->guards[i].payload == (char *)p) {
+      const rvc_set::GuardRec r = s->guards[i];
+      if (r.fenced) { hipMemUnmap(r.base, r.mapped); hipMemRelease(r.handle); hipMemAddressFree(r.va, r.va_bytes); }
+      else hipFree(r.base);
       s->guards.erase(s->guards.begin() + (long)i);
       return;
     }
@@ -2247,12 +2292,14 @@ long rvc_debug_guard_check(rvc_set *s) {
   rvc_set_sync(s);
   std::vector<unsigned char> band(kGuardBytes);
   long bad = 0;
-  for (const rvc_set::GuardRec &g : s->guards)
+  for (const rvc_set::GuardRec &g : s->guards) {
+    if (g.fenced) continue;                     // (fence mode: a stray access has faulted already)
     for (int side = 0; side < 2; ++side) {
       const char *src = side == 0 ? g.base : g.base + kGuardBytes + g.bytes;
       if (hipMemcpy(band.data(), src, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
       for (unsigned char v : band) bad += v != 0xFF;
     }
+  }
   return bad;
 }
 
@@ -2264,7 +2311,6 @@ int rvc_debug_set_tuning(const char *key, int value) {
   else if (k == "sweep_lw") rvc::set_sweep_lane_width(value);
   else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
   else if (k == "subsets") g_tune.subsets = value;
-  else if (k == "fft_stagger") rvc::set_fft_stagger_tuning(value);
   else if (k == "guard") g_tune.guard = value;
   else return 0;
   return 1;

@@ -41,7 +41,6 @@ struct FwdArgs {            // real time-domain segment(s) -> spectrum row(s)
   long long row0;           // absolute row index of row 0
   unsigned long long row_mask;   // row slot = (row0 + r) & row_mask
   int rows;                 // set by the launcher (several small transforms share a workgroup)
-  int stagger;              // set by the launcher: > 0 = the first `stagger` workgroups de-phase themselves (k_fft8_*: stagger_start)
 };
 
 struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency-domain delay line)
@@ -90,7 +89,6 @@ struct InvArgs {            // spectrum row(s) -> last B samples of the inverse 
   unsigned long long add_mask;
   long long add_from;       // add applies for n >= add_from
   int rows;                 // set by the launcher
-  int stagger;              // set by the launcher, see FwdArgs
 };
 
 // One head block per call (the plugin's per-block process()): ingest + forward transform +
@@ -164,7 +162,6 @@ void get_launch_events(hipEvent_t *a, hipEvent_t *b);   // (for launchers in oth
 hipError_t prepare_kernels();
 // measurement hook (rvc_debug_set_tuning "fft_loop"): -1 row-looping 8192-bin transforms by size, 0 never, 1 whenever legal
 void set_fft_loop_tuning(int mode);
-void set_fft_stagger_tuning(int mode);   // "fft_stagger": 1 = de-phase the co-resident workgroups of the one-row 8192-bin transforms
 
 // ---- persistent block-synchronous kernel (RVC_FLAG_PERSISTENT) ------------------------------------------
 // One resident launch serves the plug-in's per-block calls: the host writes a command into a ring in pinned host

@@ -562,22 +562,6 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const TW &T, con
   }
 }
 
-// One-row launches of the 8192-bin transforms keep two 1024-thread workgroups per CU, and every workgroup of a round
-// starts at the same moment: the two load together, run their passes together, store together -- memory and LDS / VALU
-// take turns instead of overlapping. The workgroup that got the UPPER wave slots of its SIMDs (the second one admitted
-// to the CU) therefore sleeps for about half a workgroup's lifetime before it starts -- first round only; later
-// workgroups inherit the phase of the one they replace.
-__device__ __forceinline__ void stagger_start(const int first_round) {
-  __shared__ int s_upper;
-  if (!first_round) return;                                   // (uniform)
-  if (threadIdx.x == 0) s_upper = (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) >= 4u);   // HW_ID.wave_id
-  __syncthreads();
-  if (s_upper) {
-    __builtin_amdgcn_s_sleep(127);
-    __builtin_amdgcn_s_sleep(127);
-  }
-}
-
 template <int LOGB, typename R>
 __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   typedef Plan8<LOGB> P;
@@ -599,8 +583,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
     bx = (int)(item % G);
     c = (int)(item / G);
   }
-  if constexpr (LOGB == 13 && sizeof(R) == 4)
-    stagger_start(a.stagger > 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) < a.stagger);
   const int r_ = bx * P::TPW + sub;
   const bool live = r_ < a.rows;      // a dead sub-transform computes on zeros and stores nothing
   const float *src = a.src + (long long)c * a.src_chan_stride;
@@ -768,8 +750,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   const int r_ = live_row ? r_raw : a.rows - 1;              // dead sub-transforms shadow the last row, store nothing
   const long long nblk = (a.blk0 + r_) * (long long)B;
   if (P::TPW == 1 && (nblk >= a.hi || nblk + B <= a.lo)) return;   // uniform early exit (one transform per workgroup)
-  if constexpr (LOGB == 13 && sizeof(R) == 4)
-    stagger_start(a.stagger > 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) < a.stagger);
   const bool live = live_row && !(nblk >= a.hi || nblk + B <= a.lo);
   const float2 *Y = a.Y + (long long)c * a.y_chan_stride + (long long)r_ * B;
   const C *tw = reinterpret_cast<const C *>(a.tw);
@@ -2157,8 +2137,6 @@ __global__ void __launch_bounds__(256) k_ingest(const IngestArgs a) {
 // ----------------------------------------------------------------------------------------
 // launchers
 // ----------------------------------------------------------------------------------------
-static int stagger_count(int logB, long long items);
-
 template <int LOGB, typename R>
 static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStream_t st) {
   if constexpr (LOGB >= 6) {
@@ -2166,7 +2144,6 @@ static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStre
     const size_t lds = sizeof(cx<R>) * P::LDS_ELEMS * P::TPW;
     FwdArgs b = a;
     b.rows = rows;
-    b.stagger = sizeof(R) == 4 ? stagger_count(LOGB, (long long)rows * channels) : 0;
     RVC_LAUNCH((k_fft8_fwd<LOGB, R>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
   } else {
     const size_t lds = sizeof(cx<R>) << LOGB;
@@ -2181,7 +2158,6 @@ static hipError_t launch_inv_t(const InvArgs &a, int rows, int channels, hipStre
     const size_t lds = sizeof(cx<R>) * P::LDS_ELEMS * P::TPW;
     InvArgs b = a;
     b.rows = rows;
-    b.stagger = sizeof(R) == 4 ? stagger_count(LOGB, (long long)rows * channels) : 0;
     RVC_LAUNCH((k_fft8_inv<LOGB, R>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
   } else {
     const size_t lds = sizeof(cx<R>) << LOGB;
@@ -2225,14 +2201,7 @@ int fft8_table_entries(int logB) {   // entries of the tw8 table the radix-8 ker
 // ---- row-looping big transforms: when, and on how many workgroups --------------------------------------------
 static int g_fft_loop = -1;                      // -1: by size, 0: never, 1: whenever the rows qualify
 void set_fft_loop_tuning(int mode) { g_fft_loop = mode; }
-static int g_fft_stagger = 0;
-void set_fft_stagger_tuning(int mode) { g_fft_stagger = mode; }
-static int stagger_count(int logB, long long items) {   // first-round workgroups of a launch that fills the device twice over
-  if (!g_fft_stagger || logB != 13) return 0;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  return items >= 4ll * cus ? 2 * cus : 0;
-}
+
 constexpr int kLoopLogB = 13;
 static size_t fft_loop_lds_bytes(bool inverse) {   // exchange buffer (+ the inverse kernel's twiddle table)
   typedef Plan8<kLoopLogB> P;

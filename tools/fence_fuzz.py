@@ -1,0 +1,43 @@
+"""Out-of-bounds net, fence mode (rvc_debug_set_tuning("guard", 2)): every device allocation of a set ends exactly at the
+end of its mapping, with unmapped address space behind (and in front of) it -- an out-of-bounds access of a kernel, also
+a read whose value is dropped afterwards, is a GPU memory fault and the process dies. Runs the block-synchronous fuzz
+geometries (all tiling modes, both stream modes) and a lock-step set at the bench's geometry; prints one line per case.
+NOT part of the test-suite: a failure here is an abort.   python tools/fence_fuzz.py [n_seeds]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import reevr_amd
+from reevr_amd import synth
+sys.argv, nseeds = sys.argv[:1], int(sys.argv[1]) if len(sys.argv) > 1 else 12
+exec(open(os.path.join(os.path.dirname(__file__), "guard_diag.py")).read().split("for seed in")[0])
+for seed in [226] + list(range(nseeds)):
+    head, tail, nch, irs, sched, x = case(seed)
+    for tiling in (False, True, "force", "force2"):
+        reevr_amd.set_tuning("guard", 2)
+        s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1), time_tiling=tiling)
+        ok = s.init(head, tail, irs, max_len=max(sched))
+        reevr_amd.set_tuning("guard", 0)
+        assert ok, s.last_error_string
+        pos = 0
+        fin = True
+        for n in sched:
+            fin = fin and bool(np.isfinite(s.process(x[:, pos:pos + n])).all())
+            pos += n
+        assert s.last_error == 0, s.last_error_string
+        print(f"fence ok: seed {seed} head {head} tail {tail} nch {nch} tiling {tiling} finite {fin}", flush=True)
+        s.close()
+import torch
+for nch, head, tail, ir_len, nblk in ((64, 512, 8192, 480000, 16 * 20), (64, 256, 8192, 700000, 32 * 40), (40, 4096, 8192, 100000, 24)):
+    irs = [synth.synth_ir(ir_len - 997 * (c % 5), 1, 600 + c)[0] for c in range(nch)]
+    xx = torch.from_numpy(np.stack([synth.synth_input(head * nblk, 20 + c % 7) for c in range(nch)])).cuda()
+    for tiling in (True, "force", "force2"):
+        reevr_amd.set_tuning("guard", 2)
+        s = reevr_amd.ConvolverSet(nch, time_tiling=tiling)
+        ok = s.init(head, tail, irs, max_len=head)
+        reevr_amd.set_tuning("guard", 0)
+        assert ok, s.last_error_string
+        y = s.process_device_blocks(xx, head)
+        print(f"fence ok: lock-step {nch} x head {head} tail {tail} ir {ir_len} tiling {tiling} tiles {s.tile_rows(0)}/{s.tile_rows(1)} "
+              f"finite {bool(torch.isfinite(y).all())}", flush=True)
+        s.close()
+print("fence fuzz done")
