@@ -353,6 +353,9 @@ int rvc_debug_set_tuning(const char *key, int value);
  * 0xFF-filled itself (0xFFFFFFFF is a NaN: a value read out of bounds, or never written, and USED shows in the output).
  * Returns the number of guard bytes that changed (0 = no out-of-bounds write so far), -1 if the set has no guards. */
 long rvc_debug_guard_check(rvc_set *s);
+/* Fence mode ("guard" = 2) self-check: 1 if the last bytes of the set's first allocation can be copied out and the bytes
+ * right behind it cannot (the range is reserved but unmapped), 0 if both succeed, -1 if the set is not fenced. */
+int rvc_debug_fence_probe(rvc_set *s);
 
 /* Number of visible HIP devices (0 when there is none or the runtime cannot start). */
 int rvc_device_count(void);

@@ -2303,6 +2303,22 @@ long rvc_debug_guard_check(rvc_set *s) {
   return bad;
 }
 
+int rvc_debug_fence_probe(rvc_set *s) {
+  if (!s) return -1;
+  if (!s->kids.empty()) return rvc_debug_fence_probe(s->kids[0]);
+  hipSetDevice(s->device);
+  rvc_set_sync(s);
+  for (const rvc_set::GuardRec &g : s->guards)
+    if (g.fenced) {
+      unsigned char buf[16];
+      const hipError_t in = hipMemcpy(buf, g.base + g.mapped - 16, 16, hipMemcpyDeviceToHost);    // last bytes of the mapping
+      const hipError_t out = hipMemcpy(buf, g.base + g.mapped, 16, hipMemcpyDeviceToHost);        // first bytes behind it
+      (void)hipGetLastError();
+      return (in == hipSuccess && out != hipSuccess) ? 1 : 0;
+    }
+  return -1;
+}
+
 int rvc_debug_set_tuning(const char *key, int value) {
   if (!key) return 0;
   const std::string k(key);

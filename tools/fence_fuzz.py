@@ -37,6 +37,7 @@ for nch, head, tail, ir_len, nblk in ((64, 512, 8192, 480000, 16 * 20), (64, 256
         reevr_amd.set_tuning("guard", 0)
         assert ok, s.last_error_string
         y = s.process_device_blocks(xx, head)
+        assert s._lib.rvc_debug_fence_probe(s._h) == 1, "the range behind an allocation is readable: no fence"
         print(f"fence ok: lock-step {nch} x head {head} tail {tail} ir {ir_len} tiling {tiling} tiles {s.tile_rows(0)}/{s.tile_rows(1)} "
               f"finite {bool(torch.isfinite(y).all())}", flush=True)
         s.close()
