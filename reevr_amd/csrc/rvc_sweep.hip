@@ -125,14 +125,18 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
     V hq[D], xq[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      hq[d] = loadH(part(d));
-      xq[d] = loadX(in_row(d));
+      const int sd = d < P ? d : P - 1;
+      hq[d] = loadH(part(sd));
+      xq[d] = loadX(in_row(sd));
     }
     auto step = [&](const int s, const int u) {     // u = s mod K, compile-time after unrolling
       const V h = hq[u % D];
       const V xin = xq[u % D];
-      hq[u % D] = loadH(part(s + D));
-      xq[u % D] = loadX(in_row(s + D));
+      // (past the last partition the queue re-requests the LAST step's rows -- cache hits -- instead of walking on into
+      //  older delay-line rows nobody needs: those D trailing requests were +6 % HBM traffic on a 32-partition stage)
+      const int sn = s + D < P ? s + D : P - 1;
+      hq[u % D] = loadH(part(sn));
+      xq[u % D] = loadX(in_row(sn));
       __builtin_amdgcn_sched_barrier(0);
       const float hz = packed ? 0.f : h.y;            // first bin: ordinary (re, re, im) / packed (DC gain, Nyquist gain, 0)
       const float h3 = packed ? h.y : h.x;
