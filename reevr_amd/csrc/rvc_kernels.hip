@@ -2243,7 +2243,9 @@ hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int ch
   if (logB == kLoopLogB && !f64 && g_fft_loop != 0 && fwd_rows_loopable(a, rows)) {
     const int nwg = fft_loop_workgroups(false);
     const long long items = (long long)rows * channels;
-    if (nwg > 0 && items < (1ll << 30) && (g_fft_loop > 0 || items >= 4ll * nwg)) {   // (a few rows per workgroup, else the loop is all prologue)
+    // (many rows per workgroup, else the loop is all prologue -- and a looping workgroup needs a CU's whole register file:
+    //  beside another child set's stream of small launches a 4-rows-per-workgroup launch waited for CUs longer than it ran)
+    if (nwg > 0 && items < (1ll << 30) && (g_fft_loop > 0 || items >= 8ll * nwg)) {
       typedef Plan8<kLoopLogB> P;
       FwdArgs b = a;
       b.rows = rows;
@@ -2268,7 +2270,7 @@ hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int ch
   if (logB == kLoopLogB && !f64 && g_fft_loop > 0 && inv_rows_loopable(a, rows)) {
     const int nwg = fft_loop_workgroups(true);
     const long long items = (long long)rows * channels;
-    if (nwg > 0 && items < (1ll << 30) && (g_fft_loop > 0 || items >= 4ll * nwg)) {
+    if (nwg > 0 && items < (1ll << 30) && (g_fft_loop > 0 || items >= 8ll * nwg)) {
       typedef Plan8<kLoopLogB> P;
       InvArgs b = a;
       b.rows = rows;

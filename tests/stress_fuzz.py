@@ -11,7 +11,9 @@ bad = runs = 0
 for seed in range(first, first + count):
     jobs = [(T.test_fuzz_geometry_and_call_pattern, (seed, "default")), (T.test_fuzz_geometry_and_call_pattern, (seed, "force")),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, False)), (T.test_fuzz_block_synchronous_time_tiling, (seed, True)),
-            (T.test_fuzz_block_synchronous_time_tiling, (seed, "force")), (T.test_fuzz_single_stage_sets, (seed,)), (TP.test_fuzz_call_patterns_persistent, (seed,))]
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "force")), (T.test_fuzz_single_stage_sets, (seed,)), (TP.test_fuzz_call_patterns_persistent, (seed,)),
+            (T.test_fuzz_geometry_and_call_pattern, (seed, "force2")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "force2")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "force2_k32")), (T.test_guard_bands_stay_intact_and_outputs_finite, (seed,))]
     for fn, a in jobs:
         runs += 1
         if os.environ.get("STRESS_LOG"):
