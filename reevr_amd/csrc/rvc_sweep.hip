@@ -189,12 +189,111 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
   }
 }
 
+// The own-tile form (SPLIT == 1) with a LINEAR window: the body is unrolled over U = 8 steps whatever K is, the K + U - 1
+// window rows it touches have compile-time indices, and the window is shifted by U rows (register moves, ~6 % of the
+// body's FMAs) at the end of each body. The circular window of fdl_sweep_body has to be unrolled over K steps: 4096 FMAs
+// = 32 KiB of code per walk at K = 32 -- more than the instruction cache feeds to waves in different phases of it (measured:
+// 0.73 / 0.65 / 0.49 of the HBM peak at 4 / 16 / 32 KiB bodies); this body is 8 KiB at K = 32.
+template <int K, int D, int LW, bool NT>
+__device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_tile, const int c) {
+  constexpr int U = 8, WN = K + U - 1;
+  static_assert(U % D == 0 && K % U == 0, "queue / window indexing");
+  typedef typename SweepVec<LW>::T V;
+  constexpr int BPL = LW / 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = wg_tile * 4 + wave;
+  const int bin = tile * (64 * BPL) + lane * BPL;
+  const bool active = bin < a.B;
+  const int b = active ? bin : 0;
+  const int P = a.P;
+  const long long B = a.B;
+  const float2 *__restrict__ Hc = a.H + (long long)c * a.h_chan_stride;
+  const float2 *__restrict__ Xc = a.X + (long long)c * a.x_chan_stride;
+  const unsigned boff = (unsigned)b * (unsigned)sizeof(float2);
+  const long long cbase = a.k0 - a.delay;            // input row meeting partition 0 for output row 0
+  const bool packed = (bin == 0);
+  const V zero = sweep_zero(V());
+  const long long lo = a.x_from > 0 ? a.x_from : 0;
+  const long long safe = a.x_hi >= lo ? a.x_hi : lo;
+  auto validX = [&](long long row) -> bool { return row >= lo && row <= a.x_hi; };
+  auto loadX = [&](long long row) -> V {
+    const long long rr = validX(row) ? row : safe;
+    const char *rp = reinterpret_cast<const char *>(Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B);
+    return sweep_ld<NT>(reinterpret_cast<const V *>(rp + boff));
+  };
+  auto loadH = [&](int i) -> V {
+    const char *rp = reinterpret_cast<const char *>(Hc + (long long)i * B);
+    return sweep_ld<NT>(reinterpret_cast<const V *>(rp + boff));
+  };
+  V acc[K], W[WN];                                   // W[j] = delay-line row cbase - s0 - (U - 1) + j of the current body
+#pragma unroll
+  for (int t = 0; t < K; ++t) acc[t] = zero;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) W[j] = zero;
+  if (P > 0) {
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+      if (validX(cbase + t)) W[U - 1 + t] = loadX(cbase + t);        // (wave-uniform: rows that do not count are not requested)
+    V hq[D], xq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int sd = d < P ? d : P - 1;
+      hq[d] = loadH(sd);
+      xq[d] = loadX(cbase - sd - 1);
+    }
+    auto body = [&](const int s0, auto guard_tag) {
+      constexpr bool GUARD = decltype(guard_tag)::value;
+      V carry = zero;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int s = s0 + u;
+        if (GUARD && s >= P) continue;                                   // (wave-uniform; the last, partial body only)
+        const V h = hq[u % D];
+        const V xin = xq[u % D];
+        const int sn = s + D < P ? s + D : P - 1;                        // (past the last partition: re-request its rows)
+        hq[u % D] = loadH(sn);
+        xq[u % D] = loadX(cbase - sn - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float hz = packed ? 0.f : h.y;
+        const float h3 = packed ? h.y : h.x;
+#pragma unroll
+        for (int t = 0; t < K; ++t) sweep_mac(acc[t], h, W[t - u + U - 1], hz, h3);
+        const V xv = validX(cbase - s - 1) ? xin : zero;                 // the row the NEXT step's output 0 meets
+        if (u < U - 1) W[U - 2 - u] = xv;
+        else carry = xv;
+      }
+#pragma unroll
+      for (int j = WN - 1; j >= U; --j) W[j] = W[j - U];                 // the window moves U rows into the past
+      W[U - 1] = carry;
+    };
+    const int Pfull = P - (P % U);
+    int s0 = 0;
+    for (; s0 < Pfull; s0 += U) body(s0, std::false_type());
+    if (s0 < P) body(s0, std::true_type());
+  }
+  if (active) {
+    float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
+    const float2 *Yb = a.Ybase ? a.Ybase + (long long)c * a.ybase_chan_stride + bin : nullptr;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      V r = acc[t];
+      if (Yb) sweep_add(r, *reinterpret_cast<const V *>(Yb + (long long)((unsigned)(a.k0 + t) & a.ybase_row_mask) * B));
+      *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
+    }
+  }
+}
+
 // grid (bin tiles, channels), block 256. STAGE names the instantiation for profilers (0 head, 1 tail).
 template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
 __global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a) {
   typedef typename SweepVec<LW>::T V;
-  __shared__ V red[SPLIT == 1 ? 1 : SPLIT][K][SPLIT == 1 ? 1 : 64];
-  fdl_sweep_body<K, D, SPLIT, LW, NT>(a, reinterpret_cast<V (*)[K][64]>(red), blockIdx.x, blockIdx.y);
+  if constexpr (SPLIT == 1) {
+    fdl_sweep_own<K, D, LW, NT>(a, blockIdx.x, blockIdx.y);
+  } else {
+    __shared__ V red[SPLIT][K][64];
+    fdl_sweep_body<K, D, SPLIT, LW, NT>(a, reinterpret_cast<V (*)[K][64]>(red), blockIdx.x, blockIdx.y);
+  }
 }
 
 template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
@@ -218,21 +317,17 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
   // level sweeps and long tiles: every wave of the split form reads K rows of window besides its share of the partitions.
   const long long waves1 = (long long)((a.B + 127) / 128) * channels;
   bool split = a.M == kSweepRows && a.Ybase == nullptr && (waves1 < 2048 || a.B >= 2048);
-  if (a.M > kSweepRows) split = (long long)((a.B + 63) / 64) * channels < 2048 && a.P >= 4 * a.M;
-  if (g_sweep_split >= 0) split = g_sweep_split != 0;
+  if (a.M > kSweepRows) split = false;      // (long tiles: every wave of the split form reads K window rows besides its share)
+  else if (g_sweep_split >= 0) split = g_sweep_split != 0;
   // K = 8: 16 B per lane, 4 row pairs ahead, <= 168 VGPRs (3 waves per SIMD), non-temporal loads on the own-tile form;
   // measured against 8 B per lane, deeper queues, 2 / 4 waves per SIMD on MI355X (profiles/r2_sweep_variants.txt).
   // K = 16 / 32 (first level of long delay lines): 8 B per lane -- 2 K registers of accumulators, 2 K of window.
   if (a.M == 32) {
-    if (split) launch_variant<32, 4, STAGE, 2, 4, 2, false>(a, channels, st);
-    else launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);
+    launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);
   } else if (a.M == 16) {
     // 16 B per lane (2 waves per SIMD) on the long rows of a tail stage, 8 B per lane (4 waves) on short ones: measured on
     // MI355X, config 2's 57 x 8192-bin tail: 0.63 vs 0.60 of the HBM peak (profiles/r3_tuning.txt)
-    if (g_sweep_lw == 4 || (g_sweep_lw == 0 && a.B >= 1024)) {
-      if (split) launch_variant<16, 4, STAGE, 4, 4, 2, false>(a, channels, st);
-      else launch_variant<16, 1, STAGE, 4, 4, 2, true>(a, channels, st);
-    } else if (split) launch_variant<16, 4, STAGE, 2, 4, 3, false>(a, channels, st);
+    if (g_sweep_lw == 4 || (g_sweep_lw == 0 && a.B >= 1024)) launch_variant<16, 1, STAGE, 4, 4, 2, true>(a, channels, st);
     else launch_variant<16, 1, STAGE, 2, 4, 3, true>(a, channels, st);
   } else {
     if (split) launch_variant<8, 4, STAGE, 4, 4, 3, false>(a, channels, st);
