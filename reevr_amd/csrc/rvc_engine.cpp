@@ -104,7 +104,7 @@ struct Tile {
 
 // process-wide measurement knobs (rvc_debug_set_tuning); the defaults are what the engine ships with
 struct Tuning {
-  int k1 = 16;            // first-level tile of delay lines with more than kTwoLevelMinP partitions (16 or 32; 8: one level)
+  int k1 = 0;             // first-level tile of delay lines with more than kTwoLevelMinP partitions: 0 by length, else 8 / 16 / 32
   int fft_loop = -1;      // row-looping form of the 8192-bin transforms: -1 by size, 0 never, 1 always
   int subsets = -1;       // children of a many-channel set: -1 by size, else the count
   int guard = 0;          // 1: NaN-filled guard bands around (and NaN poison inside) every device allocation of a set
@@ -676,7 +676,9 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     s->pk_enabled = pk;
     // one level of 8 blocks, or -- long delay lines -- a first level of 16 / 32 blocks with second-level sweeps every 8
     auto first_level = [&](size_t P) -> int {
-      const int k1 = (g_tune.k1 == 32 || g_tune.k1 == 16) ? g_tune.k1 : (int)K;
+      // g_tune.k1: 0 = by length (16 above kTwoLevelMinP partitions, 32 from kLongLineMinP on: measured, profiles/r3_tuning.txt)
+      int k1 = (g_tune.k1 == 32 || g_tune.k1 == 16 || g_tune.k1 == 8) ? g_tune.k1 : ((int)P >= rvc::kLongLineMinP ? 32 : 16);
+      if (force2 && k1 == 8) k1 = 16;
       return (force2 || (int)P > rvc::kTwoLevelMinP) ? k1 : (int)K;
     };
     tA.K1 = pk ? (int)K : first_level(pa);       // (the resident kernel's own tile scheme has one level)
@@ -2325,6 +2327,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   if (k == "k1") g_tune.k1 = value;
   else if (k == "sweep_split") rvc::set_sweep_tuning(value);
   else if (k == "sweep_lw") rvc::set_sweep_lane_width(value);
+  else if (k == "sweep_d") rvc::set_sweep_depth(value);
   else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
   else if (k == "subsets") g_tune.subsets = value;
   else if (k == "guard") g_tune.guard = value;

@@ -245,11 +245,13 @@ int fir_time_tile(int M);
 constexpr int kSweepRows = 8;     // tile of the level the patches work on (second level, or the only one)
 constexpr int kSweepRowsMax = 32; // largest first-level tile
 constexpr int kTwoLevelMinP = 40; // below this many partitions one level of 8 blocks is as good (P / 4 + 10 rows per block)
+constexpr int kLongLineMinP = 80; // from this many partitions on the first level covers 32 blocks (BASELINE configs 1 and 3)
 constexpr int kSweepLagMax = 3;   // a sweep may run up to this many blocks before its first row is due (x_hi that much older)
 // M = 8, 16 or 32 output rows
 hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st);
 // measurement hook (rvc_debug_set_tuning): "sweep_split" -1 auto / 0 own-tile form / 1 partition-split form
 void set_sweep_tuning(int split);
+void set_sweep_depth(int d);         // "sweep_d": 8 = eight row pairs requested ahead in the long-tile sweeps (default 4)
 void set_sweep_lane_width(int lw);   // "sweep_lw": 4 = 16-byte lanes for the 16-block first-level sweeps (default 8-byte)
 
 // A prepared impulse as rvc_set_init_impulse sees it (rvc_impulse.hip): device pointers of the

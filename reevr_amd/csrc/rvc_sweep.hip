@@ -306,9 +306,10 @@ static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
   else hipLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a);
 }
 
-static int g_sweep_split = -1, g_sweep_lw = 0;
+static int g_sweep_split = -1, g_sweep_lw = 0, g_sweep_depth = 0;
 void set_sweep_tuning(int split) { g_sweep_split = split; }
 void set_sweep_lane_width(int lw) { g_sweep_lw = lw; }
+void set_sweep_depth(int d) { g_sweep_depth = d; }
 
 template <int STAGE>
 static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
@@ -322,12 +323,17 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
   // K = 8: 16 B per lane, 4 row pairs ahead, <= 168 VGPRs (3 waves per SIMD), non-temporal loads on the own-tile form;
   // measured against 8 B per lane, deeper queues, 2 / 4 waves per SIMD on MI355X (profiles/r2_sweep_variants.txt).
   // K = 16 / 32 (first level of long delay lines): 8 B per lane -- 2 K registers of accumulators, 2 K of window.
+  const bool deep = g_sweep_depth == 8;           // (measurement: 8 row pairs requested ahead instead of 4)
   if (a.M == 32) {
-    launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);
+    if (deep) launch_variant<32, 1, STAGE, 2, 8, 2, true>(a, channels, st);
+    else launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);
   } else if (a.M == 16) {
     // 16 B per lane (2 waves per SIMD) on the long rows of a tail stage, 8 B per lane (4 waves) on short ones: measured on
     // MI355X, config 2's 57 x 8192-bin tail: 0.63 vs 0.60 of the HBM peak (profiles/r3_tuning.txt)
-    if (g_sweep_lw == 4 || (g_sweep_lw == 0 && a.B >= 1024)) launch_variant<16, 1, STAGE, 4, 4, 2, true>(a, channels, st);
+    if (g_sweep_lw == 4 || (g_sweep_lw == 0 && a.B >= 1024)) {
+      if (deep) launch_variant<16, 1, STAGE, 4, 8, 2, true>(a, channels, st);
+      else launch_variant<16, 1, STAGE, 4, 4, 2, true>(a, channels, st);
+    } else if (deep) launch_variant<16, 1, STAGE, 2, 8, 3, true>(a, channels, st);
     else launch_variant<16, 1, STAGE, 2, 4, 3, true>(a, channels, st);
   } else {
     if (split) launch_variant<8, 4, STAGE, 4, 4, 3, false>(a, channels, st);

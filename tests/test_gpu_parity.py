@@ -629,7 +629,7 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
         s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling="force2" if tiling == "force2_k32" else tiling)
         assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
     finally:
-        reevr_amd.set_tuning("k1", 16)
+        reevr_amd.set_tuning("k1", 0)
     if str(tiling).startswith("force2"):
         assert s.tile_rows(1) == (32 if tiling == "force2_k32" else 16)
     clear_at = int(rng.randint(len(sched) // 4, len(sched))) if rng.randint(0, 3) == 0 else -1
