@@ -23,8 +23,10 @@ for c in FETCH_SIZE WRITE_SIZE; do
   find "$OUT/calib_$c" -name '*counter_collection.csv' -exec cp {} "$OUT/calib_$c.csv" \;
 done
 cd "$ROOT"
+# PMC_ARGS: geometry of the profiled configuration for tools/pmc_summarize.py (default: config 2, two child sets), e.g.
+#   PMC_ARGS="--config 3 --head-log 8 --k1-head 16 --k1-tail 32 --channels 2048" tools/profile_bench.sh out --config 3
 python tools/pmc_summarize.py "$OUT/FETCH_SIZE.csv" "$OUT/WRITE_SIZE.csv" --calib-fetch "$OUT/calib_FETCH_SIZE.csv" \
-  --calib-write "$OUT/calib_WRITE_SIZE.csv" --command "python bench.py $ARGS" -o "$OUT/traffic.json" > "$OUT/traffic.txt" 2>&1
+  --calib-write "$OUT/calib_WRITE_SIZE.csv" --command "python bench.py $ARGS" ${PMC_ARGS:-} -o "$OUT/traffic.json" > "$OUT/traffic.txt" 2>&1
 # the raw per-dispatch traces are large: keep the summaries only
 rm -rf "$OUT/kt" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/calib_FETCH_SIZE "$OUT"/calib_WRITE_SIZE
 python - "$OUT" <<'PY'
