@@ -162,6 +162,7 @@ void get_launch_events(hipEvent_t *a, hipEvent_t *b);   // (for launchers in oth
 hipError_t prepare_kernels();
 // measurement hook (rvc_debug_set_tuning "fft_loop"): -1 row-looping 8192-bin transforms by size, 0 never, 1 whenever legal
 void set_fft_loop_tuning(int mode);
+void set_patch_nt_tuning(int on);    // "patch_nt": 0 = ordinary loads in the stand-alone patch kernel (default: non-temporal for many channels)
 
 // ---- persistent block-synchronous kernel (RVC_FLAG_PERSISTENT) ------------------------------------------
 // One resident launch serves the plug-in's per-block calls: the host writes a command into a ring in pinned host

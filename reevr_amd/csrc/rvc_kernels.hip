@@ -1736,7 +1736,20 @@ __device__ __forceinline__ bool fdl_is_patch(const FirArgs &a) { return a.Yadd !
 
 // NP = the number of partitions the code is unrolled for: exactly a.P when the caller dispatches on it (fdl_patch_any:
 // no request is issued twice), kPatchMax with clamped addresses otherwise (the resident kernel: one code path).
-template <bool PK, int NP>
+// streaming (non-temporal) 16-byte load: the rows a patch reads are far larger than any cache by the time they are read again
+typedef float patch_vf4 __attribute__((ext_vector_type(4)));
+static int g_patch_nt = 1;
+void set_patch_nt_tuning(int on) { g_patch_nt = on; }
+template <bool NT> __device__ __forceinline__ float4 patch_ld(const float2 *p) {
+  if constexpr (NT) {
+    const patch_vf4 v = __builtin_nontemporal_load(reinterpret_cast<const patch_vf4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *reinterpret_cast<const float4 *>(p);
+  }
+}
+
+template <bool PK, int NP, bool NT = false>
 __device__ __forceinline__ void fdl_patch_n(const FirArgs &a, const int bx, const int c) {
   const int bin = bx * 512 + (int)threadIdx.x * 2;
   if (bin >= a.B) return;
@@ -1749,17 +1762,17 @@ __device__ __forceinline__ void fdl_patch_n(const FirArgs &a, const int bx, cons
   for (int i = 0; i < NP; ++i) {                        // clamped addresses: every load is issued, unused ones dropped below
     const int ii = i < a.P ? i : a.P - 1;
     const long long row = cbase - ii, rr = row < 0 ? 0 : row;
-    hv[i] = *reinterpret_cast<const float4 *>(Hc + (long long)ii * B);
+    hv[i] = patch_ld<NT>(Hc + (long long)ii * B);
     const float2 *xr = Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B;
     if constexpr (PK)         // delay-line rows and sweep rows come from other workgroups / launches (see xk_ld)
       xv[i] = xk_ld4(xk_rsrc(xr - bin), (unsigned)bin * 8u);
-    else xv[i] = *reinterpret_cast<const float4 *>(xr);
+    else xv[i] = patch_ld<NT>(xr);
   }
   float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.Yadd) {                                         // (uniform; nullptr: the plain sum, launch_fir's many-channel row form)
     const float2 *yr = a.Yadd + (long long)c * a.yadd_chan_stride;
     if constexpr (PK) y = xk_ld4(xk_rsrc(yr), (unsigned)bin * 8u);
-    else y = *reinterpret_cast<const float4 *>(yr + bin);
+    else y = patch_ld<NT>(yr + bin);
   }
   const bool packed = (bin == 0);
 #pragma unroll
@@ -1785,24 +1798,26 @@ __device__ __forceinline__ void fdl_patch_n(const FirArgs &a, const int bx, cons
 template <bool PK = false>
 __device__ __forceinline__ void fdl_patch_body(const FirArgs &a, const int bx, const int c) { fdl_patch_n<PK, kPatchMax>(a, bx, c); }
 // dispatch on the (launch-uniform) partition count
+template <bool NT>
 __device__ __forceinline__ void fdl_patch_any(const FirArgs &a, const int bx, const int c) {
   static_assert(kPatchMax == 10, "cases below");
   switch (a.P) {
-    case 1: fdl_patch_n<false, 1>(a, bx, c); break;
-    case 2: fdl_patch_n<false, 2>(a, bx, c); break;
-    case 3: fdl_patch_n<false, 3>(a, bx, c); break;
-    case 4: fdl_patch_n<false, 4>(a, bx, c); break;
-    case 5: fdl_patch_n<false, 5>(a, bx, c); break;
-    case 6: fdl_patch_n<false, 6>(a, bx, c); break;
-    case 7: fdl_patch_n<false, 7>(a, bx, c); break;
-    case 8: fdl_patch_n<false, 8>(a, bx, c); break;
-    case 9: fdl_patch_n<false, 9>(a, bx, c); break;
-    default: fdl_patch_n<false, 10>(a, bx, c); break;
+    case 1: fdl_patch_n<false, 1, NT>(a, bx, c); break;
+    case 2: fdl_patch_n<false, 2, NT>(a, bx, c); break;
+    case 3: fdl_patch_n<false, 3, NT>(a, bx, c); break;
+    case 4: fdl_patch_n<false, 4, NT>(a, bx, c); break;
+    case 5: fdl_patch_n<false, 5, NT>(a, bx, c); break;
+    case 6: fdl_patch_n<false, 6, NT>(a, bx, c); break;
+    case 7: fdl_patch_n<false, 7, NT>(a, bx, c); break;
+    case 8: fdl_patch_n<false, 8, NT>(a, bx, c); break;
+    case 9: fdl_patch_n<false, 9, NT>(a, bx, c); break;
+    default: fdl_patch_n<false, 10, NT>(a, bx, c); break;
   }
 }
 
-template <int STAGE>
-__global__ void __launch_bounds__(256) k_fdl_patch(const FirArgs a) { fdl_patch_any(a, blockIdx.x, blockIdx.y); }
+// NT: non-temporal loads (many channels: nothing of a row survives in a cache until the next patch reads it)
+template <int STAGE, bool NT>
+__global__ void __launch_bounds__(256) k_fdl_patch(const FirArgs a) { fdl_patch_any<NT>(a, blockIdx.x, blockIdx.y); }
 
 // One launch per block of the streaming path: workgroups [0, n_audio) run block k's audio path
 // (fused_audio<FOLD = true>), the rest compute sum_{i>=2} H_i X_{k+1-i} for block k+1 (fir_row_body;
@@ -2379,8 +2394,9 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   // 16 bytes per lane, all requests of a thread in flight at once; the row kernel below is built for the latency of a few)
   if (a.M == 1 && a.P <= kPatchMax && (a.B % 2) == 0 && (a.Yadd != nullptr || (long long)channels * a.B >= (1ll << 18))) {
     const dim3 grid((a.B + 511) / 512, channels), block(256);
-    if (a.tag == 0) RVC_LAUNCH((k_fdl_patch<0>), grid, block, 0, st, a);
-    else RVC_LAUNCH((k_fdl_patch<1>), grid, block, 0, st, a);
+    const bool nt = g_patch_nt != 0 && (long long)channels * a.B >= (1ll << 20);    // (a few channels: rows stay in the L2 / MALL)
+    if (a.tag == 0) { if (nt) RVC_LAUNCH((k_fdl_patch<0, true>), grid, block, 0, st, a); else RVC_LAUNCH((k_fdl_patch<0, false>), grid, block, 0, st, a); }
+    else { if (nt) RVC_LAUNCH((k_fdl_patch<1, true>), grid, block, 0, st, a); else RVC_LAUNCH((k_fdl_patch<1, false>), grid, block, 0, st, a); }
     return hipGetLastError();
   }
   if (a.M == 1) {                         // one block: the latency-oriented row kernel
