@@ -1846,7 +1846,7 @@ k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int 
 // The same patch by ONE wave for the channel(s) of one audio workgroup (head blocks of 128 / 256 / 512: 4 / 2 / 1 channels
 // per workgroup, 512 row entries in all): 4 x (64 lanes x 2 bins), the partitions in rounds of three (24 requests of
 // 16 bytes per lane in flight).
-template <int LOGB>
+template <int LOGB, bool NT>
 __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, const int channels) {
   typedef Plan8<LOGB> P8;
   static_assert(P8::B * P8::TPW == 512 && P8::B >= 128, "one wave patches 512 row entries");
@@ -1870,7 +1870,7 @@ __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, c
     Hq[q] = a.H + (long long)c * a.h_chan_stride + off;
     Xq[q] = a.X + (long long)c * a.x_chan_stride + off;
     Yq[q] = a.Y + (long long)c * a.y_chan_stride + off;
-    y[q] = *reinterpret_cast<const float4 *>(a.Yadd + (long long)c * a.yadd_chan_stride + off);
+    y[q] = patch_ld<NT>(a.Yadd + (long long)c * a.yadd_chan_stride + off);
   }
   for (int i0 = 0; i0 < a.P; i0 += CH) {                 // (uniform)
     float4 hv[CH][NQ], xv[CH][NQ];
@@ -1881,8 +1881,8 @@ __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, c
       const long long ho = (long long)ii * B, xo = (long long)((unsigned long long)rr & a.x_row_mask) * B;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        hv[u][q] = *reinterpret_cast<const float4 *>(Hq[q] + ho);
-        xv[u][q] = *reinterpret_cast<const float4 *>(Xq[q] + xo);
+        hv[u][q] = patch_ld<NT>(Hq[q] + ho);
+        xv[u][q] = patch_ld<NT>(Xq[q] + xo);
       }
     }
 #pragma unroll
@@ -1917,11 +1917,13 @@ __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, c
 // given ALL AT ONCE, and the launch dispatches a quarter of the waves k_fused_block2 does (256-thread audio workgroups of
 // which three waves retire at once + separate 256-thread patch workgroups, one resident per CU).
 // Measured for 1024 channels at head 512: 17.4 -> 17.0 us per launch; where the rest goes: DESIGN.md section 7.
-template <int LOGB>
+// NT: the patch wave's rows with non-temporal loads (many channels: they are long gone from every cache when the next
+// block reads them again)
+template <int LOGB, bool NT>
 __global__ void __launch_bounds__(128) k_fused_block2w(const FusedArgs a, const FirArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (threadIdx.x < 64) fused_audio<LOGB, true, false, true>(a, smem_raw, blockIdx.x);
-  else if (f.P > 0) fdl_patch_wave<LOGB>(f, blockIdx.x, a.channels);
+  else if (f.P > 0) fdl_patch_wave<LOGB, NT>(f, blockIdx.x, a.channels);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2330,7 +2332,8 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
   const bool patch = f.Yadd != nullptr && f.P <= kPatchMax && f.P >= 1;
   if constexpr (LOGB >= 7 && LOGB <= 9) {     // the audio workgroup is ONE wave: audio wave + patch wave per workgroup
     if (patch || f.P <= 0) {
-      RVC_LAUNCH((k_fused_block2w<LOGB>), dim3(n_audio), dim3(128), lds, st, b, f);
+      if (g_patch_nt >= 2 && (long long)channels * P::B >= (1ll << 19)) RVC_LAUNCH((k_fused_block2w<LOGB, true>), dim3(n_audio), dim3(128), lds, st, b, f);
+      else RVC_LAUNCH((k_fused_block2w<LOGB, false>), dim3(n_audio), dim3(128), lds, st, b, f);
       return hipGetLastError();
     }
   }
