@@ -692,6 +692,35 @@ def main():
                         "partition (FFTConvolver.cpp:176-187): physical bytes = SURVEY.md 8d algorithmic bytes"}
             if roof is not None:
                 roof["alg_frac_reference_schedule"] = side["reference_schedule"]["frac_of_hbm_peak"]
+        if subsets > 1 and not args.tune:
+            # the same loop on ONE queue (no child sets): every launch has the device to itself, so bytes per launch / mean
+            # launch duration is each family's own efficiency -- the contract's literal per-launch roofline
+            reevr_amd.set_tuning("subsets", 1)
+            try:
+                qs = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, True, bool(args.bg_stream), blocks, irs=irs, x=x)
+            finally:
+                reevr_amd.set_tuning("subsets", -1)
+            qs.preroll()
+            qsteps = max(2, args.steps // 2)
+            qrate, qms = qs.timed(qsteps, 1)
+            qprobe = qs.check_probe()
+            qs.conv.check()
+            qkern = qs.kernel_times(KERNEL_NAMES)
+            qexe = executed_bytes(qs.conv, nch, head, tail, ir_len, host_block, qs.tiled)
+            qroof, _ = roofline_tables(qkern, qexe, {})
+            qs.close()
+            qdom = max(qroof, key=lambda k: qroof[k]["ms_per_step"])
+            side["single_queue"] = {
+                "value": round(qrate / 1e6, 3), "unit": "Msamples/s", "steps": qsteps, "ms_per_step": round(qms, 4),
+                "probe_ok": bool(qprobe and qprobe["ok"]),
+                "roofline": {"kernel": qdom, "frac": qroof[qdom]["frac"], "achieved": qroof[qdom]["achieved_GBs"],
+                             "bytes_per_launch": qroof[qdom]["bytes_per_launch"], "avg_launch_ms": qroof[qdom]["avg_launch_ms"]},
+                "roofline_all": {k: {"launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"],
+                                     "bytes_per_launch": v["bytes_per_launch"], "frac": v["frac"]} for k, v in qroof.items()},
+                "note": "RVC_FLAG_NO_SUBSETS-equivalent run of the headline loop: all channels in one set on one queue; "
+                        "frac = bytes per launch / mean launch duration / 8 TB/s (no concurrent launch shares the device)"}
+            if roof is not None:
+                roof["frac_single_queue"] = qroof[qdom]["frac"] if qdom == roof["kernel"] else qroof.get(roof["kernel"], {}).get("frac")
         if args.config == 2:
             side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
     if world == 1 and args.cpu_seconds > 0 and lockstep_cfg:
