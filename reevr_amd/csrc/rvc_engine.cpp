@@ -2331,6 +2331,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
   else if (k == "subsets") g_tune.subsets = value;
   else if (k == "patch_nt") rvc::set_patch_nt_tuning(value);
+  else if (k == "block_occ") rvc::set_block_occ3_tuning(value);
   else if (k == "guard") g_tune.guard = value;
   else return 0;
   return 1;

@@ -297,7 +297,7 @@ __device__ __forceinline__ cx<R> wave_partner(const cx<R> *v, const int tid, con
 // INLDS: the pass twiddles are parked in the thread's own column of an LDS table ([slot][thread]: written and read by the
 // same thread, so no barrier) and read back one pass ahead -- for the inverse loop kernel, whose register budget they
 // do not fit in (a spilled twiddle is reloaded behind a wait for EVERY outstanding load, the row prefetch included).
-template <int LOGB, typename R, bool HELD_ = false, bool CONJ_ = false, bool INLDS_ = false> struct Tw8 {
+template <int LOGB, typename R, bool HELD_ = false, bool CONJ_ = false, bool INLDS_ = false, bool NOEAGER_ = false> struct Tw8 {
   typedef Plan8<LOGB> P;
   static constexpr bool HELD = HELD_;
   static constexpr bool CONJ = CONJ_;   // HELD: held conjugated (the inverse kernel: no per-pass negation, no second copy)
@@ -305,7 +305,8 @@ template <int LOGB, typename R, bool HELD_ = false, bool CONJ_ = false, bool INL
   static constexpr int LDS_SLOTS = (P::N8 > 1 ? P::N8 - 1 : 0) * P::S * 3;
   cx<R> *ltab = nullptr;     // INLDS: [LDS_SLOTS][NT]
   // eager (register) prefetch only where it fits the 128-VGPR budget of a 1024-thread workgroup
-  static constexpr bool EAGER = !HELD_ && (sizeof(R) == 4 ? (LOGB <= 12) : (LOGB <= 11));
+  // NOEAGER: fetch per pass also where the registers would hold them (the lean many-channel per-block kernel: -22 registers)
+  static constexpr bool EAGER = !HELD_ && !NOEAGER_ && (sizeof(R) == 4 ? (LOGB <= 12) : (LOGB <= 11));
   static constexpr int NH = (HELD_ && !INLDS_) ? (P::N8 > 1 ? P::N8 - 1 : 1) : 1;
   // INLDS: the three twiddles of pass j, slot s
   __device__ __forceinline__ void held_from_lds(const int j, const int s, cx<R> *w) const {
@@ -1135,9 +1136,16 @@ __device__ __forceinline__ void xk_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, kXkAux);
 }
 
-template <int LOGB, bool FOLD, bool PK = false, bool SOLO = false>
+// LEAN (many-channel launches, k_fused_block2w<.., 4>): nothing is requested before it is needed -- the twiddles per pass,
+// the IR rows / accumulator / previous spectrum behind the forward transform, the inverse split's twiddles behind the MAC,
+// the tail stream behind the inverse transform. Every one of those requests then sits on the wave's dependent chain, which
+// is what the default form avoids for the plug-in's handful of channels; with thousands of channels the chain of one wave is
+// hidden by the other waves, and at <= 128 registers there are four of them per SIMD instead of two.
+template <int LOGB, bool FOLD, bool PK = false, bool SOLO = false, bool LEAN = false>
 __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, const int wg) {
   static_assert(!SOLO || Plan8<LOGB>::WG == 64, "SOLO: the workgroup's transform(s) live in one wave");
+  static_assert(!LEAN || (!PK && FOLD), "LEAN: the folded launch path only");
+  typedef Tw8<LOGB, float, false, false, false, LEAN> TW;
   typedef Plan8<LOGB> P;
   typedef cx<float> C;
   constexpr int B = P::B;
@@ -1156,7 +1164,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
 
   // 0. everything that does not depend on the audio is requested first: twiddles, split
   //    twiddles, partition 0 of the IR and the pre-multiplied accumulator
-  Tw8<LOGB, float> T;
+  TW T;
   T.load(tw8, tw, tid);
   const float2 *H0 = a.H0 + (long long)c * a.h_chan_stride;
   const float2 *Ypre = a.Ypre + (long long)c * a.ypre_chan_stride;
@@ -1164,22 +1172,47 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   float2 h0[P::E], ypre[P::E];
   float2 h1[FOLD ? P::E : 1], xp[FOLD ? P::E : 1];
   const bool fold = FOLD && a.H1 && a.k >= 1;     // partition 1 exists and block k-1 is not before time 0
+  auto load_wso = [&]() {
 #pragma unroll
-  for (int e = 0; e < P::E; ++e) {
-    wso[e] = wsplit[P::out_idx(tid, e)];
-    wsi[e] = wsplit[P::in_idx(tid, e)];
-    h0[e] = H0[P::out_idx(tid, e)];
-    if constexpr (PK) ypre[e] = xk_ld2(xk_rsrc(Ypre), (unsigned)P::out_idx(tid, e) * 8u);
-    else ypre[e] = Ypre[P::out_idx(tid, e)];
-    if constexpr (FOLD) {
-      // (clamped to row k when there is no block k-1: any resident row, the product is dropped below)
-      const float2 *H1 = (fold ? a.H1 : a.H0) + (long long)c * a.h_chan_stride;
-      const float2 *Xp = a.Xrow + (long long)c * a.x_chan_stride +
-                         (long long)((unsigned long long)(fold ? a.k - 1 : a.k) & a.x_row_mask) * B;
-      h1[e] = H1[P::out_idx(tid, e)];
-      xp[e] = Xp[P::out_idx(tid, e)];
+    for (int e = 0; e < P::E; ++e) wso[e] = wsplit[P::out_idx(tid, e)];
+  };
+  auto load_wsi = [&]() {
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) wsi[e] = wsplit[P::in_idx(tid, e)];
+  };
+  auto load_mac = [&]() {
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      h0[e] = H0[P::out_idx(tid, e)];
+      if constexpr (PK) ypre[e] = xk_ld2(xk_rsrc(Ypre), (unsigned)P::out_idx(tid, e) * 8u);
+      else ypre[e] = Ypre[P::out_idx(tid, e)];
+      if constexpr (FOLD) {
+        // (clamped to row k when there is no block k-1: any resident row, the product is dropped below)
+        const float2 *H1 = (fold ? a.H1 : a.H0) + (long long)c * a.h_chan_stride;
+        const float2 *Xp = a.Xrow + (long long)c * a.x_chan_stride +
+                           (long long)((unsigned long long)(fold ? a.k - 1 : a.k) & a.x_row_mask) * B;
+        h1[e] = H1[P::out_idx(tid, e)];
+        xp[e] = Xp[P::out_idx(tid, e)];
+      }
     }
-  }
+  };
+  // (FOLD) yp = Ypre + H_1 X_{k-1} needs nothing of this block: formed before the transform in the default form, so that
+  // only ONE accumulator row per value stays live across it
+  auto fold_in = [&]() {
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int e = 0; e < P::E; ++e) {
+        if (fold) {
+          const float2 g = h1[e], x = xp[e];
+          float2 yp = ypre[e];
+          if (P::out_idx(tid, e) == 0) yp = make_float2(fmaf(g.x, x.x, yp.x), fmaf(g.y, x.y, yp.y));
+          else yp = make_float2(fmaf(g.x, x.x, fmaf(-g.y, x.y, yp.x)), fmaf(g.x, x.y, fmaf(g.y, x.x, yp.y)));
+          ypre[e] = yp;
+        }
+      }
+    }
+  };
+  if constexpr (!LEAN) { load_wso(); load_wsi(); load_mac(); }
   // 1. load the segment: history from the ring, this call's samples from `in` (and append them
   //    to the ring), zero for the not-yet-played rest of block k and for time < 0
   // (persistent kernel: calls on even sample positions with 8-byte aligned buffers move sample PAIRS per access. Single
@@ -1192,18 +1225,21 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   // memory round trip behind the inverse transform (calls on even sample positions: pairs of samples per access).
   const bool pre_add = PK ? wide : (((a.n0 | a.n1) & 1) == 0);
   float2 addv[P::E / 2];
-  if constexpr (!PK) {
-    if (pre_add && a.add) {
-      const float *addc = a.add + (long long)c * a.add_chan_stride;
-      int q = 0;
+  auto load_addv = [&]() {
+    if constexpr (!PK) {
+      if (pre_add && a.add) {
+        const float *addc = a.add + (long long)c * a.add_chan_stride;
+        int q = 0;
 #pragma unroll
-      for (int e = 0; e < P::E; ++e)
-        if (!P::out_is_low(e)) {
-          const long long n = a.k * (long long)B + 2 * P::out_idx(tid, e) - B;
-          addv[q++] = *reinterpret_cast<const float2 *>(addc + ((unsigned long long)(n >= a.add_from ? n : a.add_from) & a.add_mask));
-        }
+        for (int e = 0; e < P::E; ++e)
+          if (!P::out_is_low(e)) {
+            const long long n = a.k * (long long)B + 2 * P::out_idx(tid, e) - B;
+            addv[q++] = *reinterpret_cast<const float2 *>(addc + ((unsigned long long)(n >= a.add_from ? n : a.add_from) & a.add_mask));
+          }
+      }
     }
-  }
+  };
+  if constexpr (!LEAN) load_addv();
   if constexpr (PK) {
     if (wide && a.add) {
       const __amdgpu_buffer_rsrc_t radd = xk_rsrc(a.add + (long long)c * a.add_chan_stride);
@@ -1267,23 +1303,14 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       }
     }
   }
-  // (FOLD) yp = Ypre + H_1 X_{k-1} needs nothing of this block: formed now, so that only ONE accumulator row per value
-  // stays live across the transform (48 VGPRs fewer -> more of the appended workgroups resident beside the audio waves)
-  if constexpr (FOLD) {
-#pragma unroll
-    for (int e = 0; e < P::E; ++e) {
-      if (fold) {
-        const float2 g = h1[e], x = xp[e];
-        float2 yp = ypre[e];
-        if (P::out_idx(tid, e) == 0) yp = make_float2(fmaf(g.x, x.x, yp.x), fmaf(g.y, x.y, yp.y));
-        else yp = make_float2(fmaf(g.x, x.x, fmaf(-g.y, x.y, yp.x)), fmaf(g.x, x.y, fmaf(g.y, x.x, yp.y)));
-        ypre[e] = yp;
-      }
-    }
-  }
+  if constexpr (!LEAN) fold_in();
   // 2. forward transform, real split; X_k goes to the delay line and, times H0 plus the
   //    pre-multiplied accumulator, becomes Y_k
-  fft8_core<LOGB, false, float, SOLO>(v, lds, T, tid);
+  fft8_core<LOGB, false, float, SOLO, TW>(v, lds, T, tid);
+  if constexpr (LEAN) {
+    __builtin_amdgcn_sched_barrier(0);           // (nothing of what follows is requested above the transform)
+    load_wso(); load_mac(); fold_in();
+  }
   // The real split pairs bin k with bin B - k. Head blocks of 64 / 512: the whole transform lives in one wave and the
   // partner arrives through a lane reversal (wave_partner: ds_bpermute, no LDS round trip, no barrier); else through LDS.
   constexpr bool kWS = WaveSplit<LOGB>::ok;
@@ -1334,6 +1361,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
     for (int e = 0; e < P::E; ++e) lds[lpad(P::out_idx(tid, e))] = y[e];
     core_sync<SOLO>();
   }
+  if constexpr (LEAN) load_wsi();
   const float sc = 0.5f / (float)B;
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
@@ -1354,7 +1382,11 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
     }
   }
   if constexpr (!kWS) core_sync<SOLO>();
-  fft8_core<LOGB, true, float, SOLO>(v, lds, T, tid);
+  fft8_core<LOGB, true, float, SOLO, TW>(v, lds, T, tid);
+  if constexpr (LEAN) {
+    __builtin_amdgcn_sched_barrier(0);
+    load_addv();
+  }
   // 4. the block's samples are z[B/2 .. B); only [n0, n1) is wanted; add the tail contribution
   float *out = a.out + (long long)c * a.out_chan_stride;
   const float *add = a.add ? a.add + (long long)c * a.add_chan_stride : nullptr;
@@ -1738,8 +1770,9 @@ __device__ __forceinline__ bool fdl_is_patch(const FirArgs &a) { return a.Yadd !
 // no request is issued twice), kPatchMax with clamped addresses otherwise (the resident kernel: one code path).
 // streaming (non-temporal) 16-byte load: the rows a patch reads are far larger than any cache by the time they are read again
 typedef float patch_vf4 __attribute__((ext_vector_type(4)));
-static int g_patch_nt = 1;
+static int g_patch_nt = 1, g_block_occ3 = 3;     // g_block_occ3: waves per SIMD of the many-channel per-block kernel (2 / 3 / 4)
 void set_patch_nt_tuning(int on) { g_patch_nt = on; }
+void set_block_occ3_tuning(int on) { g_block_occ3 = on; }
 template <bool NT> __device__ __forceinline__ float4 patch_ld(const float2 *p) {
   if constexpr (NT) {
     const patch_vf4 v = __builtin_nontemporal_load(reinterpret_cast<const patch_vf4 *>(p));
@@ -1846,11 +1879,11 @@ k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int 
 // The same patch by ONE wave for the channel(s) of one audio workgroup (head blocks of 128 / 256 / 512: 4 / 2 / 1 channels
 // per workgroup, 512 row entries in all): 4 x (64 lanes x 2 bins), the partitions in rounds of three (24 requests of
 // 16 bytes per lane in flight).
-template <int LOGB, bool NT>
+template <int LOGB, bool NT, int CH = 3>
 __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, const int channels) {
   typedef Plan8<LOGB> P8;
   static_assert(P8::B * P8::TPW == 512 && P8::B >= 128, "one wave patches 512 row entries");
-  constexpr int NQ = 4, CH = 3;
+  constexpr int NQ = 4;
   constexpr int QPC = P8::B / 128;                        // 128-bin pieces per channel
   const int lane = (int)threadIdx.x & 63;
   const long long B = a.B;
@@ -1917,13 +1950,20 @@ __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, c
 // given ALL AT ONCE, and the launch dispatches a quarter of the waves k_fused_block2 does (256-thread audio workgroups of
 // which three waves retire at once + separate 256-thread patch workgroups, one resident per CU).
 // Measured for 1024 channels at head 512: 17.4 -> 17.0 us per launch; where the rest goes: DESIGN.md section 7.
-// NT: the patch wave's rows with non-temporal loads (many channels: they are long gone from every cache when the next
-// block reads them again)
-template <int LOGB, bool NT>
-__global__ void __launch_bounds__(128) k_fused_block2w(const FusedArgs a, const FirArgs f) {
+// NT: the patch wave's rows with non-temporal loads (measurement, patch_nt = 2: no gain for config 2, +3 % for config 1).
+// OCC3: the register budget of THREE waves per SIMD (168; the audio path wants 170-174 and takes 3 spilled dwords for it):
+// six instead of four workgroups resident per CU. Worth nothing for a handful of channels (and a spill on the plug-in's
+// latency path), but launches of thousands of channels run in rounds of resident workgroups and more of them overlap one
+// round's latency-bound end with the next one's loads: measured at 4096 channels 52.4 -> 48.8 us per launch (0.62 -> 0.66 of
+// the HBM peak), 8192 channels 105.7 -> 101.6 us (profiles/r3_tuning.txt). Round 2's "occupancy is not what bounds this
+// launch" was measured with 1024 channels, where four workgroups per CU are the whole launch.
+// OCC = waves per SIMD the register budget is held to: 2 (the default form, 170-174 registers), 3 (168, a few spilled dwords)
+// or 4 (128: the LEAN form of the audio path, two partitions per round in the patch wave).
+template <int LOGB, bool NT, int OCC>
+__global__ void __launch_bounds__(128, OCC) k_fused_block2w(const FusedArgs a, const FirArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (threadIdx.x < 64) fused_audio<LOGB, true, false, true>(a, smem_raw, blockIdx.x);
-  else if (f.P > 0) fdl_patch_wave<LOGB, NT>(f, blockIdx.x, a.channels);
+  if (threadIdx.x < 64) fused_audio<LOGB, true, false, true, OCC == 4>(a, smem_raw, blockIdx.x);
+  else if (f.P > 0) fdl_patch_wave<LOGB, NT, OCC == 4 ? 2 : 3>(f, blockIdx.x, a.channels);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2332,8 +2372,11 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
   const bool patch = f.Yadd != nullptr && f.P <= kPatchMax && f.P >= 1;
   if constexpr (LOGB >= 7 && LOGB <= 9) {     // the audio workgroup is ONE wave: audio wave + patch wave per workgroup
     if (patch || f.P <= 0) {
-      if (g_patch_nt >= 2 && (long long)channels * P::B >= (1ll << 19)) RVC_LAUNCH((k_fused_block2w<LOGB, true>), dim3(n_audio), dim3(128), lds, st, b, f);
-      else RVC_LAUNCH((k_fused_block2w<LOGB, false>), dim3(n_audio), dim3(128), lds, st, b, f);
+      const int occ = n_audio >= 1024 ? g_block_occ3 : 2;             // (many workgroups: several rounds of resident ones)
+      if (g_patch_nt == 2 && (long long)channels * P::B >= (1ll << 19)) RVC_LAUNCH((k_fused_block2w<LOGB, true, 2>), dim3(n_audio), dim3(128), lds, st, b, f);
+      else if (occ == 4) RVC_LAUNCH((k_fused_block2w<LOGB, false, 4>), dim3(n_audio), dim3(128), lds, st, b, f);
+      else if (occ == 3) RVC_LAUNCH((k_fused_block2w<LOGB, false, 3>), dim3(n_audio), dim3(128), lds, st, b, f);
+      else RVC_LAUNCH((k_fused_block2w<LOGB, false, 2>), dim3(n_audio), dim3(128), lds, st, b, f);
       return hipGetLastError();
     }
   }
