@@ -1770,9 +1770,9 @@ __device__ __forceinline__ bool fdl_is_patch(const FirArgs &a) { return a.Yadd !
 // no request is issued twice), kPatchMax with clamped addresses otherwise (the resident kernel: one code path).
 // streaming (non-temporal) 16-byte load: the rows a patch reads are far larger than any cache by the time they are read again
 typedef float patch_vf4 __attribute__((ext_vector_type(4)));
-static int g_patch_nt = 1, g_block_occ3 = 3;     // g_block_occ3: waves per SIMD of the many-channel per-block kernel (2 / 3 / 4)
+static int g_patch_nt = 1, g_block_occ = 0;      // g_block_occ = 4: the lean 4-waves-per-SIMD per-block kernel for many-channel launches
 void set_patch_nt_tuning(int on) { g_patch_nt = on; }
-void set_block_occ3_tuning(int on) { g_block_occ3 = on; }
+void set_block_occ3_tuning(int on) { g_block_occ = on; }
 template <bool NT> __device__ __forceinline__ float4 patch_ld(const float2 *p) {
   if constexpr (NT) {
     const patch_vf4 v = __builtin_nontemporal_load(reinterpret_cast<const patch_vf4 *>(p));
@@ -1951,19 +1951,20 @@ __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, c
 // which three waves retire at once + separate 256-thread patch workgroups, one resident per CU).
 // Measured for 1024 channels at head 512: 17.4 -> 17.0 us per launch; where the rest goes: DESIGN.md section 7.
 // NT: the patch wave's rows with non-temporal loads (measurement, patch_nt = 2: no gain for config 2, +3 % for config 1).
-// OCC3: the register budget of THREE waves per SIMD (168; the audio path wants 170-174 and takes 3 spilled dwords for it):
-// six instead of four workgroups resident per CU. Worth nothing for a handful of channels (and a spill on the plug-in's
-// latency path), but launches of thousands of channels run in rounds of resident workgroups and more of them overlap one
-// round's latency-bound end with the next one's loads: measured at 4096 channels 52.4 -> 48.8 us per launch (0.62 -> 0.66 of
-// the HBM peak), 8192 channels 105.7 -> 101.6 us (profiles/r3_tuning.txt). Round 2's "occupancy is not what bounds this
-// launch" was measured with 1024 channels, where four workgroups per CU are the whole launch.
-// OCC = waves per SIMD the register budget is held to: 2 (the default form, 170-174 registers), 3 (168, a few spilled dwords)
-// or 4 (128: the LEAN form of the audio path, two partitions per round in the patch wave).
-template <int LOGB, bool NT, int OCC>
-__global__ void __launch_bounds__(128, OCC) k_fused_block2w(const FusedArgs a, const FirArgs f) {
+// Registers: with the audio path's requests grouped by phase (fused_audio: load_wso / load_mac / fold_in / load_addv) the
+// kernel needs 154 (B = 512) ... 166 registers: THREE waves per SIMD, six workgroups per CU, without a spill. Round 2's form
+// (170-174 registers, two waves per SIMD) took 52.4 us per 4096-channel launch, this one 48.9 us (0.62 -> 0.66 of the HBM
+// peak): launches of thousands of channels run in rounds of resident workgroups, and more resident ones overlap one round's
+// latency-bound end with the next one's loads (round 2's "occupancy is not what bounds this launch" was measured with 1024
+// channels, where four workgroups per CU are the whole launch).
+// LEAN (measurement, block_occ = 4): the register budget of FOUR waves per SIMD -- the lean form of the audio path, two
+// partitions per round in the patch wave, 7-11 spilled dwords. Measured: config 2 52.9 vs 48.9 us per launch, config 1
+// 87 vs 81 us, config 3 (256-bin heads) 16.9 vs 17.7 us: every request on the wave's chain costs more than the fourth wave buys.
+template <int LOGB, bool NT, bool LEAN>
+__global__ void __launch_bounds__(128, LEAN ? 4 : 2) k_fused_block2w(const FusedArgs a, const FirArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (threadIdx.x < 64) fused_audio<LOGB, true, false, true, OCC == 4>(a, smem_raw, blockIdx.x);
-  else if (f.P > 0) fdl_patch_wave<LOGB, NT, OCC == 4 ? 2 : 3>(f, blockIdx.x, a.channels);
+  if (threadIdx.x < 64) fused_audio<LOGB, true, false, true, LEAN>(a, smem_raw, blockIdx.x);
+  else if (f.P > 0) fdl_patch_wave<LOGB, NT, LEAN ? 2 : 3>(f, blockIdx.x, a.channels);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2372,11 +2373,9 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
   const bool patch = f.Yadd != nullptr && f.P <= kPatchMax && f.P >= 1;
   if constexpr (LOGB >= 7 && LOGB <= 9) {     // the audio workgroup is ONE wave: audio wave + patch wave per workgroup
     if (patch || f.P <= 0) {
-      const int occ = n_audio >= 1024 ? g_block_occ3 : 2;             // (many workgroups: several rounds of resident ones)
-      if (g_patch_nt == 2 && (long long)channels * P::B >= (1ll << 19)) RVC_LAUNCH((k_fused_block2w<LOGB, true, 2>), dim3(n_audio), dim3(128), lds, st, b, f);
-      else if (occ == 4) RVC_LAUNCH((k_fused_block2w<LOGB, false, 4>), dim3(n_audio), dim3(128), lds, st, b, f);
-      else if (occ == 3) RVC_LAUNCH((k_fused_block2w<LOGB, false, 3>), dim3(n_audio), dim3(128), lds, st, b, f);
-      else RVC_LAUNCH((k_fused_block2w<LOGB, false, 2>), dim3(n_audio), dim3(128), lds, st, b, f);
+      if (g_patch_nt == 2 && (long long)channels * P::B >= (1ll << 19)) RVC_LAUNCH((k_fused_block2w<LOGB, true, false>), dim3(n_audio), dim3(128), lds, st, b, f);
+      else if (g_block_occ == 4 && n_audio >= 1024) RVC_LAUNCH((k_fused_block2w<LOGB, false, true>), dim3(n_audio), dim3(128), lds, st, b, f);
+      else RVC_LAUNCH((k_fused_block2w<LOGB, false, false>), dim3(n_audio), dim3(128), lds, st, b, f);
       return hipGetLastError();
     }
   }
