@@ -2332,6 +2332,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   else if (k == "subsets") g_tune.subsets = value;
   else if (k == "patch_nt") rvc::set_patch_nt_tuning(value);
   else if (k == "block_occ") rvc::set_block_occ3_tuning(value);
+  else if (k == "tile_rot") rvc::set_tile_rot_tuning(value);
   else if (k == "guard") g_tune.guard = value;
   else return 0;
   return 1;

@@ -626,10 +626,17 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
       const unsigned m = (unsigned)P::in_idx(tid, e);
       const float2 x = ((e & 7) < 4 ? b0 : b1)[m];
       v[e] = mk<R>((R)x.x, (R)x.y);
-      if ((e & 7) >= 4 && keep_hist) {
-        const long long n = seg + 2 * (long long)m;
-        if (n >= a.ring_out_from) *reinterpret_cast<float2 *>(ring_out + ((unsigned long long)n & a.ring_out_mask)) = x;
-      }
+    }
+    // (the history stores in their OWN loop: between the loads, every later load would have to stay behind the store -- the
+    //  buffers could alias -- and the requests would go out one memory round trip at a time)
+    if (keep_hist) {
+#pragma unroll
+      for (int e = 0; e < P::E; ++e)
+        if ((e & 7) >= 4) {
+          const long long n = seg + 2 * (long long)P::in_idx(tid, e);
+          if (n >= a.ring_out_from)
+            *reinterpret_cast<float2 *>(ring_out + ((unsigned long long)n & a.ring_out_mask)) = make_float2((float)v[e].x, (float)v[e].y);
+        }
     }
   } else if (whole && s2ok) {
 #pragma unroll
@@ -639,9 +646,16 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
       const float *p = (src2 && n >= a.src2_from) ? src2 + (n - a.src2_from) : src + ((unsigned long long)n & a.src_mask);
       const float2 x = *reinterpret_cast<const float2 *>(p);
       v[e] = mk<R>((R)x.x, (R)x.y);
-      // second half of the segment = this block's own samples: keep the recent ones as history
-      if (ring_out && m >= B / 2 && n >= a.ring_out_from)
-        *reinterpret_cast<float2 *>(ring_out + ((unsigned long long)n & a.ring_out_mask)) = x;
+    }
+    // second half of the segment = this block's own samples: keep the recent ones as history (own loop: see above)
+    if (ring_out) {
+#pragma unroll
+      for (int e = 0; e < P::E; ++e) {
+        const int m = P::in_idx(tid, e);
+        const long long n = seg + 2 * m;
+        if (m >= B / 2 && n >= a.ring_out_from)
+          *reinterpret_cast<float2 *>(ring_out + ((unsigned long long)n & a.ring_out_mask)) = make_float2((float)v[e].x, (float)v[e].y);
+      }
     }
   } else {
 #pragma unroll
@@ -656,9 +670,16 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
       const float x0 = *sample_ptr(a, src, src2, n0, ok0), x1 = *sample_ptr(a, src, src2, n1, ok1);
       const float v0 = ok0 ? x0 : 0.f, v1 = ok1 ? x1 : 0.f;
       v[e] = mk<R>((R)v0, (R)v1);
-      if (live && ring_out && q >= B) {
-        if (n0 >= a.ring_out_from && n0 >= a.lo && n0 < a.hi) ring_out[(unsigned long long)n0 & a.ring_out_mask] = v0;
-        if (n1 >= a.ring_out_from && n1 >= a.lo && n1 < a.hi) ring_out[(unsigned long long)n1 & a.ring_out_mask] = v1;
+    }
+    if (live && ring_out) {                            // (own loop: see above)
+#pragma unroll
+      for (int e = 0; e < P::E; ++e) {
+        const int q = 2 * P::in_idx(tid, e);
+        const long long n0 = seg + q, n1 = n0 + 1;
+        if (q >= B) {
+          if (n0 >= a.ring_out_from && n0 >= a.lo && n0 < a.hi) ring_out[(unsigned long long)n0 & a.ring_out_mask] = (float)v[e].x;
+          if (n1 >= a.ring_out_from && n1 >= a.lo && n1 < a.hi) ring_out[(unsigned long long)n1 & a.ring_out_mask] = (float)v[e].y;
+        }
       }
     }
   }
@@ -815,13 +836,10 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
     }
   __syncthreads();                                       // the transform's first exchange overwrites the buffer
   }
-  fft8_core<LOGB, true, R>(v, lds, T, tid);
-
   // z[m] = (s[2m], s[2m+1]); the overlap-save output is s[B..2B) = z[B/2..B): 8-byte stores
   float *dst = a.dst + (long long)c * a.dst_chan_stride;
   const float *add = a.add ? a.add + (long long)c * a.add_chan_stride : nullptr;
   const bool whole = nblk >= a.lo && nblk + B <= a.hi;      // every sample of the block is wanted
-  if (!live) return;                                        // (after the last barrier)
   // Common case: the whole block goes to one contiguous, 8-byte aligned run of dst (and of the add
   // stream): wave-uniform base pointers + 32-bit lane offsets instead of 64-bit masked indices per value.
   const unsigned long long o_dst = (unsigned long long)(nblk - a.dst_origin) & a.dst_mask;
@@ -831,15 +849,30 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
                     ((reinterpret_cast<uintptr_t>(dst) & 7u) == 0u) &&
                     (!add || nblk + B <= a.add_from ||
                      (add_all && (a.add_mask == ~0ull || o_add + B <= a.add_mask + 1ull)));
+  // The stream the epilogue adds (the other stage's output) does not depend on this transform: requested BEFORE it. Behind
+  // it, written as load / add / store per value, the requests went out one memory round trip at a time -- the compiler has
+  // to keep a load behind the previous store (the streams could alias) and waits for both.
+  const float2 *ab = (flat && add_all) ? reinterpret_cast<const float2 *>(add + o_add) - B / 2 : nullptr;
+  float2 addv[P::E / 2];
+  if (ab) {
+    int q = 0;
+#pragma unroll
+    for (int e = 0; e < P::E; ++e)
+      if (!P::out_is_low(e)) addv[q++] = ab[(unsigned)P::out_idx(tid, e)];
+  }
+  fft8_core<LOGB, true, R>(v, lds, T, tid);
+
+  if (!live) return;                                        // (after the last barrier)
   if (flat) {
     float2 *ob = reinterpret_cast<float2 *>(dst + o_dst) - B / 2;          // ob[m] <-> samples nblk + 2m - B
-    const float2 *ab = add_all ? reinterpret_cast<const float2 *>(add + o_add) - B / 2 : nullptr;
+    int q = 0;
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       if (!P::out_is_low(e)) {
         const unsigned m = (unsigned)P::out_idx(tid, e);
         float2 o = make_float2((float)v[e].x, (float)v[e].y);
-        if (ab) { const float2 t = ab[m]; o.x += t.x; o.y += t.y; }
+        if (ab) { const float2 t = addv[q]; o.x += t.x; o.y += t.y; }
+        ++q;
         ob[m] = o;
       }
     }
@@ -1141,6 +1174,9 @@ __device__ __forceinline__ void xk_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 // the tail stream behind the inverse transform. Every one of those requests then sits on the wave's dependent chain, which
 // is what the default form avoids for the plug-in's handful of channels; with thousands of channels the chain of one wave is
 // hidden by the other waves, and at <= 128 registers there are four of them per SIMD instead of two.
+// (SOLO: the many-channel form. Its general path -- ragged calls -- keeps the ring append between the sample loads: the
+//  requests then go out one at a time, but 16 fewer registers are live, and the whole-block path every lock-step launch
+//  takes sets the kernel's budget: three waves per SIMD.)
 template <int LOGB, bool FOLD, bool PK = false, bool SOLO = false, bool LEAN = false>
 __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, const int wg) {
   static_assert(!SOLO || Plan8<LOGB>::WG == 64, "SOLO: the workgroup's transform(s) live in one wave");
@@ -1212,7 +1248,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       }
     }
   };
-  if constexpr (!LEAN) { load_wso(); load_wsi(); load_mac(); }
+  if constexpr (!LEAN) { load_wso(); load_mac(); }
   // 1. load the segment: history from the ring, this call's samples from `in` (and append them
   //    to the ring), zero for the not-yet-played rest of block k and for time < 0
   // (persistent kernel: calls on even sample positions with 8-byte aligned buffers move sample PAIRS per access. Single
@@ -1223,7 +1259,13 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   C v[P::E];
   // The tail contribution the epilogue adds is requested NOW -- it does not depend on this block -- instead of costing a
   // memory round trip behind the inverse transform (calls on even sample positions: pairs of samples per access).
-  const bool pre_add = PK ? wide : (((a.n0 | a.n1) & 1) == 0);
+  // The plug-in's own call (one whole block, starting on its boundary, 8-byte aligned buffers): both halves of the segment are
+  // contiguous runs -- history in the ring, the block in the call's input -- addressed as base + lane offset, moved as sample
+  // PAIRS, and no per-sample window test is left anywhere (launch-uniform conditions).
+  const bool blockcall = !PK && a.n0 == seg + B && a.n1 >= seg + 2 * (long long)B &&
+                         ((reinterpret_cast<uintptr_t>(a.in) | (uintptr_t)(a.in_chan_stride * 4) | reinterpret_cast<uintptr_t>(a.out) |
+                           (uintptr_t)(a.out_chan_stride * 4)) & 7u) == 0;
+  const bool pre_add = PK ? wide : (blockcall || ((a.n0 | a.n1) & 1) == 0);
   float2 addv[P::E / 2];
   auto load_addv = [&]() {
     if constexpr (!PK) {
@@ -1252,6 +1294,24 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
         }
     }
   }
+  if (blockcall) {
+    const bool hist = seg >= 0;                                        // (block 0: the first half is time < 0)
+    const float2 *hb = reinterpret_cast<const float2 *>(ring + ((unsigned long long)(hist ? seg : 0) & a.ring_mask));
+    const float2 *ib = reinterpret_cast<const float2 *>(in) - B / 2;   // ib[m] <-> samples seg + 2m, m >= B/2
+    float2 *rb = reinterpret_cast<float2 *>(ring + ((unsigned long long)(seg + B) & a.ring_mask)) - B / 2;
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      const int m = P::in_idx(tid, e);
+      const float2 x = ((e & 7) < 4 ? hb : ib)[m];                     // (e & 7) < 4 <=> m < B/2: first half
+      v[e] = ((e & 7) < 4 && !hist) ? mk<float>(0.f, 0.f) : mk<float>(x.x, x.y);
+    }
+    // (the ring append in its OWN loop: a store between the loads keeps every later load behind it -- the buffers could
+    //  alias -- and the sample requests went out one memory round trip at a time: 3.4 of the 7.4 us of a stereo pair's
+    //  block, profiles/r2_block_kernel_breakdown.txt)
+#pragma unroll
+    for (int e = 0; e < P::E; ++e)
+      if ((e & 7) >= 4 && live) rb[P::in_idx(tid, e)] = make_float2(v[e].x, v[e].y);
+  } else {
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     // unconditional loads from an always legal address, then selects: loads under a branch would be
@@ -1285,10 +1345,21 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       const float *pm = m_in ? in + (m - a.n0) : ring + ((unsigned long long)(m_hist ? m : 0) & a.ring_mask);
       const float ln = *pn, lm = *pm;
       s0 = (n_in || n_hist) ? ln : 0.f; s1 = (m_in || m_hist) ? lm : 0.f;
-      if (live && n_in) ring[(unsigned long long)n & a.ring_mask] = s0;
-      if (live && m_in) ring[(unsigned long long)m & a.ring_mask] = s1;
+      if constexpr (SOLO) {
+        if (live && n_in) ring[(unsigned long long)n & a.ring_mask] = s0;
+        if (live && m_in) ring[(unsigned long long)m & a.ring_mask] = s1;
+      }
     }
     v[e] = mk<float>(s0, s1);
+  }
+  if constexpr (!PK && !SOLO) {        // (the ring append: own loop, as above)
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) {
+      const long long n = seg + 2 * P::in_idx(tid, e), m = n + 1;
+      if (live && n >= a.n0 && n < a.n1) ring[(unsigned long long)n & a.ring_mask] = v[e].x;
+      if (live && m >= a.n0 && m < a.n1) ring[(unsigned long long)m & a.ring_mask] = v[e].y;
+    }
+  }
   }
   if constexpr (PK) {
     const __amdgpu_buffer_rsrc_t rring = xk_rsrc(ring);
@@ -1310,6 +1381,11 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   if constexpr (LEAN) {
     __builtin_amdgcn_sched_barrier(0);           // (nothing of what follows is requested above the transform)
     load_wso(); load_mac(); fold_in();
+  } else {
+    // the inverse split's twiddles (a table every channel shares: L2) are requested behind the forward transform: with the
+    // 2 E sample requests in flight together their 2 E registers are what keeps the kernel at three waves per SIMD
+    __builtin_amdgcn_sched_barrier(0);
+    load_wsi();
   }
   // The real split pairs bin k with bin B - k. Head blocks of 64 / 512: the whole transform lives in one wave and the
   // partner arrives through a lane reversal (wave_partner: ds_bpermute, no LDS round trip, no barrier); else through LDS.
@@ -1393,6 +1469,19 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   const long long nblk = a.k * (long long)B;
   if (!live) return;
   int addq = 0;
+  if (blockcall) {
+    // whole block, pairs: ob[m] <-> samples nblk + 2m - B; the tail stream's pairs were requested at the top
+    float2 *ob = reinterpret_cast<float2 *>(out) - B / 2;
+    const bool addb = add && nblk >= a.add_from;                       // (add_from is a multiple of the block sizes)
+#pragma unroll
+    for (int e = 0; e < P::E; ++e)
+      if (!P::out_is_low(e)) {
+        float2 o = make_float2(v[e].x, v[e].y);
+        if (addb) { o.x += addv[addq].x; o.y += addv[addq].y; }
+        ++addq;
+        ob[P::out_idx(tid, e)] = o;
+      }
+  } else {
 #pragma unroll
   for (int e = 0; e < P::E; ++e) {
     const int m = P::out_idx(tid, e);
@@ -1436,6 +1525,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
         if (n + 1 >= a.n0 && n + 1 < a.n1) out[n + 1 - a.n0] = t1;
       }
     }
+  }
   }
   if (a.done_flag) {   // output is in (host-visible) memory: tell the polling host, do not make it wait for kernel end
     if constexpr (PK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores: landed when acknowledged
@@ -1850,7 +1940,10 @@ __device__ __forceinline__ void fdl_patch_any(const FirArgs &a, const int bx, co
 
 // NT: non-temporal loads (many channels: nothing of a row survives in a cache until the next patch reads it)
 template <int STAGE, bool NT>
-__global__ void __launch_bounds__(256) k_fdl_patch(const FirArgs a) { fdl_patch_any<NT>(a, blockIdx.x, blockIdx.y); }
+__global__ void __launch_bounds__(256) k_fdl_patch(const FirArgs a, const int rot) {
+  // rot: channel c takes its 512-bin tiles in the order rotated by c (every XCD sees every part of the rows: rvc_sweep.hip)
+  fdl_patch_any<NT>(a, rot ? (int)((blockIdx.x + blockIdx.y) % gridDim.x) : (int)blockIdx.x, blockIdx.y);
+}
 
 // One launch per block of the streaming path: workgroups [0, n_audio) run block k's audio path
 // (fused_audio<FOLD = true>), the rest compute sum_{i>=2} H_i X_{k+1-i} for block k+1 (fir_row_body;
@@ -2440,8 +2533,9 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   if (a.M == 1 && a.P <= kPatchMax && (a.B % 2) == 0 && (a.Yadd != nullptr || (long long)channels * a.B >= (1ll << 18))) {
     const dim3 grid((a.B + 511) / 512, channels), block(256);
     const bool nt = g_patch_nt != 0 && (long long)channels * a.B >= (1ll << 20);    // (a few channels: rows stay in the L2 / MALL)
-    if (a.tag == 0) { if (nt) RVC_LAUNCH((k_fdl_patch<0, true>), grid, block, 0, st, a); else RVC_LAUNCH((k_fdl_patch<0, false>), grid, block, 0, st, a); }
-    else { if (nt) RVC_LAUNCH((k_fdl_patch<1, true>), grid, block, 0, st, a); else RVC_LAUNCH((k_fdl_patch<1, false>), grid, block, 0, st, a); }
+    const int rot = (grid.x >= 8 && tile_rot_tuning()) ? 1 : 0;
+    if (a.tag == 0) { if (nt) RVC_LAUNCH((k_fdl_patch<0, true>), grid, block, 0, st, a, rot); else RVC_LAUNCH((k_fdl_patch<0, false>), grid, block, 0, st, a, rot); }
+    else { if (nt) RVC_LAUNCH((k_fdl_patch<1, true>), grid, block, 0, st, a, rot); else RVC_LAUNCH((k_fdl_patch<1, false>), grid, block, 0, st, a, rot); }
     return hipGetLastError();
   }
   if (a.M == 1) {                         // one block: the latency-oriented row kernel

@@ -274,36 +274,57 @@ __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_til
   }
   if (active) {
     float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
-    const float2 *Yb = a.Ybase ? a.Ybase + (long long)c * a.ybase_chan_stride + bin : nullptr;
+    if (a.Ybase) {
+      // second level: + the first-level rows. ALL K requests first, then the stores: written as load / add / store per row
+      // the compiler has to keep the order (the rows could alias) and waits for each load AND the previous store in turn --
+      // K dependent memory round trips at the end of every wave of a sweep that only walks K1 partitions.
+      const float2 *Yb = a.Ybase + (long long)c * a.ybase_chan_stride + bin;
+      V yb[K];
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-      V r = acc[t];
-      if (Yb) sweep_add(r, *reinterpret_cast<const V *>(Yb + (long long)((unsigned)(a.k0 + t) & a.ybase_row_mask) * B));
-      *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
+      for (int t = 0; t < K; ++t) yb[t] = *reinterpret_cast<const V *>(Yb + (long long)((unsigned)(a.k0 + t) & a.ybase_row_mask) * B);
+#pragma unroll
+      for (int t = 0; t < K; ++t) {
+        V r = acc[t];
+        sweep_add(r, yb[t]);
+        *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < K; ++t) *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = acc[t];
     }
   }
 }
 
 // grid (bin tiles, channels), block 256. STAGE names the instantiation for profilers (0 head, 1 tail).
 template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
-__global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a) {
+__global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a, const int rot) {
   typedef typename SweepVec<LW>::T V;
+  // rot: the bin tiles of channel c are taken in the order rotated by c (see launch_variant)
+  const int bx = rot ? (int)((blockIdx.x + blockIdx.y * (unsigned)rot) % gridDim.x) : (int)blockIdx.x;
   if constexpr (SPLIT == 1) {
-    fdl_sweep_own<K, D, LW, NT>(a, blockIdx.x, blockIdx.y);
+    fdl_sweep_own<K, D, LW, NT>(a, bx, blockIdx.y);
   } else {
     __shared__ V red[SPLIT][K][64];
-    fdl_sweep_body<K, D, SPLIT, LW, NT>(a, reinterpret_cast<V (*)[K][64]>(red), blockIdx.x, blockIdx.y);
+    fdl_sweep_body<K, D, SPLIT, LW, NT>(a, reinterpret_cast<V (*)[K][64]>(red), bx, blockIdx.y);
   }
 }
+
+static int g_tile_rot = 1;
+void set_tile_rot_tuning(int on) { g_tile_rot = on; }
+int tile_rot_tuning() { return g_tile_rot; }
 
 template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
 static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
   const int tiles = (a.B + 32 * LW - 1) / (32 * LW);
   const dim3 grid(SPLIT == 1 ? (tiles + 3) / 4 : tiles, channels), block(256);
+  // Workgroups go to the 8 XCDs round robin by linear index. With a power-of-two count of workgroups per channel, XCD j
+  // would only ever see the bin tiles j, j + 8, .. of every row: a fixed eighth of each row's addresses. Rotating the order
+  // by the channel index gives every XCD every part of the rows.
+  const int rot = (grid.x >= 8 && g_tile_rot) ? 1 : 0;
   hipEvent_t ea, eb;
   get_launch_events(&ea, &eb);
-  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, ea, eb, 0, a);
-  else hipLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a);
+  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, ea, eb, 0, a, rot);
+  else hipLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a, rot);
 }
 
 static int g_sweep_split = -1, g_sweep_lw = 0, g_sweep_depth = 0;
