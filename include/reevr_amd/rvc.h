@@ -80,7 +80,8 @@ enum {
                                    blocks over all partitions, second-level sweeps every 8 blocks over what arrived
                                    since (BASELINE config 3's 350 tail partitions: ~1.7x fewer bytes again). */
 
-#define RVC_FLAG_PERSISTENT 64u  /* EXPERIMENTAL (its 99th-percentile call time is above the launch path's: DESIGN.md 5b).
+#define RVC_FLAG_PERSISTENT 64u  /* EXPERIMENTAL, and since round 3 SLOWER than ordinary launches (stereo pair, MI355X: 9.7 vs
+                                   6.3 us per block; host call median 17 vs 11.7 us, p99 33 vs 21-30: DESIGN.md 5b / 7).
                                    Per-block calls (a call inside one head block, head block 512 ... 4096) are served by ONE
                                    RESIDENT kernel fed through a doorbell in pinned host memory instead of one launch per
                                    block (the loop of TwoStageFFTConvolver.cpp:151-233): no launch on the latency path.
@@ -346,7 +347,10 @@ double rvc_debug_persist_rtt(rvc_set *s, int n);
  * key is known. Keys: "k1" first-level tile of long delay lines (8 = one level, 16 default, 32); "sweep_split" -1 auto /
  * 0 own-tile / 1 partition-split sweeps; "fft_loop" -1 auto / 0 / 1 row-looping 8192-bin transforms; "subsets" -1 auto /
  * n children of a many-channel set; "guard" 0 / 1 guard bands around every device allocation (see rvc_debug_guard_check) / 2 every
- * allocation END-aligned against an unmapped address range (an out-of-bounds access faults: tools/fence_fuzz.py only). */
+ * allocation END-aligned against an unmapped address range (an out-of-bounds access faults: tools/fence_fuzz.py only);
+ * "two_level_min_p" delay lines with more partitions than this get two tiling levels (-1: default 24); "tile_rot" 1 (default) /
+ * 0 sweeps and patches on long rows take channel c's bin tiles in the order rotated by c; "sweep_lw", "sweep_d", "patch_nt",
+ * "block_occ": kernel variants (rvc_internal.h). */
 int rvc_debug_set_tuning(const char *key, int value);
 /* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set
  * is initialised, every device allocation of the set lies between two 256 KiB guard bands filled with 0xFF and starts out

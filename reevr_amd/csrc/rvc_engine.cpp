@@ -105,6 +105,7 @@ struct Tile {
 // process-wide measurement knobs (rvc_debug_set_tuning); the defaults are what the engine ships with
 struct Tuning {
   int k1 = 0;             // first-level tile of delay lines with more than kTwoLevelMinP partitions: 0 by length, else 8 / 16 / 32
+  int two_min_p = -1;     // "two_level_min_p": delay lines with MORE partitions than this get two levels (-1: kTwoLevelMinP)
   int fft_loop = -1;      // row-looping form of the 8192-bin transforms: -1 by size, 0 never, 1 always
   int subsets = -1;       // children of a many-channel set: -1 by size, else the count
   int guard = 0;          // 1: NaN-filled guard bands around (and NaN poison inside) every device allocation of a set
@@ -679,7 +680,8 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
       // g_tune.k1: 0 = by length (16 above kTwoLevelMinP partitions, 32 from kLongLineMinP on: measured, profiles/r3_tuning.txt)
       int k1 = (g_tune.k1 == 32 || g_tune.k1 == 16 || g_tune.k1 == 8) ? g_tune.k1 : ((int)P >= rvc::kLongLineMinP ? 32 : 16);
       if (force2 && k1 == 8) k1 = 16;
-      return (force2 || (int)P > rvc::kTwoLevelMinP) ? k1 : (int)K;
+      const int minp = g_tune.two_min_p >= 0 ? g_tune.two_min_p : rvc::kTwoLevelMinP;
+      return (force2 || (int)P > minp) ? k1 : (int)K;
     };
     tA.K1 = pk ? (int)K : first_level(pa);       // (the resident kernel's own tile scheme has one level)
     tA.rows1 = tA.K1 * (pk ? 2 : 1);
@@ -2333,6 +2335,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   else if (k == "patch_nt") rvc::set_patch_nt_tuning(value);
   else if (k == "block_occ") rvc::set_block_occ3_tuning(value);
   else if (k == "tile_rot") rvc::set_tile_rot_tuning(value);
+  else if (k == "two_level_min_p") g_tune.two_min_p = value;
   else if (k == "guard") g_tune.guard = value;
   else return 0;
   return 1;

@@ -20,16 +20,17 @@ import re
 CALIB_BYTES = 4 * (1 << 28)      # tools/pmc_calib.py copies 1 GiB per dispatch: this many bytes read AND as many written
 
 
-K1 = {"0": 8, "1": 8}      # blocks per first-level sweep tile of the head / tail stage (--k1-head / --k1-tail)
 
 
 def family(name: str, head_log: int, tail_log: int):
     if "k_fused_block" in name or "k_block_step" in name:
         return "fused_block"
-    m = re.search(r"k_fdl_sweep<(\d+), \d+, (\d)", name)          # <K, SPLIT, STAGE, ...>
+    m = re.search(r"k_fdl_sweep<(\d+), (\d+), (\d), \d+, \d+, \d+, (true|false)>", name)   # <K, SPLIT, STAGE, LW, D, LB, NT>
     if m:
-        st = "head" if m.group(2) == "0" else "tail"
-        return ("sweep_" if int(m.group(1)) == K1[m.group(2)] else "sweep2_") + st
+        st = "head" if m.group(3) == "0" else "tail"
+        # second-level sweeps are exactly the own-tile K = 8 instantiation with ordinary loads (rvc_sweep.hip launch_stage)
+        second = m.group(1) == "8" and m.group(2) == "1" and m.group(4) == "false"
+        return ("sweep2_" if second else "sweep_") + st
     m = re.search(r"k_fft8_(fwd|inv)_loop<(\d+)>", name)
     if m:
         return f"fft_{m.group(1)}_tail"
@@ -85,13 +86,12 @@ def main():
     ap.add_argument("--channels", type=int, default=4096)
     ap.add_argument("--time-tiling", type=int, default=1)
     ap.add_argument("--config", type=int, default=2)
-    ap.add_argument("--k1-head", type=int, default=8)
-    ap.add_argument("--k1-tail", type=int, default=16)
+    ap.add_argument("--k1-head", type=int, default=16, help="(recorded only)")
+    ap.add_argument("--k1-tail", type=int, default=16, help="(recorded only)")
     ap.add_argument("--subsets", type=int, default=2, help="child sets: every launch covers channels / subsets")
     ap.add_argument("--command", default="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --side 0")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
-    K1["0"], K1["1"] = a.k1_head, a.k1_tail
     fe = per_family(a.fetch_csv, a.head_log, a.tail_log)
     wr = per_family(a.write_csv, a.head_log, a.tail_log)
     ff, fk = calib_factor(a.calib_fetch, 2.0)
