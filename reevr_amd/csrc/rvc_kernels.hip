@@ -2044,15 +2044,16 @@ __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, c
 // which three waves retire at once + separate 256-thread patch workgroups, one resident per CU).
 // Measured for 1024 channels at head 512: 17.4 -> 17.0 us per launch; where the rest goes: DESIGN.md section 7.
 // NT: the patch wave's rows with non-temporal loads (measurement, patch_nt = 2: no gain for config 2, +3 % for config 1).
-// Registers: with the audio path's requests grouped by phase (fused_audio: load_wso / load_mac / fold_in / load_addv) the
-// kernel needs 154 (B = 512) ... 166 registers: THREE waves per SIMD, six workgroups per CU, without a spill. Round 2's form
-// (170-174 registers, two waves per SIMD) took 52.4 us per 4096-channel launch, this one 48.9 us (0.62 -> 0.66 of the HBM
-// peak): launches of thousands of channels run in rounds of resident workgroups, and more resident ones overlap one round's
-// latency-bound end with the next one's loads (round 2's "occupancy is not what bounds this launch" was measured with 1024
-// channels, where four workgroups per CU are the whole launch).
+// Registers: with the audio path's requests grouped by phase (fused_audio: load_wso / load_mac / fold_in / load_addv) and the
+// whole-block path for the samples (uniform bases, pairs) the kernel needs 145 (B = 512) ... 167 registers: THREE waves per
+// SIMD, six workgroups per CU, without a spill. Round 2's form (170-174 registers, two waves per SIMD) took 52.4 us per
+// 4096-channel launch, three waves 48.9 us, this one -- its sample requests no longer one memory round trip at a time -- 42.6 us
+// (0.62 -> 0.66 -> 0.76 of the HBM peak): launches of thousands of channels run in rounds of resident workgroups, and more
+// resident ones overlap one round's latency-bound end with the next one's loads (round 2's "occupancy is not what bounds
+// this launch" was measured with 1024 channels, where four workgroups per CU are the whole launch).
 // LEAN (measurement, block_occ = 4): the register budget of FOUR waves per SIMD -- the lean form of the audio path, two
-// partitions per round in the patch wave, 7-11 spilled dwords. Measured: config 2 52.9 vs 48.9 us per launch, config 1
-// 87 vs 81 us, config 3 (256-bin heads) 16.9 vs 17.7 us: every request on the wave's chain costs more than the fourth wave buys.
+// partitions per round in the patch wave. Measured: no faster for configs 2 / 1, slower for config 3 (profiles/r3_tuning.txt
+// passes Q, T): every request on the wave's chain costs more than the fourth wave buys.
 template <int LOGB, bool NT, bool LEAN>
 __global__ void __launch_bounds__(128, LEAN ? 4 : 2) k_fused_block2w(const FusedArgs a, const FirArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
