@@ -759,7 +759,9 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   }
 }
 
-template <int LOGB, typename R>
+// ADD: the launch has a stream to add (InvArgs::add); without one the kernel carries no registers for its prefetch (the
+// 8192-bin tail inverse of many channels: 54 instead of 64 registers)
+template <int LOGB, typename R, bool ADD = true>
 __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
@@ -838,7 +840,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   }
   // z[m] = (s[2m], s[2m+1]); the overlap-save output is s[B..2B) = z[B/2..B): 8-byte stores
   float *dst = a.dst + (long long)c * a.dst_chan_stride;
-  const float *add = a.add ? a.add + (long long)c * a.add_chan_stride : nullptr;
+  const float *add = (ADD && a.add) ? a.add + (long long)c * a.add_chan_stride : nullptr;
   const bool whole = nblk >= a.lo && nblk + B <= a.hi;      // every sample of the block is wanted
   // Common case: the whole block goes to one contiguous, 8-byte aligned run of dst (and of the add
   // stream): wave-uniform base pointers + 32-bit lane offsets instead of 64-bit masked indices per value.
@@ -852,9 +854,9 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   // The stream the epilogue adds (the other stage's output) does not depend on this transform: requested BEFORE it. Behind
   // it, written as load / add / store per value, the requests went out one memory round trip at a time -- the compiler has
   // to keep a load behind the previous store (the streams could alias) and waits for both.
-  const float2 *ab = (flat && add_all) ? reinterpret_cast<const float2 *>(add + o_add) - B / 2 : nullptr;
-  float2 addv[P::E / 2];
-  if (ab) {
+  const float2 *ab = (ADD && flat && add_all) ? reinterpret_cast<const float2 *>(add + o_add) - B / 2 : nullptr;
+  float2 addv[ADD ? P::E / 2 : 1];
+  if (ADD && ab) {
     int q = 0;
 #pragma unroll
     for (int e = 0; e < P::E; ++e)
@@ -871,7 +873,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
       if (!P::out_is_low(e)) {
         const unsigned m = (unsigned)P::out_idx(tid, e);
         float2 o = make_float2((float)v[e].x, (float)v[e].y);
-        if (ab) { const float2 t = addv[q]; o.x += t.x; o.y += t.y; }
+        if constexpr (ADD) { if (ab) { const float2 t = addv[q]; o.x += t.x; o.y += t.y; } }
         ++q;
         ob[m] = o;
       }
@@ -2310,7 +2312,8 @@ static hipError_t launch_inv_t(const InvArgs &a, int rows, int channels, hipStre
     const size_t lds = sizeof(cx<R>) * P::LDS_ELEMS * P::TPW;
     InvArgs b = a;
     b.rows = rows;
-    RVC_LAUNCH((k_fft8_inv<LOGB, R>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
+    if (b.add) RVC_LAUNCH((k_fft8_inv<LOGB, R, true>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
+    else RVC_LAUNCH((k_fft8_inv<LOGB, R, false>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
   } else {
     const size_t lds = sizeof(cx<R>) << LOGB;
     RVC_LAUNCH((k_fft_inv<LOGB, R>), dim3(rows, channels), dim3(fft_threads(LOGB)), lds < 16 ? 16 : lds, st, a);
@@ -2584,10 +2587,14 @@ hipError_t prepare_kernels() {
     if (e != hipSuccess) return e;
   }
   const void *big[] = {reinterpret_cast<const void *>(k_fft8_fwd_loop<kLoopLogB>), reinterpret_cast<const void *>(k_fft8_inv_loop<kLoopLogB>),
-                       reinterpret_cast<const void *>(k_fft8_fwd<13, float>), reinterpret_cast<const void *>(k_fft8_inv<13, float>),
-                       reinterpret_cast<const void *>(k_fft8_fwd<14, float>), reinterpret_cast<const void *>(k_fft8_inv<14, float>),
-                       reinterpret_cast<const void *>(k_fft8_fwd<12, double>), reinterpret_cast<const void *>(k_fft8_inv<12, double>),
-                       reinterpret_cast<const void *>(k_fft8_fwd<13, double>), reinterpret_cast<const void *>(k_fft8_inv<13, double>)};
+                       reinterpret_cast<const void *>(k_fft8_fwd<13, float>), reinterpret_cast<const void *>(k_fft8_inv<13, float, true>),
+                       reinterpret_cast<const void *>(k_fft8_inv<13, float, false>),
+                       reinterpret_cast<const void *>(k_fft8_fwd<14, float>), reinterpret_cast<const void *>(k_fft8_inv<14, float, true>),
+                       reinterpret_cast<const void *>(k_fft8_inv<14, float, false>),
+                       reinterpret_cast<const void *>(k_fft8_fwd<12, double>), reinterpret_cast<const void *>(k_fft8_inv<12, double, true>),
+                       reinterpret_cast<const void *>(k_fft8_inv<12, double, false>),
+                       reinterpret_cast<const void *>(k_fft8_fwd<13, double>), reinterpret_cast<const void *>(k_fft8_inv<13, double, true>),
+                       reinterpret_cast<const void *>(k_fft8_inv<13, double, false>)};
   for (const void *f : big) {
     // (the inverse loop kernel: 68 KiB exchange buffer + 72 KiB twiddle table)
     hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
