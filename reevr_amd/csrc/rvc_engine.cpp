@@ -1420,6 +1420,21 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   const long long hb = (long long)A.B;
   const long long k0 = n0 / hb, k1 = (n1 - 1) / hb;
 
+  // A call that crosses ONE head-block boundary (a host whose buffer size is not the head block: 480 frames against
+  // 512) = the end of block k0 + the start of block k0 + 1: two steps of the latency path -- one launch each -- instead
+  // of the general path's ingest / transform / delay line / inverse launches (measured, stereo pair, host pointers: 37.5 ->
+  // ~22 us per 480-frame call). The reference does the same thing in its own terms: it runs a block's transform when its
+  // input buffer fills, in the middle of the call (FFTConvolver.cpp:140-207). Host-pointer calls: only the second step
+  // publishes completion flags / is followed by the copy back (in-order stream: it implies the first).
+  if (k1 == k0 + 1 && !s->block_general && rvc::fused_supported(A.logB, A.f64)) {
+    const size_t part1 = (size_t)((k0 + 1) * hb - n0);
+    const size_t copy_len = s->out_copy_len;
+    s->out_copy_len = 0;
+    const bool ok = step_device(s, d_in, in_stride, d_out, out_stride, part1);
+    s->out_copy_len = copy_len;
+    return ok && step_device(s, d_in + part1, in_stride, d_out + part1, out_stride, len - part1);
+  }
+
   // ---- latency path: the call stays inside one head block (the plugin's per-block call) ----
   if (k0 == k1 && s->pk_enabled && !pk_paused()) {
     if (s->out_copy_len != 0) {          // host-pointer call: the resident kernel reads / writes the pinned buffers itself
@@ -1943,7 +1958,8 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   // buffers are device-visible, the kernel reads its 2 KB per channel over PCIe and writes the
   // result straight back; the host waits for the event behind that kernel. Longer calls use DMA.
   const long long hb = (long long)s->A.B;
-  s->zero_copy = !s->block_general && rvc::fused_supported(s->A.logB, s->A.f64) && (s->n / hb) == ((s->n + (long long)len - 1) / hb);
+  // (a call across one block boundary is two such launches: step_device)
+  s->zero_copy = !s->block_general && rvc::fused_supported(s->A.logB, s->A.f64) && ((s->n + (long long)len - 1) / hb - s->n / hb) <= 1;
   bool ok = true;
   if (!s->zero_copy)
     ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * len * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
