@@ -16,8 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libreevr_amd.so")
 SOURCES = ["rvc_kernels.hip", "rvc_sweep.hip", "rvc_impulse.hip", "rvc_engine.cpp"]
-# per-source extra flags (rvc_sweep.hip: see the comment at its top)
-EXTRA_FLAGS = {"rvc_sweep.hip": ["-fno-slp-vectorize"]}
+# per-source extra flags: the kernels are built WITHOUT the SLP vectoriser (rvc_sweep.hip: the comment at its top;
+# rvc_kernels.hip: v_pk_* issues at half the rate of the scalar ops on gfx950 and costs a register shuffle per operand pair --
+# the 8192-bin inverse transform 614 -> 679 instructions but 239 packed + 168 moves -> 424 scalar + 36 moves, 56 -> 40 registers,
+# 115 -> 108 us per 4096 rows; no kernel spills any more)
+EXTRA_FLAGS = {"rvc_sweep.hip": ["-fno-slp-vectorize"], "rvc_kernels.hip": ["-fno-slp-vectorize"]}
 HEADERS = ["rvc_internal.h", "rvc_fft_lds.hpp", os.path.join("..", "..", "include", "reevr_amd", "rvc.h")]
 
 
