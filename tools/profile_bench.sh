@@ -12,7 +12,10 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --side 0 --distinct 64 $*"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" $ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
+# (kernel trace: the driver's step counts, so that the timed steps outweigh the untimed pre-roll -- a delay line that is still
+#  filling moves fewer bytes per launch -- and the one event-instrumented step of bench.py's own per-kernel measurement)
+KT_ARGS="--steps 20 --warmup 5 --cpu-seconds 0 --side 0 --distinct 64 $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python "$ROOT/bench.py" $KT_ARGS > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
 find "$OUT/kt" -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 # launches of the two child sets overlap: per family, the UNION of the dispatch intervals of the trace (tools/trace_union.py)
 find "$OUT/kt" -name '*kernel_trace.csv' -exec python "$ROOT/tools/trace_union.py" {} \; > "$OUT/kernel_union.txt" 2>&1
