@@ -339,6 +339,17 @@ int rvc_send_pre_device(int device, void *stream, const rvc_send_params *p);
 int rvc_debug_rfft(int device, size_t n, int f64, const float *data, float *re, float *im);
 int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re, const float *im);
 
+/* Development / tests: ONE launch of a frequency-domain delay-line kernel on caller-provided rows -- the complex
+ * multiply-accumulate of Utilities.cpp:62-111 as FFTConvolver.cpp:176-187 applies it, in isolation:
+ *   Y[m] = (Yadd) + sum_{i < P} H[i] * X[(k0 + m - delay - i) & (ring_rows - 1)],  m < M,  rows before block 0 read as zero.
+ * Rows are B interleaved (re, im) bins, bin 0 holding the packed (DC, Nyquist) pair (two real products). H: [channels][P][B],
+ * X: [channels][ring_rows][B], Y: [channels][M][B]. kind 0: the general launcher (LDS-tiled, row or patch kernel by shape;
+ * Yadd = [channels][B], M = 1 only); kind 1: a sweep of the time-tiled delay line, M = 8 / 16 / 32, input rows outside
+ * [x_from, x_hi] read as zero, output row j in slot (k0 + j) & (M - 1), Yadd = [channels][M][B] first-level rows or NULL.
+ * Returns 1 on success. */
+int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int delay, long long k0, int ring_rows,
+                  const float *H, const float *X, const float *Yadd, float *Y, long long x_hi, long long x_from);
+
 /* RVC_FLAG_PERSISTENT diagnostics: the median host -> resident kernel -> host round trip of n empty commands,
  * microseconds (-1: not persistent). */
 double rvc_debug_persist_rtt(rvc_set *s, int n);

@@ -24,11 +24,36 @@ def factory(kind):
     return O.FFTConvolver("ref") if kind == "fftconv" else O.TwoStageFFTConvolver("ref")
 
 
+CMAC_LENS = (1, 3, 4, 7, 64, 513, 1027)
+
+
+def cmac_inputs(n):
+    """the six operand arrays of one ComplexMultiplyAccumulate known-answer case (re, im, reA, imA, reB, imB)"""
+    from reevr_amd import synth
+    return [synth.white_noise(n, 0xC0AC + 16 * n + j) for j in range(6)]
+
+
+def gen_cmac(gold):
+    """ComplexMultiplyAccumulate (Utilities.cpp:62-111) known answers: the accumulators after ONE call on seeded noise"""
+    out = {}
+    for n in CMAC_LENS:
+        a = cmac_inputs(n)
+        re, im = a[0].copy(), a[1].copy()
+        O.cmac(re, im, *a[2:], which="ref")
+        out[f"n{n}/re"] = re
+        out[f"n{n}/im"] = im
+    np.savez_compressed(os.path.join(gold, "cmac.npz"), **out)
+    print("cmac.npz:", len(CMAC_LENS), "cases")
+
+
 def main():
     O.build(ref=True)
     assert O.have_ref(), "oracle/_ref missing: reference sources not available here"
     gold = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gold, exist_ok=True)
+    gen_cmac(gold)
+    if sys.argv[1:] == ["cmac"]:        # (only this fixture: the others take minutes)
+        return
 
     kat = {}
     for kind, tups in (("fftconv", cases.KAT_FFTCONV), ("twostage", cases.KAT_TWOSTAGE)):

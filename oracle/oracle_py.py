@@ -57,6 +57,12 @@ class _Backend:
             g = getattr(self.lib, f"{prefix}_{name}")
             g.restype = None
             g.argtypes = [C.c_size_t, _F32P, _F32P, _F32P]
+        try:
+            g = getattr(self.lib, f"{prefix}_cmac")       # (a reference library built before the shim had it: rebuild)
+            g.restype = None
+            g.argtypes = [_F32P] * 6 + [C.c_size_t]
+        except AttributeError:
+            pass
         if prefix == "orc":
             self.lib.orc_direct_convolve.restype = None
             self.lib.orc_direct_convolve.argtypes = [_F32P, C.c_size_t, _F32P, C.c_size_t, _F64P]
@@ -151,6 +157,13 @@ def irfft(re: np.ndarray, im: np.ndarray, which: str = "orc"):
     out = np.empty(n, np.float32)
     backend(which).fn("irfft")(n, _fp(out), _fp(re), _fp(im))
     return out
+
+
+def cmac(re: np.ndarray, im: np.ndarray, reA, imA, reB, imB, which: str = "orc") -> None:
+    """re/im += A * B in place, the reference's ComplexMultiplyAccumulate (Utilities.cpp:62-111) / its restatement"""
+    arrs = [np.ascontiguousarray(v, dtype=np.float32) for v in (reA, imA, reB, imB)]
+    assert re.dtype == np.float32 and im.dtype == np.float32 and re.flags.c_contiguous and im.flags.c_contiguous
+    backend(which).fn("cmac")(_fp(re), _fp(im), *[_fp(v) for v in arrs], re.size)
 
 
 def direct_convolve(x: np.ndarray, ir: np.ndarray) -> np.ndarray:

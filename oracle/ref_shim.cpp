@@ -10,11 +10,13 @@
 //   fftconvolver::FFTConvolver            libs/FFTConvolver/FFTConvolver.h:52-80
 //   fftconvolver::TwoStageFFTConvolver    libs/FFTConvolver/TwoStageFFTConvolver.h:54-83
 //   audiofft::AudioFFT                    libs/FFTConvolver/AudioFFT.h:123-165
+//   fftconvolver::ComplexMultiplyAccumulate  libs/FFTConvolver/Utilities.h:338-344
 #include <cstddef>
 
 #include "AudioFFT.h"
 #include "FFTConvolver.h"
 #include "TwoStageFFTConvolver.h"
+#include "Utilities.h"
 
 extern "C" {
 
@@ -55,6 +57,10 @@ void ref_irfft(size_t n, float *data, const float *re, const float *im) {
   audiofft::AudioFFT f;
   f.init(n);
   f.ifft(data, re, im);
+}
+
+void ref_cmac(float *re, float *im, const float *reA, const float *imA, const float *reB, const float *imB, size_t len) {
+  fftconvolver::ComplexMultiplyAccumulate(re, im, reA, imA, reB, imB, len);
 }
 
 }  // extern "C"

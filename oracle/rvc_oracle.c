@@ -199,6 +199,11 @@ static void cmac(float *re, float *im, const float *reA, const float *imA,
   }
 }
 
+/* the multiply-accumulate alone (tests of the GPU delay-line kernels in isolation; Utilities.cpp:62-111) */
+void orc_cmac(float *re, float *im, const float *reA, const float *imA, const float *reB, const float *imB, size_t len) {
+  cmac(re, im, reA, imA, reB, imB, len);
+}
+
 /* ------------------------------------------------------------------------------- */
 /* FFTConvolver  (FFTConvolver.cpp)                                                */
 /* ------------------------------------------------------------------------------- */

@@ -44,6 +44,8 @@ void orc_twostage_reset(orc_twostage *c);
 /* audiofft::AudioFFT facade (AudioFFT.h:123-165): N must be a power of two.
  * re/im hold N/2+1 bins, split-complex. */
 void orc_rfft(size_t n, const float *data, float *re, float *im);
+/* Utilities.cpp:62-111 (ComplexMultiplyAccumulate, SSE order): re/im += a * b, len values */
+void orc_cmac(float *re, float *im, const float *reA, const float *imA, const float *reB, const float *imB, size_t len);
 void orc_irfft(size_t n, float *data, const float *re, const float *im);
 
 /* Test.cpp:33-66 SimpleConvolve, accumulated in double (out has inLen+irLen-1). */

@@ -2273,6 +2273,43 @@ int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re,
   return debug_fft(device, n, f64, true, nullptr, data, re, im, nullptr, nullptr);
 }
 
+// One launch of a delay-line kernel on caller-provided rows: the complex multiply-accumulate kernels in isolation
+// (tests: against Utilities.cpp:62-111 applied the way FFTConvolver.cpp:176-187 applies it).
+int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int delay, long long k0, int ring_rows,
+                  const float *H, const float *X, const float *Yadd, float *Y, long long x_hi, long long x_from) {
+  if (!H || !X || !Y || channels < 1 || B < 2 || (B & (B - 1)) || P < 1 || M < 1 || ring_rows < 1 || (ring_rows & (ring_rows - 1)))
+    return 0;
+  if (kind == 1 && M != 8 && M != 16 && M != 32) return 0;
+  if (hipSetDevice(device) != hipSuccess) return 0;
+  const size_t nh = (size_t)channels * P * B, nx = (size_t)channels * ring_rows * B, ny = (size_t)channels * M * B;
+  const size_t nadd = Yadd ? (kind == 1 ? ny : (size_t)channels * B) : 0;
+  float2 *dH = nullptr, *dX = nullptr, *dY = nullptr, *dA = nullptr;
+  bool ok = hipMalloc(&dH, nh * sizeof(float2)) == hipSuccess && hipMalloc(&dX, nx * sizeof(float2)) == hipSuccess &&
+            hipMalloc(&dY, ny * sizeof(float2)) == hipSuccess && (!nadd || hipMalloc(&dA, nadd * sizeof(float2)) == hipSuccess);
+  ok = ok && hipMemcpy(dH, H, nh * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(dX, X, nx * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemset(dY, 0xFF, ny * sizeof(float2)) == hipSuccess &&
+       (!nadd || hipMemcpy(dA, Yadd, nadd * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess);
+  if (ok) {
+    rvc::FirArgs a{};
+    a.H = dH; a.h_chan_stride = (long long)P * B;
+    a.X = dX; a.x_chan_stride = (long long)ring_rows * B; a.x_row_mask = (unsigned long long)ring_rows - 1;
+    a.Y = dY; a.y_chan_stride = (long long)M * B;
+    a.k0 = k0; a.M = M; a.P = P; a.delay = delay; a.B = B; a.tag = delay ? 1 : 0;
+    if (kind == 1) {             // sweep: output row j in slot (k0 + j) & (M - 1); Yadd = first-level rows (second-level form)
+      a.x_hi = x_hi; a.x_from = x_from; a.y_row_mask = (unsigned)(M - 1);
+      a.Ybase = dA; a.ybase_chan_stride = (long long)M * B; a.ybase_row_mask = (unsigned)(M - 1);
+      ok = rvc::launch_fdl_sweep(a, channels, nullptr) == hipSuccess;
+    } else {                     // launch_fir: the LDS-tiled / row / patch kernel by shape; Yadd = a sweep's row (M = 1)
+      a.Yadd = (M == 1) ? dA : nullptr; a.yadd_chan_stride = B;
+      ok = rvc::launch_fir(a, channels, nullptr) == hipSuccess;
+    }
+    ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(Y, dY, ny * sizeof(float2), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  (void)hipFree(dH); (void)hipFree(dX); (void)hipFree(dY); (void)hipFree(dA);
+  return ok ? 1 : 0;
+}
+
 // diagnostics: round trip of n empty commands through the resident kernel (median microseconds), -1 on failure
 double rvc_debug_persist_rtt(rvc_set *s, int n) {
   if (!s || !s->pk_enabled || !s->live || n < 1) return -1.0;

@@ -1106,3 +1106,94 @@ def test_many_channels_large_head_block_general_path():
         o = O.TwoStageFFTConvolver("orc")
         assert o.init(head, tail, irs[ch])
         assert rel_rms(got[ch], o.process(x[ch])) <= TOL, ch
+
+
+def _fdl_case(rng, nch, B, P, M, rows):
+    """split-complex operands the way the reference holds them (B + 1 bins, im[0] = im[B] = 0: SplitComplex of a real
+    transform) and their packed interleaved form (bin 0 = (DC, Nyquist)) for the GPU"""
+    def split(shape):
+        re = rng.uniform(-1, 1, shape + (B + 1,)).astype(np.float32)
+        im = rng.uniform(-1, 1, shape + (B + 1,)).astype(np.float32)
+        im[..., 0] = 0.0
+        im[..., B] = 0.0
+        return re, im
+
+    def pack(re, im):
+        out = np.empty(re.shape[:-1] + (B, 2), np.float32)
+        out[..., 0] = re[..., :B]
+        out[..., 1] = im[..., :B]
+        out[..., 0, 1] = re[..., B]
+        return np.ascontiguousarray(out)
+    return split, pack
+
+
+@pytest.mark.parametrize("kind,nch,B,P,M,delay,k0,variant", [
+    (0, 3, 512, 6, 1, 0, 40, "patch"),            # k_fdl_patch: a sweep row + a few recent partitions
+    (0, 2, 8192, 10, 1, 2, 40, "patch"),
+    (0, 600, 512, 4, 1, 0, 9, "row_many"),         # many channels, no base row: the streaming single-row form
+    (0, 2, 512, 33, 1, 0, 100, "row"),             # k_fir_row (the latency-oriented row kernel), whole delay line
+    (0, 2, 512, 33, 1, 0, 5, "row_early"),         # rows before block 0 read as zero
+    (0, 2, 256, 7, 5, 0, 20, "fir"),               # k_fir<TK>: a few rows per launch
+    (0, 2, 1024, 19, 12, 2, 30, "fir"),
+    (0, 2, 512, 21, 40, 0, 64, "fir_lds"),         # k_fir_lds: long calls, LDS-tiled
+    (1, 2, 8192, 20, 8, 2, 64, "split"),           # K = 8 sweep, partition-split form
+    (1, 3, 512, 30, 8, 0, 64, "own"),              # K = 8 sweep, own-tile form
+    (1, 3, 512, 17, 8, 0, 64, "second"),           # second-level sweep: window [x_from, x_hi] + first-level rows
+    (1, 2, 8192, 57, 16, 2, 128, "own"),           # first-level sweeps of long delay lines
+    (1, 3, 256, 64, 16, 0, 128, "own"),
+    (1, 2, 512, 94, 32, 0, 128, "own"),
+    (1, 2, 8192, 11, 16, 2, 3, "own_early"),       # the clock has just started: most rows do not exist yet
+])
+def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant):
+    """The complex multiply-accumulate kernels ALONE (SURVEY a-12): one launch of the general delay-line launcher / a sweep
+    on given rows through rvc_debug_fdl, against the reference's ComplexMultiplyAccumulate (Utilities.cpp:62-111, restated
+    in oracle/rvc_oracle.c and pinned bit for bit by tests/test_oracle.py::test_cmac_vs_golden) applied partition by
+    partition the way FFTConvolver.cpp:176-187 applies it. Tolerance: the GPU accumulates with fused multiply-adds and, in
+    the partition-split sweep, in four partial sums."""
+    import ctypes as C
+    from reevr_amd import _lib as L
+    rng = np.random.RandomState(1000 * kind + B + P + M)
+    rows = 1
+    while rows < P + M + 4:
+        rows *= 2
+    split, pack = _fdl_case(rng, nch, B, P, M, rows)
+    Hre, Him = split((nch, P))
+    Xre, Xim = split((nch, rows))
+    second = variant == "second"
+    has_add = variant in ("patch", "second")
+    Are, Aim = split((nch, M if kind == 1 else 1)) if has_add else (None, None)
+    x_hi = k0 + M - 1 - delay if kind == 0 else (k0 - 2 if variant != "second" else k0 + 3)
+    x_from = (k0 - 9) if second else 0
+    want_re = np.zeros((nch, M, B + 1), np.float32)
+    want_im = np.zeros((nch, M, B + 1), np.float32)
+    for c in range(nch):
+        for m in range(M):
+            re = Are[c, m if kind == 1 else 0].copy() if has_add else np.zeros(B + 1, np.float32)
+            im = Aim[c, m if kind == 1 else 0].copy() if has_add else np.zeros(B + 1, np.float32)
+            for i in range(P):
+                row = k0 + m - delay - i
+                if row < 0 or (kind == 1 and not (x_from <= row <= x_hi)):
+                    continue
+                O.cmac(re, im, Hre[c, i], Him[c, i], Xre[c, row & (rows - 1)], Xim[c, row & (rows - 1)])
+            want_re[c, m], want_im[c, m] = re, im
+    want = pack(want_re, want_im)
+    H, X = pack(Hre, Him), pack(Xre, Xim)
+    A = pack(Are, Aim) if has_add else None
+    got = np.empty((nch, M, B, 2), np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+    tune = {"split": 1, "own": 0, "own_early": 0, "second": 0}.get(variant)
+    if tune is not None:
+        reevr_amd.set_tuning("sweep_split", tune)
+    try:
+        ok = L.lib().rvc_debug_fdl(0, kind, nch, B, P, M, delay, k0, rows, fp(H), fp(X), fp(A), fp(got), x_hi, x_from)
+    finally:
+        reevr_amd.set_tuning("sweep_split", -1)
+    assert ok == 1
+    if kind == 1:                                   # output row j sits in slot (k0 + j) & (M - 1)
+        got = np.stack([got[:, (k0 + j) & (M - 1)] for j in range(M)], axis=1)
+    assert np.isfinite(got).all()
+    d = got.astype(np.float64) - want
+    scale = max(float(np.abs(want).max()), 1e-9)
+    assert np.abs(d).max() <= 1e-5 * scale, (variant, float(np.abs(d).max()), scale)
+    assert np.sqrt(np.mean(d ** 2)) <= 2e-6 * np.sqrt(np.mean(want.astype(np.float64) ** 2))
+

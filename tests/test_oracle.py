@@ -3,6 +3,7 @@
   * the reference's own 58 known-answer cases and pass rule (Test.cpp:129-145, :256-329),
   * oracle/_ref itself when it has been built in this container.
 """
+import os
 import numpy as np
 import pytest
 
@@ -112,3 +113,32 @@ def test_init_error_and_empty_semantics():
     b = O.TwoStageFFTConvolver("orc"); b.init(4, 16, ir)
     x = np.arange(40, dtype=np.float32)
     assert np.array_equal(a.process(x), b.process(x))
+
+
+def _cmac_inputs(n):
+    from reevr_amd import synth
+    return [synth.white_noise(n, 0xC0AC + 16 * n + j) for j in range(6)]     # (oracle/gen_golden.py cmac_inputs)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 7, 64, 513, 1027])
+def test_cmac_vs_golden(n):
+    """ComplexMultiplyAccumulate (Utilities.cpp:62-111) alone: the oracle's restatement against the reference's own
+    result (tests/golden/cmac.npz, generated by oracle/gen_golden.py from oracle/_ref), bit for bit -- the SSE order
+    of the first 4 * (len / 4) values and the scalar tail included."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cmac.npz"))
+    a = _cmac_inputs(n)
+    re, im = a[0].copy(), a[1].copy()
+    O.cmac(re, im, *a[2:], which="orc")
+    assert np.array_equal(re, g[f"n{n}/re"]) and np.array_equal(im, g[f"n{n}/im"])
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built")
+def test_cmac_vs_live_reference():
+    rng = np.random.RandomState(5)
+    for n in (2, 5, 8, 129, 4097):
+        a = [rng.randn(n).astype(np.float32) for _ in range(6)]
+        r1, i1, r2, i2 = a[0].copy(), a[1].copy(), a[0].copy(), a[1].copy()
+        O.cmac(r1, i1, *a[2:], which="orc")
+        O.cmac(r2, i2, *a[2:], which="ref")
+        assert np.array_equal(r1, r2) and np.array_equal(i1, i2), n
+
