@@ -20,6 +20,10 @@ is used before the block has arrived) and both with the reference's partition si
     FFTConvolver.cpp:176-187: physical bytes = SURVEY.md 8d's algorithmic bytes, frac <= 1. Its
     fraction of the HBM peak is `roofline.alg_frac_reference_schedule`.
 
+The set runs on ONE queue (the engine's default): every launch has the device to itself, so `roofline` = bytes per
+launch / mean launch duration of the dominant kernel is an efficiency. The side entry `child_sets` is the same loop with
+RVC_FLAG_CHILD_SETS (child sets of ~2048 channels on their own streams: +4-5 % throughput, launches overlap).
+
 The other BASELINE configurations run in the SAME lock-step regime in the same default run
 (`--configs 1,3,5`; entries `config1` / `config3` / `config5` of the line): config 1 (mono, 1 s IR,
 one FFTConvolver of block 512), config 3 (30 s IR @ 96 kHz, block 256 -> head 256 / tail 8192,
@@ -239,7 +243,7 @@ class Lockstep:
     """One lock-step workload on this rank: the set, its resident input / output batches, the step function."""
 
     def __init__(self, torch, reevr_amd, synth, cfg: int, instances, local_rank: int, tiling: bool, bg: bool,
-                 blocks_per_step: int, long_call: bool = False, distinct: int = 0, irs=None, x=None):
+                 blocks_per_step: int, long_call: bool = False, distinct: int = 0, irs=None, x=None, child_sets: bool = False):
         self.torch, self.cfg = torch, cfg
         w = WORKLOADS[cfg if cfg in WORKLOADS else 2]
         self.ir_len, self.host_block, self.single = w["ir_len"], w["host_block"], w["single"]
@@ -263,7 +267,7 @@ class Lockstep:
                 x[0, self.probe_at] = 1.0
         self.x = x
         self.synth_s = time.perf_counter() - t0
-        self.conv = reevr_amd.ConvolverSet(self.nch, device=local_rank, bg_stream=bg, time_tiling=tiling)
+        self.conv = reevr_amd.ConvolverSet(self.nch, device=local_rank, bg_stream=bg, time_tiling=tiling, child_sets=child_sets)
         t0 = time.perf_counter()
         max_len = self.frames_step if long_call else self.host_block
         ok = (self.conv.init_uniform(self.host_block, self.irs, max_len=max_len) if self.single
@@ -447,6 +451,17 @@ def side_config(torch, reevr_amd, synth, KERNEL_NAMES, cfg: int, channels: int, 
                                  "ms_per_step": round(rms, 4), "achieved_GBs": round(rrate * bps / 1e9, 1),
                                  "alg_frac": round(rrate * bps / 1e9 / HBM_PEAK_GBS, 4)}
     out["alg_frac_reference_schedule"] = out["reference_schedule"]["alg_frac"]
+    # ... and with RVC_FLAG_CHILD_SETS (the throughput option: child sets of ~2048 channels on their own streams)
+    cs = Lockstep(torch, reevr_amd, synth, cfg, inst, local_rank, True, False, w["blocks"], irs=irs, x=x, child_sets=True)
+    if cs.conv.subsets > 1:
+        cs.preroll()
+        csteps = max(2, steps // 2)
+        crate, cms = cs.timed(csteps, 1)
+        cprobe = cs.check_probe()
+        cs.conv.check()
+        out["child_sets"] = {"value": round(crate / 1e6, 3), "unit": "Msamples/s", "steps": csteps, "ms_per_step": round(cms, 4),
+                             "subsets": cs.conv.subsets, "probe_ok": bool(cprobe and cprobe["ok"])}
+    cs.close()
     if cpu_s > 0:
         cores = os.cpu_count() or 1
         n_ir = min(len(irs), max(2, cores))
@@ -474,6 +489,7 @@ def main():
     ap.add_argument("--config-cpu-seconds", type=float, default=8.0, help="budget of each other configuration's CPU leg")
     ap.add_argument("--side", type=int, default=1, help="0: skip the side measurements")
     ap.add_argument("--distinct", type=int, default=0, help="synthesise only this many different stereo IRs and cycle them (0: all different; config 3: 128)")
+    ap.add_argument("--child-sets", type=int, default=0, help="1: RVC_FLAG_CHILD_SETS for the measured set (throughput option)")
     ap.add_argument("--tune", type=str, default="", help="rvc_debug_set_tuning knobs, e.g. k1=32,subsets=2 (measurement hook)")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a stuck run dumps every thread's stack and exits (0: off)")
@@ -545,7 +561,7 @@ def main():
         raise SystemExit("--blocks-per-step must cover whole tail periods (a multiple of %d)" % ((tail or head) // host_block))
 
     ls = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, bool(args.time_tiling), bool(args.bg_stream), blocks,
-                  long_call=long_call, distinct=args.distinct or (128 if wcfg == 3 else 0))
+                  long_call=long_call, distinct=args.distinct or (128 if wcfg == 3 else 0), child_sets=bool(args.child_sets))
     conv, nch, frames_step, nbuf, ir_len = ls.conv, ls.nch, ls.frames_step, ls.nbuf, ls.ir_len
     do_gather = bool(args.gather and dist is not None)
     # The output batch of every step is gathered with ONE all_gather, overlapped with the next step's compute:
@@ -636,8 +652,9 @@ def main():
         roof = {"bound": "hbm", "kernel": dominant, "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": r["frac"], "traffic": r["traffic"], "bytes_per_launch": r["bytes_per_launch"],
                 "avg_launch_ms": r["avg_launch_ms"], "traffic_source": tsrc,
-                # child sets: two launches of the family run side by side on their own streams -- `achieved` is bytes over
-                # the UNION of the launch intervals (HIP events, one clock); the per-launch literal is frac_per_launch
+                # one queue (the default): every launch has the device to itself, `achieved` = bytes per launch / mean launch
+                # duration (HIP events on the launching stream), concurrency 1. With --child-sets 1 launches of the family run
+                # side by side: `achieved` is then bytes over the UNION of the launch intervals, the literal frac_per_launch
                 "concurrency": r["concurrency"], "frac_per_launch": r["frac_per_launch"], "busy_ms_per_step": r["ms_per_step"],
                 # SURVEY.md 8d's numerator (1497 B per channel-sample of the REFERENCE's loop nest): as a fraction of the
                 # peak only where the executed schedule moves those bytes (reference_schedule, filled in below); with
@@ -692,35 +709,31 @@ def main():
                         "partition (FFTConvolver.cpp:176-187): physical bytes = SURVEY.md 8d algorithmic bytes"}
             if roof is not None:
                 roof["alg_frac_reference_schedule"] = side["reference_schedule"]["frac_of_hbm_peak"]
-        if subsets > 1 and not args.tune:
-            # the same loop on ONE queue (no child sets): every launch has the device to itself, so bytes per launch / mean
-            # launch duration is each family's own efficiency -- the contract's literal per-launch roofline
-            reevr_amd.set_tuning("subsets", 1)
-            try:
-                qs = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, True, bool(args.bg_stream), blocks, irs=irs, x=x)
-            finally:
-                reevr_amd.set_tuning("subsets", -1)
-            qs.preroll()
-            qsteps = max(2, args.steps // 2)
-            qrate, qms = qs.timed(qsteps, 1)
-            qprobe = qs.check_probe()
-            qs.conv.check()
-            qkern = qs.kernel_times(KERNEL_NAMES)
-            qexe = executed_bytes(qs.conv, nch, head, tail, ir_len, host_block, qs.tiled)
-            qroof, _ = roofline_tables(qkern, qexe, {})
-            qs.close()
-            qdom = max(qroof, key=lambda k: qroof[k]["ms_per_step"])
-            side["single_queue"] = {
-                "value": round(qrate / 1e6, 3), "unit": "Msamples/s", "steps": qsteps, "ms_per_step": round(qms, 4),
-                "probe_ok": bool(qprobe and qprobe["ok"]),
-                "roofline": {"kernel": qdom, "frac": qroof[qdom]["frac"], "achieved": qroof[qdom]["achieved_GBs"],
-                             "bytes_per_launch": qroof[qdom]["bytes_per_launch"], "avg_launch_ms": qroof[qdom]["avg_launch_ms"]},
+        if not args.tune and not args.child_sets:
+            # the same loop with RVC_FLAG_CHILD_SETS: the set served by child sets of ~2048 channels on their own streams (the
+            # engine's throughput option). Launches of different children overlap, so a family's efficiency is its bytes over
+            # the UNION of its launch intervals; bytes per launch / mean launch duration is then NOT an efficiency (the
+            # device is shared) -- which is why the headline and its roofline are measured on one queue.
+            cs = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, True, bool(args.bg_stream), blocks, irs=irs, x=x,
+                          child_sets=True)
+            cs.preroll()
+            csteps = max(2, args.steps // 2)
+            crate, cms = cs.timed(csteps, 1)
+            cprobe = cs.check_probe()
+            cs.conv.check()
+            ckern = cs.kernel_times(KERNEL_NAMES)
+            cexe = executed_bytes(cs.conv, nch, head, tail, ir_len, host_block, cs.tiled)
+            croof, _ = roofline_tables(ckern, cexe, {})
+            csub = cs.conv.subsets
+            cs.close()
+            side["child_sets"] = {
+                "value": round(crate / 1e6, 3), "unit": "Msamples/s", "steps": csteps, "ms_per_step": round(cms, 4),
+                "subsets": csub, "probe_ok": bool(cprobe and cprobe["ok"]),
                 "roofline_all": {k: {"launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"],
-                                     "bytes_per_launch": v["bytes_per_launch"], "frac": v["frac"]} for k, v in qroof.items()},
-                "note": "RVC_FLAG_NO_SUBSETS-equivalent run of the headline loop: all channels in one set on one queue; "
-                        "frac = bytes per launch / mean launch duration / 8 TB/s (no concurrent launch shares the device)"}
-            if roof is not None:
-                roof["frac_single_queue"] = qroof[qdom]["frac"] if qdom == roof["kernel"] else qroof.get(roof["kernel"], {}).get("frac")
+                                     "concurrency": v["concurrency"], "bytes_per_launch": v["bytes_per_launch"],
+                                     "frac_over_union": v["frac"], "frac_per_launch": v["frac_per_launch"]} for k, v in croof.items()},
+                "note": "RVC_FLAG_CHILD_SETS run of the headline loop (same channels, inputs, call pattern): child sets on their "
+                        "own streams; frac_over_union = the family's bytes / the union of its launch intervals / 8 TB/s"}
         if args.config == 2:
             side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
     if world == 1 and args.cpu_seconds > 0 and lockstep_cfg:

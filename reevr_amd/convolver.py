@@ -34,9 +34,10 @@ class ConvolverSet:
 
     def __init__(self, n_channels: int, device: int = 0, bg_stream: bool = False, timing: bool = False,
                  fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True, persistent: bool = False,
-                 fft_f32: bool = False):
+                 fft_f32: bool = False, child_sets: bool = False):
         """time_tiling: True (by size) / False / "force" (every stage, one level unless long) / "force2" (two levels).
-        fft_f64 / fft_f32: every transform in double / in float (default: rvc.h, RVC_FLAG_FFT_F64)."""
+        fft_f64 / fft_f32: every transform in double / in float (default: rvc.h, RVC_FLAG_FFT_F64).
+        child_sets: RVC_FLAG_CHILD_SETS (throughput option of sets of thousands of lock-step channels)."""
         self._lib = L.lib()
         flags = ((L.RVC_FLAG_BG_STREAM if bg_stream else 0) | (L.RVC_FLAG_TIMING if timing else 0)
                  | (L.RVC_FLAG_FFT_F64 if fft_f64 else 0) | (L.RVC_FLAG_FFT_F32 if fft_f32 else 0)
@@ -44,7 +45,7 @@ class ConvolverSet:
                  | (0 if time_tiling else L.RVC_FLAG_NO_TIME_TILING)
                  | (L.RVC_FLAG_FORCE_TIME_TILING if time_tiling == "force" else 0)
                  | (L.RVC_FLAG_FORCE_TWO_LEVEL if time_tiling == "force2" else 0)
-                 | (L.RVC_FLAG_PERSISTENT if persistent else 0))
+                 | (L.RVC_FLAG_PERSISTENT if persistent else 0) | (L.RVC_FLAG_CHILD_SETS if child_sets else 0))
         self.persistent = bool(persistent)
         self.n_channels = int(n_channels)
         self.device = int(device)

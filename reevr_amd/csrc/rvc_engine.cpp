@@ -1712,15 +1712,17 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   return true;
 }
 
-// How many children a set of nch channels gets at this init (1: none). Measured on MI355X (profiles/r3_subsets.txt).
+// How many children a set of nch channels gets at this init (1: none; RVC_FLAG_CHILD_SETS asks for them, the measurement
+// hook's "subsets" forces a count). Measured on MI355X (profiles/r3_tuning.txt).
 int subset_count(const rvc_set *s, size_t head_block, size_t max_len) {
   if ((s->flags & (RVC_FLAG_PERSISTENT | RVC_FLAG_NO_SUBSETS)) != 0) return 1;
   int n = g_tune.subsets;
-  // auto: two children for sets of thousands of lock-step channels served block by block, four from 8192 channels on
+  // RVC_FLAG_CHILD_SETS: two children for sets of thousands of lock-step channels served block by block, four from 8192 on
   // (measured on MI355X, BASELINE config 2: 4096 channels 13.2 -> 14.3 Gsamples/s with two, 13.1 with four; 8192 channels
   // 14.4 -> 14.7 with two -> 15.2 with four; config 1's 8192 channels 25.6 -> 25.8: children of ~2048 channels:
   // profiles/r3_tuning.txt); long calls gain nothing from it
-  if (n < 0) n = (s->nch >= 2048 && max_len <= 2 * next_pow2(head_block ? head_block : 1)) ? (s->nch >= 8192 ? 4 : 2) : 1;
+  if (n < 0) n = ((s->flags & RVC_FLAG_CHILD_SETS) != 0 && s->nch >= 2048 && max_len <= 2 * next_pow2(head_block ? head_block : 1))
+                     ? (s->nch >= 8192 ? 4 : 2) : 1;
   if (n > 8) n = 8;
   while (n > 1 && (s->nch % n != 0 || s->nch / n < 2)) --n;
   (void)head_block; (void)max_len;

@@ -925,6 +925,35 @@ def test_two_level_tiling_at_config3_geometry():
         assert rel_rms(got[c], o.process(x[c])) <= TOL, c
 
 
+def test_child_sets_flag():
+    """RVC_FLAG_CHILD_SETS: off by default (one set, one queue); with it, 2048 block-synchronous channels run as two child
+    sets -- same bits; sets below 2048 channels and long-call sets stay single."""
+    import torch
+    nch, head, nblk = 2048, 64, 24
+    irs = [synth.synth_ir(300 + c % 17, 1, 700 + c % 29)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 70 + c % 11) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    outs = []
+    for flag, want in ((False, 1), (True, 2)):
+        s = reevr_amd.ConvolverSet(nch, child_sets=flag)
+        assert s.init_uniform(head, irs, max_len=head), s.last_error_string
+        assert s.subsets == want
+        outs.append(s.process_device_blocks(dx, head).cpu().numpy())
+        assert s.last_error == 0, s.last_error_string
+        s.close()
+    assert np.array_equal(outs[0], outs[1])
+    for c in (0, 1023, 1024, 2047):
+        o = O.FFTConvolver("orc")
+        assert o.init(head, irs[c])
+        assert rel_rms(outs[1][c], o.process(x[c])) <= TOL, c
+    small = reevr_amd.ConvolverSet(64, child_sets=True)
+    assert small.init_uniform(head, irs[:64], max_len=head) and small.subsets == 1
+    small.close()
+    long_calls = reevr_amd.ConvolverSet(nch, child_sets=True)
+    assert long_calls.init_uniform(head, irs, max_len=64 * head) and long_calls.subsets == 1
+    long_calls.close()
+
+
 @pytest.mark.parametrize("kids", [2, 4])
 def test_child_sets_match_single_set(kids):
     """A set served by child sets on their own streams (rvc_set_subsets) gives, bit for bit, what the same set gives

@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--k1-head", type=int, default=16, help="(recorded only)")
     ap.add_argument("--k1-tail", type=int, default=16, help="(recorded only)")
-    ap.add_argument("--subsets", type=int, default=2, help="child sets: every launch covers channels / subsets")
+    ap.add_argument("--subsets", type=int, default=1, help="child sets (bench.py --child-sets 1): every launch covers channels / subsets")
     ap.add_argument("--command", default="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --side 0")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
