@@ -288,6 +288,30 @@ __device__ __forceinline__ cx<R> wave_partner(const cx<R> *v, const int tid, con
   return tid == 0 ? own : other;
 }
 
+// The same for plans WITH a final radix-2 / radix-4 pass (B = 128, 256: the single-wave plans of the per-block kernel for
+// those heads). A held value sits at natural index tid + m * NT on both sides of the core; with a final pass of radix Q the
+// register that holds position m is no longer register m but e = pos_reg(m) (out_idx(tid, e) = tid + (e / Q) * NT +
+// (e % Q) * (B / Q), B / Q = (8 / Q) * NT) -- a compile-time renaming. The partner of position m is position 7 - m of lane
+// NT - tid (thread 0: its own position 8 - m): the same lane reversal.
+template <int LOGB> struct WaveSplitQ {
+  typedef Plan8<LOGB> P;
+  static constexpr bool ok = (P::S == 1) && (P::NT <= 64);
+  // position (multiple of NT) of the value register e holds after the core, and the register that holds position m
+  __host__ __device__ static constexpr int reg_pos(int e) { return P::Q == 1 ? e : e / P::Q + (e % P::Q) * (8 / P::Q); }
+  __host__ __device__ static constexpr int pos_reg(int m) { return P::Q == 1 ? m : (m % (8 / P::Q)) * P::Q + m / (8 / P::Q); }
+};
+// partner (the value at natural index B - (tid + m * NT)) of position m, out of an array indexed by OUTPUT register
+template <int LOGB, typename R>
+__device__ __forceinline__ cx<R> wave_partner_pos(const cx<R> *v, const int tid, const int m) {
+  typedef Plan8<LOGB> P;
+  typedef WaveSplitQ<LOGB> W;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int src = lane - tid + ((P::NT - tid) & (P::NT - 1));
+  const cx<R> other = shfl_cx<R>(v[W::pos_reg(7 - m)], src);
+  const cx<R> own = v[W::pos_reg((8 - m) & 7)];
+  return tid == 0 ? own : other;
+}
+
 // Twiddles of one transform, per thread, in registers: they depend on the thread index only, so
 // they are requested at the top of the kernel -- before the input data has even arrived -- and the
 // passes never wait on a twiddle load. Forward and inverse share them (conjugated on use).
@@ -1391,11 +1415,12 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   }
   // The real split pairs bin k with bin B - k. Head blocks of 64 / 512: the whole transform lives in one wave and the
   // partner arrives through a lane reversal (wave_partner: ds_bpermute, no LDS round trip, no barrier); else through LDS.
-  constexpr bool kWS = WaveSplit<LOGB>::ok;
+  constexpr bool kWS = WaveSplitQ<LOGB>::ok;
+  typedef WaveSplitQ<LOGB> WQ;
   C part[kWS ? P::E : 1];
   if constexpr (kWS) {
 #pragma unroll
-    for (int e = 0; e < P::E; ++e) part[e] = wave_partner<LOGB, float>(v, tid, e);
+    for (int e = 0; e < P::E; ++e) part[e] = wave_partner_pos<LOGB, float>(v, tid, WQ::reg_pos(e));
   } else {
     core_sync<SOLO>();
 #pragma unroll
@@ -1431,8 +1456,9 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   // 3. inverse split needs Y[k] and Y[B-k] in the in_idx mapping (= the out_idx mapping when the plan has no final
   //    radix-2/4 pass): through the wave again, or through LDS
   if constexpr (kWS) {
+    // (the inverse's first pass wants position e in register e: y is indexed by output register, so position e = y[pos_reg(e)])
 #pragma unroll
-    for (int e = 0; e < P::E; ++e) part[e] = wave_partner<LOGB, float>(y, tid, e);
+    for (int e = 0; e < P::E; ++e) part[e] = wave_partner_pos<LOGB, float>(y, tid, e);
   } else {
     core_sync<SOLO>();
 #pragma unroll
@@ -1445,7 +1471,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   for (int e = 0; e < P::E; ++e) {
     const int k = P::in_idx(tid, e);
     C Yk;
-    if constexpr (kWS) Yk = y[e];
+    if constexpr (kWS) Yk = y[WQ::pos_reg(e)];
     else Yk = lds[lpad(k)];
     if (k == 0) {
       v[e] = mk<float>(sc * (Yk.x + Yk.y), sc * (Yk.x - Yk.y));
