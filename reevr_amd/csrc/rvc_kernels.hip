@@ -1413,8 +1413,8 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
     __builtin_amdgcn_sched_barrier(0);
     load_wsi();
   }
-  // The real split pairs bin k with bin B - k. Head blocks of 64 / 512: the whole transform lives in one wave and the
-  // partner arrives through a lane reversal (wave_partner: ds_bpermute, no LDS round trip, no barrier); else through LDS.
+  // The real split pairs bin k with bin B - k. Head blocks of 64 ... 512: the whole transform lives in one wave and the
+  // partner arrives through a lane reversal (wave_partner_pos: ds_bpermute, no LDS round trip, no barrier); else through LDS.
   constexpr bool kWS = WaveSplitQ<LOGB>::ok;
   typedef WaveSplitQ<LOGB> WQ;
   C part[kWS ? P::E : 1];
