@@ -95,3 +95,27 @@ def test_wet_bus_matches_scalar_loop():
     from tests.ref_wetbus import ref_wet_bus
     want = ref_wet_bus(wet, yrev, width, dg, wg, dry)            # ... against the oracle-side scalar restatement
     assert np.array_equal(out, want)
+
+
+def test_pmc_summary_kernel_families():
+    """tools/pmc_summarize.py: rocprofv3 kernel names -> the families bench.py reports (first- vs second-level sweeps are told
+    apart by the instantiation, not by the tile size)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "pmc_summarize", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "pmc_summarize.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    fam = lambda n: m.family(n, 9, 13)
+    assert fam("void rvc::k_fused_block2w<9, false, false>(rvc::FusedArgs, rvc::FirArgs)") == "fused_block"
+    assert fam("void rvc::k_fdl_sweep<16, 1, 0, 2, 4, 3, true>(rvc::FirArgs, int)") == "sweep_head"
+    assert fam("void rvc::k_fdl_sweep<8, 1, 0, 4, 4, 3, false>(rvc::FirArgs, int)") == "sweep2_head"
+    assert fam("void rvc::k_fdl_sweep<8, 1, 0, 4, 4, 3, true>(rvc::FirArgs, int)") == "sweep_head"
+    assert fam("void rvc::k_fdl_sweep<8, 4, 1, 4, 4, 3, false>(rvc::FirArgs, int)") == "sweep_tail"
+    assert fam("void rvc::k_fdl_sweep<16, 1, 1, 4, 4, 2, true>(rvc::FirArgs, int)") == "sweep_tail"
+    assert fam("void rvc::k_fdl_sweep<8, 1, 1, 4, 4, 3, false>(rvc::FirArgs, int)") == "sweep2_tail"
+    assert fam("void rvc::k_fdl_patch<1, true>(rvc::FirArgs, int)") == "fir_tail"
+    assert fam("void rvc::k_fft8_inv<13, float, false>(rvc::InvArgs)") == "fft_inv_tail"
+    assert fam("void rvc::k_fft8_fwd_loop<13>(rvc::FwdArgs, int)") == "fft_fwd_tail"
+    assert fam("void rvc::k_fft8_fwd<13, double>(rvc::FwdArgs)") is None
+
