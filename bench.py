@@ -791,7 +791,7 @@ def side_measurements(torch, reevr_amd, synth, irs2, local_rank, dev, host_block
     """ONE stereo pair (the plug-in's own case), three ways. Not the headline."""
     out = {}
     # (a) block-synchronous: per 512-frame block, device-resident loop and host-pointer calls (the audio thread's view),
-    #     with one launch per block (tail job inline / on the second stream) and with the resident kernel
+    #     with one launch per block (tail job inline / on the second stream)
     nblk = 3000
     xs_h = np.stack([synth.synth_input(host_block * nblk, c) for c in range(2)])
     xs = torch.from_numpy(xs_h).to(dev)
@@ -799,8 +799,7 @@ def side_measurements(torch, reevr_amd, synth, irs2, local_rank, dev, host_block
     torch.cuda.synchronize()
     res = {}
     for mode, kw in (("tail_on_second_stream", dict(bg_stream=True)), ("tail_inline", dict(bg_stream=False)),
-                     ("tail_inline_f32", dict(bg_stream=False, fft_f32=True)),
-                     ("persistent_kernel", dict(bg_stream=True, persistent=True))):
+                     ("tail_inline_f32", dict(bg_stream=False, fft_f32=True))):
         s = reevr_amd.ConvolverSet(2, device=local_rank, **kw)
         assert s.init(host_block, tail, irs2, max_len=host_block)
         s.process_device_blocks(xs[:, :host_block * 200].contiguous(), host_block)
@@ -819,8 +818,7 @@ def side_measurements(torch, reevr_amd, synth, irs2, local_rank, dev, host_block
                                 "note": "ONE stereo pair. us_per_block: one process_device() call per 512-frame block back to back "
                                         "(host loop in C); host_call_us: rvc_set_process() on host buffers per block, back to back "
                                         "(pinned staging + hand-off + kernel + copy back; stopwatch in C). Default precision of a "
-                                        "set this small: tail transforms (8192) in double; tail_inline_f32 = RVC_FLAG_FFT_F32. "
-                                        "persistent_kernel = RVC_FLAG_PERSISTENT (experimental: resident kernel fed through a doorbell)"}
+                                        "set this small: tail transforms (8192) in double; tail_inline_f32 = RVC_FLAG_FFT_F32."}
     # (b) offline: one 40 s call per step (adaptive partitioning) and (c) the same through the fixed head/tail sizes
     frames = 40 * SR
     xl = torch.from_numpy(np.stack([synth.synth_input(frames, c) for c in range(2)])).to(dev)

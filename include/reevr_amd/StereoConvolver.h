@@ -39,7 +39,7 @@ struct Impulse {
 class StereoConvolver {
  public:
   // flags: RVC_FLAG_* of rvc.h for both channel pairs (default: tail stage on the second stream, like the reference's
-  // background thread; add RVC_FLAG_PERSISTENT for the resident per-block kernel)
+  // background thread)
   explicit StereoConvolver(int device = 0, unsigned flags = RVC_FLAG_BG_STREAM)
       : _main(rvc_set_create(2, device, flags)),
         _cross(rvc_set_create(2, device, flags)) {}

@@ -36,7 +36,8 @@ enum {
   RVC_ERR_NO_DEVICE = 1,   /* no HIP device / hipSetDevice failed */
   RVC_ERR_HIP = 2,         /* a HIP call failed; rvc_last_error_string has the detail */
   RVC_ERR_BAD_ARG = 3,     /* zero block size, len > max_len, NULL pointer ... */
-  RVC_ERR_UNSUPPORTED = 4, /* reserved (block sizes above RVC_MAX_BLOCK are clamped, not refused) */
+  RVC_ERR_UNSUPPORTED = 4, /* a removed option was asked for (RVC_FLAG_PERSISTENT); block sizes above RVC_MAX_BLOCK are
+                              clamped, not refused */
   RVC_ERR_NOT_INIT = 5
 };
 
@@ -76,21 +77,13 @@ enum {
                                    next 8 blocks (only partitions whose input has already arrived), the blocks in
                                    between add their few recent partitions: same sums, same zero latency, ~3.5x fewer
                                    HBM bytes where the path is bandwidth-bound (many lock-step channels). Delay lines
-                                   of more than 40 partitions get two levels of it: a first-level sweep every 16
-                                   blocks over all partitions, second-level sweeps every 8 blocks over what arrived
+                                   of more than 24 partitions get two levels of it: a first-level sweep every 16
+                                   blocks (32 from 80 partitions on) over all partitions, second-level sweeps every 8 blocks over what arrived
                                    since (BASELINE config 3's 350 tail partitions: ~1.7x fewer bytes again). */
 
-#define RVC_FLAG_PERSISTENT 64u  /* EXPERIMENTAL, and since round 3 SLOWER than ordinary launches (stereo pair, MI355X: 9.7 vs
-                                   6.3 us per block; host call median 17 vs 11.7 us, p99 33 vs 21-30: DESIGN.md 5b / 7).
-                                   Per-block calls (a call inside one head block, head block 512 ... 4096) are served by ONE
-                                   RESIDENT kernel fed through a doorbell in pinned host memory instead of one launch per
-                                   block (the loop of TwoStageFFTConvolver.cpp:151-233): no launch on the latency path.
-                                   The kernel parks itself after 2 s without a call and is relaunched by the next one.
-                                   Device-pointer calls are pipelined: rvc_set_sync() is the only completion point
-                                   (the resident kernel is not on rvc_set_stream) and d_in must be COMPLETE when the call
-                                   is made -- the resident kernel reads it as soon as the command is pushed, on no stream
-                                   an event could order it behind. Other call patterns, and sets whose workgroups would
-                                   not all be resident at once, fall back to ordinary launches. */
+#define RVC_FLAG_PERSISTENT 64u  /* REMOVED in round 4 (the resident-kernel mode of rounds 2-3 lost to ordinary launches on
+                                   latency, p99 and throughput). The bit stays reserved: a set created with it reports
+                                   RVC_ERR_UNSUPPORTED and every init on it fails -- never silently ignored. */
 #define RVC_FLAG_FORCE_TIME_TILING 32u /* testing: time-tile every stage that has partitions to tile, however small
                                    (by default only stages whose per-block sweep is long enough to be bandwidth-bound) */
 #define RVC_FLAG_CHILD_SETS 1024u /* throughput option for sets of >= 2048 block-synchronous channels: serve the set by child sets
@@ -355,10 +348,6 @@ int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re,
  * Returns 1 on success. */
 int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int delay, long long k0, int ring_rows,
                   const float *H, const float *X, const float *Yadd, float *Y, long long x_hi, long long x_from);
-
-/* RVC_FLAG_PERSISTENT diagnostics: the median host -> resident kernel -> host round trip of n empty commands,
- * microseconds (-1: not persistent). */
-double rvc_debug_persist_rtt(rvc_set *s, int n);
 
 /* Measurement hook (bench.py, tools/): process-wide schedule knobs, read when a set is initialised. Returns 1 if the
  * key is known. Keys: "k1" first-level tile of long delay lines (8 = one level, 16 default, 32); "sweep_split" -1 auto /

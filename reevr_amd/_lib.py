@@ -87,7 +87,6 @@ SIGNATURES = {
     "rvc_send_pre_device": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "rvc_debug_rfft": (C.c_int, [C.c_int, C.c_size_t, C.c_int, F32P, F32P, F32P]),
     "rvc_debug_irfft": (C.c_int, [C.c_int, C.c_size_t, C.c_int, F32P, F32P, F32P]),
-    "rvc_debug_persist_rtt": (C.c_double, [C.c_void_p, C.c_int]),
     "rvc_debug_fdl": (C.c_int, [C.c_int] * 7 + [C.c_longlong, C.c_int, F32P, F32P, F32P, F32P, C.c_longlong, C.c_longlong]),
     "rvc_debug_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "rvc_debug_guard_check": (C.c_long, [C.c_void_p]),

@@ -33,7 +33,7 @@ class ConvolverSet:
     """n independent mono convolvers sharing one block geometry (one launch per stage)."""
 
     def __init__(self, n_channels: int, device: int = 0, bg_stream: bool = False, timing: bool = False,
-                 fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True, persistent: bool = False,
+                 fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True,
                  fft_f32: bool = False, child_sets: bool = False):
         """time_tiling: True (by size) / False / "force" (every stage, one level unless long) / "force2" (two levels).
         fft_f64 / fft_f32: every transform in double / in float (default: rvc.h, RVC_FLAG_FFT_F64).
@@ -45,8 +45,7 @@ class ConvolverSet:
                  | (0 if time_tiling else L.RVC_FLAG_NO_TIME_TILING)
                  | (L.RVC_FLAG_FORCE_TIME_TILING if time_tiling == "force" else 0)
                  | (L.RVC_FLAG_FORCE_TWO_LEVEL if time_tiling == "force2" else 0)
-                 | (L.RVC_FLAG_PERSISTENT if persistent else 0) | (L.RVC_FLAG_CHILD_SETS if child_sets else 0))
-        self.persistent = bool(persistent)
+                 | (L.RVC_FLAG_CHILD_SETS if child_sets else 0))
         self.n_channels = int(n_channels)
         self.device = int(device)
         self._h = self._lib.rvc_set_create(self.n_channels, self.device, flags)
@@ -141,12 +140,8 @@ class ConvolverSet:
 
     def _order_after_torch(self):
         """The engine runs on its own (non-blocking) HIP streams: make them wait for whatever torch's
-        current stream has queued (the kernels still producing d_in). Returns the wrapped streams (one per child set).
-        Persistent sets: the resident kernel is on no stream an event could hold back and reads d_in as soon as the
-        command is pushed, so torch's current stream is drained on the host first (rvc.h, RVC_FLAG_PERSISTENT)."""
+        current stream has queued (the kernels still producing d_in). Returns the wrapped streams (one per child set)."""
         import torch
-        if self.persistent:
-            torch.cuda.current_stream(self.device).synchronize()
         ptrs = [self._lib.rvc_set_stream(self._h, 2 * k) for k in range(max(1, self._lib.rvc_set_subsets(self._h)))]
         ptrs = [p for p in ptrs if p]
         if not ptrs:
@@ -181,7 +176,7 @@ class ConvolverSet:
         ext = self._order_after_torch() if order else None
         self._lib.rvc_set_process_device(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(),
                                          d_out.stride(0), d_in.shape[1])
-        if sync or self.persistent:     # (persistent mode: completion is only observable through sync)
+        if sync:
             self.sync()
             self.check()
         else:
@@ -201,7 +196,7 @@ class ConvolverSet:
         ext = self._order_after_torch() if order else None
         self._lib.rvc_set_process_device_blocks(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(),
                                                 d_out.stride(0), d_in.shape[1], block)
-        if sync or self.persistent:
+        if sync:
             self.sync()
             self.check()
         else:

@@ -27,8 +27,8 @@
 //   * causal time tiling of the delay lines (Tile tA / tT, rvc_internal.h): every 8th block a sweep reads a stage's IR
 //     spectra and delay line once and leaves partial sums for 8 blocks, the blocks in between patch in the few
 //     partitions whose input arrived since; long delay lines get two levels of it (first-level tiles of 16 / 32 blocks);
-//   * RVC_FLAG_PERSISTENT: the per-block launch is replaced by one resident kernel fed through a command ring in pinned host
-//     memory (pk_* functions below); sweeps and tail jobs stay ordinary launches, issued when a block retires.
+//   (the resident-kernel mode of rounds 2-3, RVC_FLAG_PERSISTENT, was removed in round 4: it lost to this launch path on
+//   latency, p99 and throughput; the flag is rejected at create)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -93,7 +93,7 @@ struct TimedLaunch {
 struct Tile {
   bool on = false;
   int K1 = rvc::kSweepRows;      // blocks per first-level tile: 8 (one level), 16 or 32
-  int rows1 = rvc::kSweepRows;   // rows of s1 per channel (K1; twice that in persistent mode)
+  int rows1 = rvc::kSweepRows;   // rows of s1 per channel (= K1)
   float2 *s1 = nullptr, *s2 = nullptr;   // [nch][rows1][B], [nch][kSweepRows][B]
   long long t0 = -1;             // blocks [t0, t0 + K1) have first-level rows; -1: none
   long long s0 = -1;             // blocks [s0, s0 + kSweepRows), s0 > t0, have second-level rows; -1: none
@@ -155,20 +155,6 @@ struct rvc_set {
   Tile tA, tT;                             // zero-latency stage / tail stage
   const float2 *ypre_cur = nullptr;        // where the accumulator of block ypre_block lives: a ypre half or a sweep row
   long long ypre_cur_stride = 0;
-  // Persistent block-synchronous kernel (RVC_FLAG_PERSISTENT; rvc_internal.h PkArgs)
-  bool pk_enabled = false, pk_running = false, pk_slot = false;
-  rvc::PkCtl *pk_ctl = nullptr;            // pinned host: doorbell + command ring
-  unsigned *pk_ypre_seq = nullptr, *pk_park = nullptr, *pk_x_seq = nullptr;   // device
-  unsigned *h_pdone = nullptr;             // pinned host: completion flags of the patch workgroups
-  float2 *pk_zero_row = nullptr;           // [nch][B] zeros: the accumulator of blocks 0 and 1 after the clock restarted
-  hipStream_t st_pk = nullptr;
-  int pk_n_audio = 0, pk_n_patch = 0;
-  unsigned pk_seq = 0, pk_retired = 0;     // last command pushed / last one whose block has been retired
-  struct PkStep { long long n0, n1, k; bool block_done; } pk_steps[rvc::kPkRing];
-  long long pk_tile_hi = -1, pk_tile_ready = -1;   // sweeps launched / known complete for every tile start <= this
-  hipEvent_t ev_sweep = nullptr;
-  bool pk_need_acquire = false;
-  unsigned pk_ypre_from = 0;               // step whose patch produces the accumulator of block ypre_block (0: a launch)
   float *d_in = nullptr, *d_out = nullptr;     // staging for the host-pointer API [nch][max_len]
   float *h_in = nullptr, *h_out = nullptr;     // pinned
   long long n = 0;               // absolute sample clock
@@ -325,7 +311,6 @@ bool ensure_streams(rvc_set *s) {
   //  background stream confined to 192 / 128 / 64 CUs by a CU mask change the step time by less than 2 % either way.)
   RVC_CK(hipStreamCreateWithFlags(&s->st_main, hipStreamNonBlocking));
   RVC_CK(hipStreamCreateWithFlags(&s->st_bg, hipStreamNonBlocking));
-  RVC_CK(hipEventCreateWithFlags(&s->ev_sweep, hipEventDisableTiming));
   RVC_CK(hipEventCreateWithFlags(&s->ev_ingest, hipEventDisableTiming));
   RVC_CK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
   for (s->ev_free = 0; s->ev_free < rvc_set::kMaxJobs; ++s->ev_free)
@@ -377,19 +362,7 @@ void drop_timing(rvc_set *s) {
   }
 }
 
-void pk_stop(rvc_set *s);
-bool pk_acquire_slot();
-void pk_release_slot(rvc_set *s);
-
 void free_device_state(rvc_set *s) {
-  pk_stop(s);
-  pk_release_slot(s);
-  rvc::FreeGuard guard;              // (other sets' resident kernels stand down while this one frees)
-  if (s->pk_ctl) hipHostFree(s->pk_ctl);
-  if (s->h_pdone) hipHostFree(s->h_pdone);
-  dev_free(s, s->pk_ypre_seq); dev_free(s, s->pk_park); dev_free(s, s->pk_zero_row); dev_free(s, s->pk_x_seq);
-  s->pk_ctl = nullptr; s->h_pdone = nullptr; s->pk_ypre_seq = s->pk_park = s->pk_x_seq = nullptr; s->pk_zero_row = nullptr;
-  s->pk_enabled = false;
   if (s->streams_ok) {
     hipSetDevice(s->device);
     hipStreamSynchronize(s->st_bg);
@@ -520,6 +493,12 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   auto drop = [&]() { if (s->streams_ok || s->live) free_device_state(s); };
   s->err = RVC_OK;
   s->errstr.clear();
+  if ((s->flags & RVC_FLAG_PERSISTENT) != 0) {   // the resident-kernel mode of rounds 2-3: removed, not silently ignored
+    drop();
+    s->err = RVC_ERR_UNSUPPORTED;
+    s->errstr = "RVC_FLAG_PERSISTENT was removed (round 4): ordinary launches are faster on every metric";
+    return false;
+  }
   if (head_block == 0 || (two_stage && tail_block == 0)) {   // TwoStageFFTConvolver.cpp:94-97, FFTConvolver.cpp:97-100
     drop();
     s->err = RVC_ERR_BAD_ARG;
@@ -593,9 +572,6 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   if (s->live && s->two_stage == two_stage && s->head == hb && s->tail == tail_pub && s->max_len == eff_max_len &&
       s->A.P == (int)pa && s->T.P == (int)pt && s->T.PF == (int)pf && s->W.P == (int)pw) {
     if (!use_device(s)) return false;
-    pk_stop(s);                                   // (the IR spectra change: the resident kernel is relaunched by the next call)
-    s->pk_tile_hi = s->pk_tile_ready = -1;
-    s->pk_ypre_from = 0;
     hipStreamSynchronize(s->st_bg);
     hipStreamSynchronize(s->st_main);
     drop_jobs(s);
@@ -668,13 +644,6 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     tA.on = tiling && s->fold && !s->block_general && A.B >= 64 &&
             (force ? pa >= 3 : (pa >= 16 && (size_t)s->nch * (pa - 2) * A.B * 16 >= ((size_t)4 << 20)));
     tT.on = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
-    // persistent mode: the resident kernel only ever adds a few recent partitions, so the zero-latency stage is tiled
-    bool pk = (s->flags & RVC_FLAG_PERSISTENT) != 0 && tiling && s->fold && rvc::persist_supported(A.logB) && pa >= 3;
-    // (its workgroups spin on each other: the whole grid must be resident at once, else ordinary launches)
-    pk = pk && rvc::persist_workgroups(A.logB, s->nch, nullptr, nullptr) <= rvc::persist_capacity(A.logB);
-    if (pk && !s->pk_slot) pk = s->pk_slot = pk_acquire_slot();     // (none left: this set uses ordinary launches)
-    if (pk) tA.on = true;
-    s->pk_enabled = pk;
     // one level of 8 blocks, or -- long delay lines -- a first level of 16 / 32 blocks with second-level sweeps every 8
     auto first_level = [&](size_t P) -> int {
       // g_tune.k1: 0 = by length (16 above kTwoLevelMinP partitions, 32 from kLongLineMinP on: measured, profiles/r3_tuning.txt)
@@ -683,41 +652,13 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
       const int minp = g_tune.two_min_p >= 0 ? g_tune.two_min_p : rvc::kTwoLevelMinP;
       return (force2 || (int)P > minp) ? k1 : (int)K;
     };
-    tA.K1 = pk ? (int)K : first_level(pa);       // (the resident kernel's own tile scheme has one level)
-    tA.rows1 = tA.K1 * (pk ? 2 : 1);
+    tA.K1 = first_level(pa);
+    tA.rows1 = tA.K1;
     tT.K1 = first_level(pt);
     tT.rows1 = tT.K1;
     if (tA.on) {
       RVC_CK(dev_alloc(s, &tA.s1, sizeof(float2) * (size_t)s->nch * (size_t)tA.rows1 * A.B));
       if (tA.K1 > (int)K) RVC_CK(dev_alloc(s, &tA.s2, sizeof(float2) * (size_t)s->nch * K * A.B));
-    }
-    if (pk) {
-      if (!s->st_pk) {
-        // the resident kernel gets a stream of its own priority class: the runtime multiplexes streams of one class onto a
-        // few hardware queues, and an ordinary launch queued behind a kernel that never ends would never start. (Created for
-        // persistent sets only: sets that never asked for one should not see a second priority class on the device.)
-        int lo = 0, hi = 0;
-        RVC_CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        RVC_CK(hipStreamCreateWithPriority(&s->st_pk, hipStreamNonBlocking, hi));
-      }
-      rvc::persist_workgroups(A.logB, s->nch, &s->pk_n_audio, nullptr);
-      s->pk_n_patch = rvc::persist_workgroups(A.logB, s->nch, nullptr, nullptr) - s->pk_n_audio;
-      RVC_CK(hipHostMalloc(&s->pk_ctl, sizeof(rvc::PkCtl), hipHostMallocDefault));
-      std::memset((void *)s->pk_ctl, 0, sizeof(rvc::PkCtl));
-      RVC_CK(hipHostMalloc(&s->h_pdone, sizeof(unsigned) * (size_t)s->pk_n_patch, hipHostMallocDefault));
-      std::memset(s->h_pdone, 0, sizeof(unsigned) * (size_t)s->pk_n_patch);
-      RVC_CK(dev_alloc(s, &s->pk_ypre_seq, sizeof(unsigned) * (size_t)s->pk_n_patch));
-      RVC_CK(hipMemsetAsync(s->pk_ypre_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_patch, s->st_main));
-      RVC_CK(dev_alloc(s, &s->pk_x_seq, sizeof(unsigned) * (size_t)s->pk_n_audio));
-      RVC_CK(hipMemsetAsync(s->pk_x_seq, 0, sizeof(unsigned) * (size_t)s->pk_n_audio, s->st_main));
-      RVC_CK(dev_alloc(s, &s->pk_park, sizeof(unsigned)));
-      RVC_CK(hipMemsetAsync(s->pk_park, 0, sizeof(unsigned), s->st_main));
-      RVC_CK(dev_alloc(s, &s->pk_zero_row, sizeof(float2) * (size_t)s->nch * A.B));
-      RVC_CK(hipMemsetAsync(s->pk_zero_row, 0, sizeof(float2) * (size_t)s->nch * A.B, s->st_main));
-      s->pk_seq = s->pk_retired = 0;
-      s->pk_tile_hi = s->pk_tile_ready = -1;
-      s->pk_need_acquire = false;
-      s->pk_ypre_from = 0;
     }
     if (tT.on) {
       RVC_CK(dev_alloc(s, &tT.s1, sizeof(float2) * (size_t)s->nch * (size_t)tT.rows1 * T.B));
@@ -731,7 +672,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   RVC_CK(hipHostMalloc(&s->h_flags, sizeof(unsigned) * (size_t)s->nch, hipHostMallocDefault));   // (>= audio workgroups)
   std::memset(s->h_flags, 0, sizeof(unsigned) * (size_t)s->nch);
   s->flag_seq = 0; s->flag_count = 0;
-  RVC_CK(hipStreamSynchronize(s->st_main));      // (not hipDeviceSynchronize: other sets' resident kernels never finish)
+  RVC_CK(hipStreamSynchronize(s->st_main));
   RVC_CK(hipStreamSynchronize(s->st_bg));
   s->n = 0;
   s->tail_fft_done = 0;
@@ -1108,309 +1049,6 @@ void mark_long_stage_stale(rvc_set *s, long long n1) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Persistent block-synchronous mode (RVC_FLAG_PERSISTENT): host side of k_persist. One command per per-block
-// call goes into the ring in pinned host memory; sweeps and tail jobs stay ordinary launches, issued here when a
-// block RETIRES (its audio workgroups have published their completion flags).
-// ------------------------------------------------------------------------------------------
-constexpr double kPkHostTimeoutS = 5.0;
-// Resident kernels of one process share the few hardware queues of their priority class: more than this many at once
-// could queue one behind another (and wait for it to park). Further persistent sets use ordinary launches.
-constexpr int kPkMaxResident = 2;
-std::atomic<int> g_pk_resident{0};
-std::atomic<int> g_pk_pause{0};       // threads about to free device memory (rvc::free_guard_enter)
-// resident kernels launched and not yet collected by their owner (process-wide). One that has PARKED itself is still
-// listed until its owner's next call, but no longer holds a stream busy: free_guard_enter skips those.
-std::mutex g_pk_mu;
-std::vector<rvc::PkCtl *> g_pk_live;
-void pk_register(rvc::PkCtl *c) { std::lock_guard<std::mutex> l(g_pk_mu); g_pk_live.push_back(c); }
-void pk_unregister(rvc::PkCtl *c) {
-  std::lock_guard<std::mutex> l(g_pk_mu);
-  g_pk_live.erase(std::remove(g_pk_live.begin(), g_pk_live.end(), c), g_pk_live.end());
-}
-int pk_busy_count() {
-  std::lock_guard<std::mutex> l(g_pk_mu);
-  int n = 0;
-  for (rvc::PkCtl *c : g_pk_live) n += (c->parked == 0 && c->error == 0) ? 1 : 0;
-  return n;
-}
-bool pk_paused() { return g_pk_pause.load(std::memory_order_acquire) > 0; }
-
-void pk_push(rvc_set *s, const rvc::PkCmd &c) {
-  rvc::PkCtl *ctl = s->pk_ctl;
-  volatile unsigned long long *slot = reinterpret_cast<volatile unsigned long long *>(&ctl->ring[c.seq % rvc::kPkRing]);
-  const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&c);
-  // the device polls the slot itself: each 64-byte line gets its payload first and its sequence word last
-  for (int i = 0; i < 7; ++i) slot[i] = src[i];
-  for (int i = 8; i < 15; ++i) slot[i] = src[i];
-  std::atomic_thread_fence(std::memory_order_release);
-  slot[7] = c.seq;
-  slot[15] = c.seq;
-  std::atomic_thread_fence(std::memory_order_release);
-  ctl->doorbell = c.seq;                                     // (informational: newest command)
-}
-
-bool pk_launch(rvc_set *s, unsigned seq0) {
-  Stage &A = s->A, &T = s->T;
-  const bool has_tail = T.P > 0;
-  const long long hb = (long long)A.B;
-  RVC_CK(hipMemsetAsync(s->pk_park, 0, sizeof(unsigned), s->st_pk));
-  s->pk_ctl->parked = 0;
-  rvc::PkArgs a{};
-  a.fa.ring = s->xring; a.fa.ring_chan_stride = (long long)s->ring_cap; a.fa.ring_mask = s->ring_cap - 1;
-  a.fa.tw = A.tw; a.fa.wsplit = A.wsplit; a.fa.tw8 = A.tw8;
-  a.fa.H0 = A.H; a.fa.h_chan_stride = (long long)A.P * hb;
-  a.fa.H1 = A.P > 1 ? A.H + hb : nullptr;
-  a.fa.Xrow = A.X; a.fa.x_chan_stride = (long long)A.rows * hb; a.fa.x_row_mask = A.rows - 1;
-  a.fa.add = has_tail ? s->tailring : nullptr;
-  a.fa.add_chan_stride = (long long)s->ring_cap; a.fa.add_mask = s->ring_cap - 1;
-  a.fa.add_from = has_tail ? 2 * (long long)T.B : 0;
-  a.pf.H = A.H + 2 * hb; a.pf.h_chan_stride = (long long)A.P * hb;
-  a.pf.X = A.X; a.pf.x_chan_stride = (long long)A.rows * hb; a.pf.x_row_mask = A.rows - 1;
-  a.pf.delay = 2; a.pf.B = (int)hb; a.pf.M = 1;
-  a.ctl = s->pk_ctl; a.ypre_seq = s->pk_ypre_seq; a.x_seq = s->pk_x_seq; a.park = s->pk_park;
-  a.h_done = s->h_flags; a.h_pdone = s->h_pdone;
-  a.seq0 = seq0;
-  a.idle_ticks = (long long)(2.0 * 1e8);                     // 2 s of a silent doorbell: the kernel parks itself
-  if (const char *e = std::getenv("RVC_PERSIST_IDLE_MS")) a.idle_ticks = (long long)(std::atof(e) * 1e5);
-  RVC_CK(rvc::launch_persist(A.logB, a, s->nch, s->st_pk));
-  s->pk_running = true;
-  pk_register(s->pk_ctl);
-  return true;
-}
-
-// a slot among the process's resident kernels (taken at init, returned when the set's device state goes)
-bool pk_acquire_slot() {
-  int cur = g_pk_resident.load();
-  while (cur < kPkMaxResident)
-    if (g_pk_resident.compare_exchange_weak(cur, cur + 1)) return true;
-  return false;
-}
-void pk_release_slot(rvc_set *s) {
-  if (s->pk_slot) { g_pk_resident.fetch_sub(1); s->pk_slot = false; }
-}
-
-// the kernel parked itself (idle) or hit an internal error: collect it; commands after the last retired one replay
-bool pk_collect(rvc_set *s) {
-  if (!s->pk_running) return true;
-  RVC_CK(hipStreamSynchronize(s->st_pk));
-  s->pk_running = false;
-  pk_unregister(s->pk_ctl);
-  if (s->pk_ctl->error) {
-    char buf[96];
-    snprintf(buf, sizeof(buf), "persistent kernel gave up (code 0x%llx)", (unsigned long long)s->pk_ctl->error);
-    s->pk_ctl->error = 0;
-    if (s->err == RVC_OK) { s->err = RVC_ERR_HIP; s->errstr = buf; }
-    return false;
-  }
-  return true;
-}
-
-bool pk_ensure_running(rvc_set *s) {
-  if (s->pk_running && (s->pk_ctl->parked || s->pk_ctl->error)) { if (!pk_collect(s)) return false; }
-  if (!s->pk_running) return pk_launch(s, s->pk_retired);   // (every step is idempotent: unretired ones simply run again)
-  return true;
-}
-
-// wait until every workgroup of the given kind has completed step `seq`
-bool pk_wait_flags(rvc_set *s, volatile unsigned *f, int n, unsigned seq) {
-  const auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < n; ++i) {
-    unsigned spins = 0;
-    while ((int)(f[i] - seq) < 0) {
-      if ((++spins & 0xfffu) == 0) {
-        if (!s->pk_running || s->pk_ctl->parked || s->pk_ctl->error) {   // parked under our feet: relaunch, the steps run again
-          if (!pk_ensure_running(s)) return false;
-        }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kPkHostTimeoutS)
-          return fail(s, RVC_ERR_HIP, hipSuccess, "persistent kernel: completion flag timeout");
-      }
-    }
-  }
-  std::atomic_thread_fence(std::memory_order_acquire);
-  return true;
-}
-
-// the tile [t0, t0 + K) of the resident kernel's (single-level, double-buffered) scheme: partial sums over the rows
-// <= t0 - 2 - lag
-bool pk_launch_sweep(rvc_set *s, long long t0) {
-  const rvc::FirArgs r = sweep1_args(s, false, t0, t0 - 2 - rvc::kPkLag);
-  RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
-  RVC_CK(hipEventRecord(s->ev_sweep, s->st_main));
-  s->pk_tile_hi = t0;
-  return true;
-}
-const float2 *pk_sweep_row(const rvc_set *s, long long k) {
-  return s->tA.s1 + (size_t)((unsigned long long)k & (unsigned long long)(s->tA.rows1 - 1)) * s->A.B;
-}
-
-// post-actions of the steps up to `seq`, in order, once their audio workgroups are done: the tail job of a completed
-// tail block and the sweep of the tile that starts 2 + lag blocks later
-bool pk_retire_upto(rvc_set *s, unsigned seq) {
-  const long long K = rvc::kSweepRows;
-  while ((int)(seq - s->pk_retired) > 0) {
-    const unsigned r = s->pk_retired + 1;
-    if (!pk_wait_flags(s, s->h_flags, s->pk_n_audio, r)) return false;
-    const rvc_set::PkStep &st = s->pk_steps[r % rvc::kPkRing];
-    s->pk_retired = r;
-    if (st.block_done) {
-      if (s->T.P > 0 && !run_tail_job(s, st.n0, st.n1, nullptr, 0, /*bg=*/true)) return false;
-      const long long t0 = st.k + 2 + rvc::kPkLag;
-      if (t0 % K == 0 && t0 > s->pk_tile_hi && !pk_launch_sweep(s, t0)) return false;
-    }
-  }
-  return true;
-}
-
-// every command consumed by every workgroup (before ordinary launches touch the shared buffers, clear, destroy)
-bool pk_quiesce(rvc_set *s) {
-  if (!s->pk_enabled || s->pk_seq == 0) return true;
-  if (!pk_retire_upto(s, s->pk_seq)) return false;
-  return pk_wait_flags(s, s->h_pdone, s->pk_n_patch, s->pk_seq);
-}
-
-void pk_stop(rvc_set *s) {
-  if (!s->pk_enabled || !s->pk_ctl) return;
-  // Steps that were pushed but not retired must still run and retire (their tail jobs and sweeps are issued on
-  // retirement) -- also when the kernel has parked itself meanwhile: quiescing relaunches it and the steps replay.
-  if (s->pk_retired != s->pk_seq && s->err == RVC_OK && s->streams_ok) (void)pk_quiesce(s);
-  if (s->pk_running) {
-    if (!(s->pk_ctl->parked || s->pk_ctl->error)) {
-      rvc::PkCmd c{};
-      c.flags = rvc::PK_QUIT;
-      c.seq = ++s->pk_seq;
-      pk_push(s, c);
-    }
-    hipStreamSynchronize(s->st_pk);
-    s->pk_running = false;
-    pk_unregister(s->pk_ctl);
-  }
-  s->pk_retired = s->pk_seq;
-  // nothing is resident any more: every flag stands at the last sequence number (the quit command is never acknowledged)
-  for (int i = 0; i < s->pk_n_audio && s->h_flags; ++i) s->h_flags[i] = s->pk_seq;
-  for (int i = 0; i < s->pk_n_patch && s->h_pdone; ++i) s->h_pdone[i] = s->pk_seq;
-  if (s->pk_ypre_seq && s->streams_ok) {
-    std::vector<unsigned> v((size_t)std::max(s->pk_n_patch, s->pk_n_audio), s->pk_seq);
-    hipMemcpy(s->pk_ypre_seq, v.data(), sizeof(unsigned) * (size_t)s->pk_n_patch, hipMemcpyHostToDevice);
-    hipMemcpy(s->pk_x_seq, v.data(), sizeof(unsigned) * (size_t)s->pk_n_audio, hipMemcpyHostToDevice);
-  }
-}
-
-// waitForBackgroundProcessing on the HOST: the resident kernel is on no stream that could wait for an event
-bool pk_wait_tail(rvc_set *s, long long n1) {
-  const long long m_need = (n1 - 1) / (long long)s->T.B;
-  while (s->job_count > 0 && s->jobs[s->job_head].m_lo <= m_need) {   // (only the jobs this call reads: cf. wait_tail_jobs)
-    const rvc_set::Job j = s->jobs[s->job_head];
-    RVC_CK(hipEventSynchronize(j.ev));
-    s->job_head = (s->job_head + 1) % rvc_set::kMaxJobs;
-    --s->job_count;
-    s->ev_pool[s->ev_free++] = j.ev;
-  }
-  return true;
-}
-
-// one per-block call (inside head block k0) through the resident kernel
-bool pk_step(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len) {
-  Stage &A = s->A, &T = s->T;
-  const long long hb = (long long)A.B, K = rvc::kSweepRows;
-  const long long n0 = s->n, n1 = n0 + (long long)len, k0 = n0 / hb;
-  const bool block_done = n1 % hb == 0;
-  const bool has_tail = T.P > 0;
-  // keep the ring shallow, retire what has completed (launches sweeps / tail jobs on time)
-  while (s->pk_seq - s->pk_retired >= (unsigned)(rvc::kPkRing / 4))
-    if (!pk_retire_upto(s, s->pk_retired + 1)) return false;
-  while (s->pk_retired != s->pk_seq) {
-    const unsigned r = s->pk_retired + 1;
-    bool done = true;
-    for (int i = 0; i < s->pk_n_audio && done; ++i) done = (int)(((volatile unsigned *)s->h_flags)[i] - r) >= 0;
-    if (!done) break;
-    if (!pk_retire_upto(s, r)) return false;
-  }
-  // tail contribution of this tail block: produced a tail period ago by a job on the second stream
-  if (has_tail) {
-    if (!pk_wait_tail(s, n1)) return false;
-    const long long need = (n1 - 1) / (long long)T.B + 1;
-    if (s->tail_out_done < need) {                            // (after a clock restart / other call patterns: made now)
-      // Quiescing retires the steps still in flight -- one of them may be the step that completed the tail block this
-      // call reads, and its retirement has just launched that tail job on the second stream: wait for it (the resident
-      // kernel is on no stream an event could hold back) before anything reads the tail ring.
-      if (!pk_quiesce(s)) return false;
-      if (!pk_wait_tail(s, n1)) return false;
-      if (!tail_rows(s, need, s->st_main)) return false;
-      RVC_CK(hipStreamSynchronize(s->st_main));
-    }
-  }
-  // the accumulator of block k0
-  unsigned ypre_wait = 0;
-  const float2 *ypre = nullptr;
-  long long ypre_stride = hb;
-  // (an accumulator that ordinary launches left in a sweep row is not taken over: this mode's own sweeps reuse the rows)
-  const bool in_sweep_rows = s->tA.s1 && s->ypre_cur >= s->tA.s1 && s->ypre_cur < s->tA.s1 + (size_t)s->nch * (size_t)s->tA.rows1 * A.B;
-  if (s->ypre_block == k0 && !in_sweep_rows) {
-    ypre = s->ypre_cur; ypre_stride = s->ypre_cur_stride; ypre_wait = s->pk_ypre_from;
-  } else {
-    if (!pk_quiesce(s)) return false;
-    if (k0 > s->xa_next) {     // a long call skipped head blocks: rebuild the delay line's history (ordinary launches)
-      if (!head_spectra(s, head_fft_from(s, k0), k0 - 1, n0, nullptr, 0, 0)) return false;
-      s->xa_next = k0;
-      s->pk_need_acquire = true;
-      s->pk_tile_hi = s->pk_tile_ready = -1;
-    }
-    if (k0 <= 1) {
-      ypre = s->pk_zero_row;   // no block before time 0: sum_{i>=2} H_i X_{k-i} = 0
-    } else {
-      const rvc::FirArgs r = premultiply_args(s, k0);          // the whole sum, one ordinary launch
-      RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
-      ypre = r.Y;
-    }
-    RVC_CK(hipStreamSynchronize(s->st_main));
-    s->ypre_block = k0; s->ypre_cur = ypre; s->ypre_cur_stride = hb; s->pk_ypre_from = 0;
-  }
-  // the sweep rows block k0 + 1 is patched from
-  rvc::PkCmd c{};
-  if (block_done) {
-    const long long kn = k0 + 1, t0 = kn - kn % K;
-    if (s->pk_tile_hi < t0) {     // the retire path has not launched this tile's sweep yet: the block it waits for
-      if (!pk_retire_upto(s, s->pk_seq)) return false;        // (t0 - 2 - lag) may still be in flight -- drain, then
-      if (s->pk_tile_hi < t0 && !pk_launch_sweep(s, t0)) return false;   // (entry / restart) launch it here
-    }
-    if (s->pk_tile_ready < t0) {
-      RVC_CK(hipEventSynchronize(s->ev_sweep));
-      s->pk_tile_ready = s->pk_tile_hi;
-    }
-    c.patch_P = std::min<long long>(kn - t0 + rvc::kPkLag, (long long)A.P - 2);
-    if (c.patch_P < 0) c.patch_P = 0;
-    c.patch_yadd = (unsigned long long)(uintptr_t)pk_sweep_row(s, kn);
-    c.patch_yadd_stride = (long long)s->tA.rows1 * hb;
-    c.patch_y = (unsigned long long)(uintptr_t)(s->ypre + (size_t)(kn & 1) * (size_t)s->nch * (size_t)hb);
-  }
-  if (!pk_ensure_running(s)) return false;
-  c.in = (unsigned long long)(uintptr_t)d_in; c.out = (unsigned long long)(uintptr_t)d_out;
-  c.in_stride = (long long)in_stride; c.out_stride = (long long)out_stride;
-  c.n0 = n0; c.n1 = n1; c.k = k0;
-  c.ypre = (unsigned long long)(uintptr_t)ypre; c.ypre_stride = ypre_stride; c.ypre_wait = ypre_wait;
-  c.flags = (block_done ? rvc::PK_BLOCK_DONE : 0u) | (s->pk_need_acquire ? rvc::PK_ACQUIRE : 0u) |
-            ((d_in == s->h_in && d_out == s->h_out) ? rvc::PK_IO_HOST : 0u);
-  s->pk_need_acquire = false;
-  c.seq = ++s->pk_seq;
-  s->pk_steps[c.seq % rvc::kPkRing] = rvc_set::PkStep{n0, n1, k0, block_done};
-  pk_push(s, c);
-  if (block_done) {
-    const long long kn = k0 + 1;
-    s->ypre_block = kn;
-    if (c.patch_P > 0) {
-      s->ypre_cur = reinterpret_cast<const float2 *>((uintptr_t)c.patch_y); s->ypre_cur_stride = hb;
-    } else {                                                   // (nothing to add: the sweep row is the accumulator)
-      s->ypre_cur = pk_sweep_row(s, kn); s->ypre_cur_stride = c.patch_yadd_stride;
-    }
-    s->pk_ypre_from = c.seq;
-  }
-  s->xa_next = block_done ? k0 + 1 : k0;
-  mark_long_stage_stale(s, n1);
-  s->n = n1;
-  return true;
-}
-
 // one process() step of at most max_len samples, device buffers, asynchronous
 bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len) {
   Stage &A = s->A, &T = s->T;
@@ -1436,23 +1074,6 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   }
 
   // ---- latency path: the call stays inside one head block (the plugin's per-block call) ----
-  if (k0 == k1 && s->pk_enabled && !pk_paused()) {
-    if (s->out_copy_len != 0) {          // host-pointer call: the resident kernel reads / writes the pinned buffers itself
-      s->out_copy_len = 0;
-      s->flag_count = -1;                // process_end: wait for this step's completion flags
-    }
-    s->tA.drop();                        // (the sweep rows now follow the resident kernel's tile scheme)
-    return pk_step(s, d_in, in_stride, d_out, out_stride, len);
-  }
-  if (s->pk_enabled) {
-    // any other call pattern -- or another thread is about to free device memory (free_guard_enter) and the resident
-    // kernel has to stand down: ordinary launches; the accumulators / sweep rows are handed over through ypre_block
-    if (pk_paused()) pk_stop(s);
-    else if (!pk_quiesce(s)) return false;
-    s->pk_need_acquire = true;
-    s->pk_tile_hi = s->pk_tile_ready = -1;
-    s->pk_ypre_from = 0;
-  }
   if (k0 == k1 && !s->block_general && rvc::fused_supported(A.logB, A.f64)) {
     if (has_tail) {
       if (bg) { if (!wait_tail_jobs(s, n1)) return false; }
@@ -1481,8 +1102,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     const bool block_done = n1 % hb == 0;
     // host-pointer call through the pinned buffers: the audio workgroups publish completion flags and
     // process_end polls them -- no event behind the kernel, no wait for the kernel's tail
-    const bool flagged = s->out_copy_len != 0 && s->zero_copy && !s->timing && !s->pk_enabled;   // (persistent sets: the
-                                                       // flags carry the resident kernel's sequence numbers)
+    const bool flagged = s->out_copy_len != 0 && s->zero_copy && !s->timing;
     if (flagged) {
       g.done_flag = s->h_flags;
       g.seq = ++s->flag_seq;
@@ -1715,7 +1335,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
 // How many children a set of nch channels gets at this init (1: none; RVC_FLAG_CHILD_SETS asks for them, the measurement
 // hook's "subsets" forces a count). Measured on MI355X (profiles/r3_tuning.txt).
 int subset_count(const rvc_set *s, size_t head_block, size_t max_len) {
-  if ((s->flags & (RVC_FLAG_PERSISTENT | RVC_FLAG_NO_SUBSETS)) != 0) return 1;
+  if ((s->flags & RVC_FLAG_NO_SUBSETS) != 0) return 1;
   int n = g_tune.subsets;
   // RVC_FLAG_CHILD_SETS: two children for sets of thousands of lock-step channels served block by block, four from 8192 on
   // (measured on MI355X, BASELINE config 2: 4096 channels 13.2 -> 14.3 Gsamples/s with two, 13.1 with four; 8192 channels
@@ -1725,7 +1345,6 @@ int subset_count(const rvc_set *s, size_t head_block, size_t max_len) {
                      ? (s->nch >= 8192 ? 4 : 2) : 1;
   if (n > 8) n = 8;
   while (n > 1 && (s->nch % n != 0 || s->nch / n < 2)) --n;
-  (void)head_block; (void)max_len;
   return n < 1 ? 1 : n;
 }
 void drop_kids(rvc_set *s) {
@@ -1781,19 +1400,6 @@ bool zero_device_out(rvc_set *s, float *d_out, size_t out_stride, size_t len) {
 
 }  // namespace
 
-namespace rvc {
-void free_guard_enter() {
-  g_pk_pause.fetch_add(1, std::memory_order_acq_rel);
-  // owners stop their resident kernels at their next call; idle kernels park by themselves within 2 s and are not
-  // waited for once they have (a parked kernel has left its stream)
-  const auto t0 = std::chrono::steady_clock::now();
-  while (pk_busy_count() > 0 &&
-         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.5)
-    std::this_thread::sleep_for(std::chrono::microseconds(200));
-}
-void free_guard_leave() { g_pk_pause.fetch_sub(1, std::memory_order_acq_rel); }
-}  // namespace rvc
-
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -1807,6 +1413,7 @@ rvc_set *rvc_set_create(int n_channels, int device, unsigned flags) {
   s->device = device;
   s->flags = flags;
   s->timing = (flags & RVC_FLAG_TIMING) != 0;
+  if ((flags & RVC_FLAG_PERSISTENT) != 0) { s->err = RVC_ERR_UNSUPPORTED; s->errstr = "RVC_FLAG_PERSISTENT was removed (round 4)"; }
   s->in_ptrs.assign((size_t)n_channels, nullptr);
   s->out_ptrs.assign((size_t)n_channels, nullptr);
   return s;
@@ -1821,8 +1428,6 @@ void rvc_set_destroy(rvc_set *s) {
     for (int i = 0; i < s->ev_free; ++i) hipEventDestroy(s->ev_pool[i]);
     hipEventDestroy(s->ev_ingest);
     hipEventDestroy(s->ev_out);
-    hipEventDestroy(s->ev_sweep);
-    if (s->st_pk) hipStreamDestroy(s->st_pk);
     hipStreamDestroy(s->st_bg);
     hipStreamDestroy(s->st_main);
   }
@@ -1984,10 +1589,7 @@ void rvc_set_process_end(rvc_set *s, float *const *out) {
   s->pending_len = 0;
   if (len == 0) return;
   bool ok = s->pending_ok;
-  if (ok && s->flag_count < 0) {          // persistent mode: this step's completion flags, then its post-actions
-    s->flag_count = 0;
-    ok = pk_retire_upto(s, s->pk_seq);
-  } else if (ok && s->flag_count > 0) {
+  if (ok && s->flag_count > 0) {
     // poll the completion flags the audio workgroups write behind their output stores
     const unsigned want = s->flag_seq;
     const int nf = s->flag_count;
@@ -2043,10 +1645,6 @@ void rvc_set_clear(rvc_set *s) {
   if (!s->live) return;
   // Outstanding tail jobs still write into rings; let them finish, then restart the clock.
   hipSetDevice(s->device);
-  (void)pk_quiesce(s);
-  s->pk_tile_hi = s->pk_tile_ready = -1;
-  s->pk_ypre_from = 0;
-  s->pk_need_acquire = s->pk_enabled;
   hipStreamSynchronize(s->st_bg);
   hipStreamSynchronize(s->st_main);
   drop_jobs(s);
@@ -2082,7 +1680,6 @@ void rvc_set_sync(rvc_set *s) {
   for (rvc_set *k : s->kids) rvc_set_sync(k);
   if (!s->streams_ok) return;
   hipSetDevice(s->device);
-  (void)pk_quiesce(s);
   hipStreamSynchronize(s->st_bg);
   hipStreamSynchronize(s->st_main);
 }
@@ -2257,11 +1854,8 @@ static int debug_fft(int device, size_t n, int f64, bool inverse, const float *i
          hipStreamSynchronize(s->st_main) == hipSuccess;
     ok = ok && hipMemcpy(out_t, d_t, sizeof(float) * n, hipMemcpyDeviceToHost) == hipSuccess;
   }
-  {
-    rvc::FreeGuard guard;
-    hipFree(d_t); hipFree(d_f);
-    free_stage(s, g);
-  }
+  hipFree(d_t); hipFree(d_f);
+  free_stage(s, g);
   rvc_set_destroy(s);
   return ok ? 1 : 0;
 }
@@ -2310,30 +1904,6 @@ int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int d
   }
   (void)hipFree(dH); (void)hipFree(dX); (void)hipFree(dY); (void)hipFree(dA);
   return ok ? 1 : 0;
-}
-
-// diagnostics: round trip of n empty commands through the resident kernel (median microseconds), -1 on failure
-double rvc_debug_persist_rtt(rvc_set *s, int n) {
-  if (!s || !s->pk_enabled || !s->live || n < 1) return -1.0;
-  hipSetDevice(s->device);
-  if (!pk_quiesce(s) || !pk_ensure_running(s)) return -1.0;
-  std::vector<double> us;
-  for (int i = 0; i < n; ++i) {
-    rvc::PkCmd c{};
-    c.flags = rvc::PK_EMPTY;
-    c.seq = ++s->pk_seq;
-    s->pk_steps[c.seq % rvc::kPkRing] = rvc_set::PkStep{0, 0, 0, false};
-    const auto a = std::chrono::steady_clock::now();
-    pk_push(s, c);
-    volatile unsigned *f = s->h_flags;
-    for (int w = 0; w < s->pk_n_audio; ++w) while ((int)(f[w] - c.seq) < 0) {}
-    us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count());
-    f = s->h_pdone;
-    for (int w = 0; w < s->pk_n_patch; ++w) while ((int)(f[w] - c.seq) < 0) {}
-    s->pk_retired = c.seq;
-  }
-  std::sort(us.begin(), us.end());
-  return us[us.size() / 2];
 }
 
 long rvc_debug_guard_check(rvc_set *s) {

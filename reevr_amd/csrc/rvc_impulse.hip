@@ -292,16 +292,12 @@ bool imp_ready(rvc_impulse *m) {
   return true;
 }
 
-// hipFree waits for every stream of the device, other sets' resident kernels included: see rvc::FreeGuard
 inline void imp_dev_free(void *p) {
-  if (!p) return;
-  rvc::FreeGuard guard;
-  hipFree(p);
+  if (p) hipFree(p);
 }
 
 void imp_free(rvc_impulse *m) {
   if (m->st) hipStreamSynchronize(m->st);
-  rvc::FreeGuard guard;
   for (int c = 0; c < 4; ++c) {
     if (m->d_raw[c]) hipFree(m->d_raw[c]);
     if (m->d_buf[c]) hipFree(m->d_buf[c]);

@@ -124,9 +124,7 @@ struct FusedArgs {
   // instead of waiting for an event behind the whole kernel.
   unsigned *done_flag;
   unsigned seq;
-  unsigned long long *dbg;  // development builds (RVC_PK_STAMPS): phase timestamps of workgroup 0, else nullptr
-  int io_host;              // persistent kernel: in / out are the set's pinned host staging buffers (uncached for the device
-                            // anyway): plain accesses -- system-scope loads of host memory measured 4x slower (9 vs 2 us / 4 KB)
+  unsigned long long *dbg;  // development builds (tools/dev/instrumentation.patch): phase timestamps of workgroup 0, else nullptr
 };
 
 struct IngestArgs {
@@ -166,65 +164,6 @@ void set_tile_rot_tuning(int on);    // "tile_rot": sweeps / patches on long row
 int tile_rot_tuning();
 void set_block_occ3_tuning(int on);  // "block_occ": 4 = the lean 4-waves-per-SIMD per-block kernel for many-channel launches (measurement)
 void set_patch_nt_tuning(int on);    // "patch_nt": 0 = ordinary loads in the stand-alone patch kernel (default: non-temporal for many channels)
-
-// ---- persistent block-synchronous kernel (RVC_FLAG_PERSISTENT) ------------------------------------------
-// One resident launch serves the plug-in's per-block calls: the host writes a command into a ring in pinned host
-// memory and rings a doorbell word; the audio workgroups (one per channel) run the one-block audio path
-// (fused_audio) and publish completion flags the host polls; the patch workgroups add, for the NEXT block, the
-// partitions that arrived since the last sweep to that sweep's row (time tiling, kSweepRows). Sweeps and tail jobs
-// stay ordinary launches on the set's streams, issued by the host when a block retires; everything the resident
-// kernel exchanges with them goes through system-scope accesses (xk_ld / xk_st in rvc_kernels.hip).
-constexpr int kPkRing = 16;           // command slots
-constexpr int kPkLag = 3;             // a tile's sweep runs once block t0 - 2 - kPkLag has retired (<= kSweepLagMax)
-struct PkCmd {                        // 16 qwords = two 64-byte lines; EACH line ends with the slot's sequence number, written
-                                      // last within that line: a line read by the device is one consistent snapshot
-  unsigned long long in, out;         // channel 0's first sample of this call (device-visible pointers)
-  long long in_stride, out_stride;    // floats between channels
-  long long n0, n1, k;                // the call covers absolute samples [n0, n1) of block k
-  unsigned long long seq_a;           // == seq: line 0 is complete
-  long long ypre_stride;
-  unsigned ypre_wait;                 // step whose patch produces the accumulator of block k (0: a completed launch did)
-  unsigned flags;                     // PK_*
-  long long patch_P;                  // > 0: patch workgroups: accumulator of block k+1 = sweep row + partitions 2 .. 1+patch_P
-  unsigned long long patch_yadd;      // sweep row of block k+1, channel 0
-  long long patch_yadd_stride;
-  unsigned long long patch_y;         // accumulator row of block k+1, channel 0 (stride = block size)
-  unsigned long long ypre;            // accumulator row of block k, channel 0
-  unsigned long long seq;             // line 1 is complete
-};
-static_assert(sizeof(PkCmd) == 128, "PkCmd layout");
-enum { PK_BLOCK_DONE = 1, PK_QUIT = 2, PK_ACQUIRE = 4, PK_EMPTY = 8, PK_IO_HOST = 16 };
-struct PkCtl {                        // pinned host memory
-  volatile unsigned long long doorbell;   // sequence number of the newest complete command
-  volatile unsigned long long parked;     // set by workgroup 0 when it parks the kernel after a silent doorbell
-  volatile unsigned long long error;      // nonzero: a bounded wait inside the kernel gave up (code)
-  unsigned long long pad[13];             // [0..4]: timestamps of audio workgroup 0's last step (diagnostics, 100 MHz ticks)
-  PkCmd ring[kPkRing];
-};
-struct PkArgs {
-  FusedArgs fa;            // static part of the audio path: rings, twiddles, H0 / H1, delay-line rows, tail ring
-  FirArgs pf;              // static part of the patch: H + 2 B, delay line, delay 2
-  PkCtl *ctl;
-  unsigned *ypre_seq;      // device: [patch workgroup] last step whose accumulator is complete
-  unsigned *x_seq;         // device: [audio workgroup] last step whose delay-line row / ring samples have landed
-  unsigned *park;          // device: nonzero = every workgroup leaves
-  unsigned *h_done;        // pinned host: [audio workgroup] last completed step
-  unsigned *h_pdone;       // pinned host: [patch workgroup] last completed step
-  unsigned seq0;           // the first command this launch consumes is seq0 + 1
-  int n_audio, patch_bx;   // audio workgroups; 512-bin patch tiles per channel
-  long long idle_ticks;    // wall_clock64 ticks (100 MHz) of doorbell silence after which the kernel parks itself
-};
-// hipFree / hipHostFree wait for EVERY stream of the device -- also for another set's resident kernel, which never
-// finishes while its owner keeps feeding it. Whoever is about to free device memory therefore brackets the frees with
-// free_guard_enter / _leave: resident kernels are asked to stand down (their owners stop them at their next call and use
-// ordinary launches while the request stands; idle ones park by themselves), the caller waits for that (bounded).
-void free_guard_enter();
-void free_guard_leave();
-struct FreeGuard { FreeGuard() { free_guard_enter(); } ~FreeGuard() { free_guard_leave(); } };
-bool persist_supported(int logB);
-int persist_workgroups(int logB, int channels, int *n_audio, int *patch_bx);
-int persist_capacity(int logB);   // workgroups of k_persist the current device holds at once (with a margin)
-hipError_t launch_persist(int logB, const PkArgs &a, int channels, hipStream_t st);
 
 // radix-8 kernels (logB >= 9): number of entries of their per-pass twiddle table, laid out as
 //   for j = 1 .. N8-1 (N8 = logB / 3):  p = 8^j entries [k < p][r < 8] = e^{-2 pi i r k / (8 p)}

@@ -8,7 +8,6 @@
 //                                              tail add-back TwoStageFFTConvolver.cpp:171-190)
 //   k_fused_block / k_fused_block2   one whole per-block process() call (TwoStageFFTConvolver.cpp:151-233, len <= head)
 //   k_fused_block2w            the same for head block 512 with a time-tiled delay line: audio wave + patch wave per channel
-//   k_persist                  the same, as ONE resident launch fed through a command ring (RVC_FLAG_PERSISTENT)
 //   k_fdl_patch                the few partitions a block adds on top of a sweep row of the time-tiled delay line
 //                              (the sweep itself: rvc_sweep.hip; both replace the per-block loop FFTConvolver.cpp:176-187)
 //   k_ingest                   the memcpy into _inputBuffer / _tailInput (FFTConvolver.cpp:166-169, TwoStage..:196-197)
@@ -1159,42 +1158,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv_loop(const InvArgs
 //                 nothing of block k-1's launch, so the workgroups appended to the launch of block
 //                 k-1 (k_fused_block2) compute it: ONE launch per block instead of two dependent ones.
 // ----------------------------------------------------------------------------------------
-// Accessors of the persistent kernel's cross-kernel data. It stays resident while OTHER launches -- sweeps, tail jobs,
-// the caller's own kernels -- produce what it reads and consume what it writes, so those accesses are made with the
-// system-scope cache policy (sc0 sc1): loads bypass this CU's L1 and the XCD's L2, stores write through -- always fresh,
-// always visible, no fence on the latency path (MI355X_MICROARCH.md, inter-workgroup visibility: the "sc0 sc1 stores and
-// loads both sides" form). Buffer instructions with a wave-uniform base (SGPR resource) + a 32-bit lane byte offset, so a
-// wave's accesses stay ONE coalesced request (single system-scope atomics are one fabric transaction per lane: measured
-// 10x slower for the 2 KB of samples of a block).
-typedef unsigned xk_u2 __attribute__((ext_vector_type(2)));
-typedef unsigned xk_u4 __attribute__((ext_vector_type(4)));
-constexpr int kXkAux = 17;                        // sc0 | sc1
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t xk_rsrc(const void *p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7fffffff, 0x00020000);   // raw buffer, 2 GiB window
-}
-__device__ __forceinline__ float xk_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, kXkAux));
-}
-__device__ __forceinline__ float2 xk_ld2(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  const xk_u2 u = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, kXkAux);
-  return make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
-}
-__device__ __forceinline__ float4 xk_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  const xk_u4 u = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, kXkAux);
-  return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-}
-__device__ __forceinline__ void xk_st(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, kXkAux);
-}
-__device__ __forceinline__ void xk_st2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float2 v) {
-  xk_u2 u; u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y);
-  __builtin_amdgcn_raw_buffer_store_b64(u, r, byte_off, 0, kXkAux);
-}
-__device__ __forceinline__ void xk_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
-  xk_u4 u; u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(u, r, byte_off, 0, kXkAux);
-}
-
 // LEAN (many-channel launches, k_fused_block2w<.., 4>): nothing is requested before it is needed -- the twiddles per pass,
 // the IR rows / accumulator / previous spectrum behind the forward transform, the inverse split's twiddles behind the MAC,
 // the tail stream behind the inverse transform. Every one of those requests then sits on the wave's dependent chain, which
@@ -1203,10 +1166,10 @@ __device__ __forceinline__ void xk_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 // (SOLO: the many-channel form. Its general path -- ragged calls -- keeps the ring append between the sample loads: the
 //  requests then go out one at a time, but 16 fewer registers are live, and the whole-block path every lock-step launch
 //  takes sets the kernel's budget: three waves per SIMD.)
-template <int LOGB, bool FOLD, bool PK = false, bool SOLO = false, bool LEAN = false>
+template <int LOGB, bool FOLD, bool SOLO = false, bool LEAN = false>
 __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, const int wg) {
   static_assert(!SOLO || Plan8<LOGB>::WG == 64, "SOLO: the workgroup's transform(s) live in one wave");
-  static_assert(!LEAN || (!PK && FOLD), "LEAN: the folded launch path only");
+  static_assert(!LEAN || FOLD, "LEAN: the folded launch path only");
   typedef Tw8<LOGB, float, false, false, false, LEAN> TW;
   typedef Plan8<LOGB> P;
   typedef cx<float> C;
@@ -1215,8 +1178,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   C *lds = reinterpret_cast<C *>(smem_raw) + sub * P::LDS_ELEMS;
   const int c_raw = wg * P::TPW + sub;
   const bool live = c_raw < a.channels;     // a dead sub-transform shadows the last channel and stores nothing
-  // (persistent kernel: one channel per workgroup, so the channel -- and every base pointer below -- is wave-uniform)
-  const int c = PK ? __builtin_amdgcn_readfirstlane(live ? c_raw : a.channels - 1) : (live ? c_raw : a.channels - 1);
+  const int c = live ? c_raw : a.channels - 1;
   const float *in = a.in + (long long)c * a.in_chan_stride;
   float *ring = a.ring + (long long)c * a.ring_chan_stride;
   const C *tw = reinterpret_cast<const C *>(a.tw);
@@ -1246,8 +1208,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       h0[e] = H0[P::out_idx(tid, e)];
-      if constexpr (PK) ypre[e] = xk_ld2(xk_rsrc(Ypre), (unsigned)P::out_idx(tid, e) * 8u);
-      else ypre[e] = Ypre[P::out_idx(tid, e)];
+      ypre[e] = Ypre[P::out_idx(tid, e)];
       if constexpr (FOLD) {
         // (clamped to row k when there is no block k-1: any resident row, the product is dropped below)
         const float2 *H1 = (fold ? a.H1 : a.H0) + (long long)c * a.h_chan_stride;
@@ -1277,49 +1238,30 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   if constexpr (!LEAN) { load_wso(); load_mac(); }
   // 1. load the segment: history from the ring, this call's samples from `in` (and append them
   //    to the ring), zero for the not-yet-played rest of block k and for time < 0
-  // (persistent kernel: calls on even sample positions with 8-byte aligned buffers move sample PAIRS per access. Single
-  //  system-scope dword stores become one partial-line PCIe write each towards pinned host memory: the 1024 of them of a
-  //  stereo block took ~100 us and held every later doorbell read behind them.)
-  const bool wide = PK && ((a.n0 | a.n1) & 1) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(a.out) |
-                                                        (uintptr_t)(a.out_chan_stride * 4)) & 7u) == 0;
   C v[P::E];
   // The tail contribution the epilogue adds is requested NOW -- it does not depend on this block -- instead of costing a
   // memory round trip behind the inverse transform (calls on even sample positions: pairs of samples per access).
   // The plug-in's own call (one whole block, starting on its boundary, 8-byte aligned buffers): both halves of the segment are
   // contiguous runs -- history in the ring, the block in the call's input -- addressed as base + lane offset, moved as sample
   // PAIRS, and no per-sample window test is left anywhere (launch-uniform conditions).
-  const bool blockcall = !PK && a.n0 == seg + B && a.n1 >= seg + 2 * (long long)B &&
+  const bool blockcall = a.n0 == seg + B && a.n1 >= seg + 2 * (long long)B &&
                          ((reinterpret_cast<uintptr_t>(a.in) | (uintptr_t)(a.in_chan_stride * 4) | reinterpret_cast<uintptr_t>(a.out) |
                            (uintptr_t)(a.out_chan_stride * 4)) & 7u) == 0;
-  const bool pre_add = PK ? wide : (blockcall || ((a.n0 | a.n1) & 1) == 0);
+  const bool pre_add = blockcall || ((a.n0 | a.n1) & 1) == 0;
   float2 addv[P::E / 2];
   auto load_addv = [&]() {
-    if constexpr (!PK) {
-      if (pre_add && a.add) {
-        const float *addc = a.add + (long long)c * a.add_chan_stride;
-        int q = 0;
-#pragma unroll
-        for (int e = 0; e < P::E; ++e)
-          if (!P::out_is_low(e)) {
-            const long long n = a.k * (long long)B + 2 * P::out_idx(tid, e) - B;
-            addv[q++] = *reinterpret_cast<const float2 *>(addc + ((unsigned long long)(n >= a.add_from ? n : a.add_from) & a.add_mask));
-          }
-      }
-    }
-  };
-  if constexpr (!LEAN) load_addv();
-  if constexpr (PK) {
-    if (wide && a.add) {
-      const __amdgpu_buffer_rsrc_t radd = xk_rsrc(a.add + (long long)c * a.add_chan_stride);
+    if (pre_add && a.add) {
+      const float *addc = a.add + (long long)c * a.add_chan_stride;
       int q = 0;
 #pragma unroll
       for (int e = 0; e < P::E; ++e)
         if (!P::out_is_low(e)) {
           const long long n = a.k * (long long)B + 2 * P::out_idx(tid, e) - B;
-          addv[q++] = xk_ld2(radd, (unsigned)((unsigned long long)(n >= a.add_from ? n : a.add_from) & a.add_mask) * 4u);
+          addv[q++] = *reinterpret_cast<const float2 *>(addc + ((unsigned long long)(n >= a.add_from ? n : a.add_from) & a.add_mask));
         }
     }
-  }
+  };
+  if constexpr (!LEAN) load_addv();
   if (blockcall) {
     const bool hist = seg >= 0;                                        // (block 0: the first half is time < 0)
     const float2 *hb = reinterpret_cast<const float2 *>(ring + ((unsigned long long)(hist ? seg : 0) & a.ring_mask));
@@ -1347,26 +1289,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
     const bool n_in = n >= a.n0 && n < a.n1, m_in = m >= a.n0 && m < a.n1;      // this call's samples
     const bool n_hist = n < a.n0 && n >= 0, m_hist = m < a.n0 && m >= 0;       // history (else: zero)
     float s0, s1;
-    if constexpr (PK) {       // both sources, clamped offsets, then selects (uniform bases: coalesced system-scope loads)
-      const __amdgpu_buffer_rsrc_t rin = xk_rsrc(in), rring = xk_rsrc(ring);
-      if (wide) {             // sample pairs (n, n+1) as ONE 8-byte access: a wave instruction then covers whole lines
-        // (pinned host staging buffer: plain loads -- the caller has just dropped this CU's L1 lines, and L1-bypassing
-        //  loads of host memory are served line by line: 9 us instead of 2.5 us for the 2 KB of a block)
-        const float2 i2 = a.io_host ? *reinterpret_cast<const float2 *>(in + (n_in ? n - a.n0 : 0))
-                                    : xk_ld2(rin, (unsigned)(n_in ? n - a.n0 : 0) * 4u);
-        const float2 h2 = xk_ld2(rring, (unsigned)((unsigned long long)(n_hist ? n : 0) & a.ring_mask) * 4u);
-        s0 = n_in ? i2.x : (n_hist ? h2.x : 0.f);
-        s1 = n_in ? i2.y : (n_hist ? h2.y : 0.f);
-      } else {
-        const float in0 = xk_ld(rin, (unsigned)(n_in ? n - a.n0 : 0) * 4u), in1 = xk_ld(rin, (unsigned)(m_in ? m - a.n0 : 0) * 4u);
-        const float h0 = xk_ld(rring, (unsigned)((unsigned long long)(n_hist ? n : 0) & a.ring_mask) * 4u);
-        const float h1 = xk_ld(rring, (unsigned)((unsigned long long)(m_hist ? m : 0) & a.ring_mask) * 4u);
-        s0 = n_in ? in0 : (n_hist ? h0 : 0.f);
-        s1 = m_in ? in1 : (m_hist ? h1 : 0.f);
-      }
-      // (the ring append follows in its own loop below: buffer stores between the loads would order every later load
-      //  behind them -- one memory round trip per value)
-    } else {
+    {
       const float *pn = n_in ? in + (n - a.n0) : ring + ((unsigned long long)(n_hist ? n : 0) & a.ring_mask);
       const float *pm = m_in ? in + (m - a.n0) : ring + ((unsigned long long)(m_hist ? m : 0) & a.ring_mask);
       const float ln = *pn, lm = *pm;
@@ -1378,7 +1301,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
     }
     v[e] = mk<float>(s0, s1);
   }
-  if constexpr (!PK && !SOLO) {        // (the ring append: own loop, as above)
+  if constexpr (!SOLO) {               // (the ring append: own loop, as above)
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       const long long n = seg + 2 * P::in_idx(tid, e), m = n + 1;
@@ -1386,19 +1309,6 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       if (live && m >= a.n0 && m < a.n1) ring[(unsigned long long)m & a.ring_mask] = v[e].y;
     }
   }
-  }
-  if constexpr (PK) {
-    const __amdgpu_buffer_rsrc_t rring = xk_rsrc(ring);
-#pragma unroll
-    for (int e = 0; e < P::E; ++e) {
-      const long long n = seg + 2 * P::in_idx(tid, e), m = n + 1;
-      if (wide) {
-        if (live && n >= a.n0 && n < a.n1) xk_st2(rring, (unsigned)((unsigned long long)n & a.ring_mask) * 4u, make_float2(v[e].x, v[e].y));
-      } else {
-        if (live && n >= a.n0 && n < a.n1) xk_st(rring, (unsigned)((unsigned long long)n & a.ring_mask) * 4u, v[e].x);
-        if (live && m >= a.n0 && m < a.n1) xk_st(rring, (unsigned)((unsigned long long)m & a.ring_mask) * 4u, v[e].y);
-      }
-    }
   }
   if constexpr (!LEAN) fold_in();
   // 2. forward transform, real split; X_k goes to the delay line and, times H0 plus the
@@ -1437,8 +1347,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
     const float2 yp = ypre[e];                                        // (+ H_1 X_{k-1} already folded in above)
     if (k == 0) {
       const float2 X = make_float2(A.x + A.y, A.x - A.y);             // packed (DC, Nyquist)
-      if constexpr (PK) { if (live) xk_st2(xk_rsrc(Xrow), 0u, X); }
-      else if (live) Xrow[0] = X;
+      if (live) Xrow[0] = X;
       y[e] = mk<float>(fmaf(h.x, X.x, yp.x), fmaf(h.y, X.y, yp.y));  // two real products
     } else {
       C Bc;
@@ -1448,8 +1357,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       const C D = mk<float>(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
       const C O = mk<float>(D.y, -D.x);
       const C X = cadd(Ev, cmul(wso[e], O));
-      if constexpr (PK) { if (live) xk_st2(xk_rsrc(Xrow), (unsigned)k * 8u, make_float2(X.x, X.y)); }
-      else if (live) Xrow[k] = make_float2(X.x, X.y);
+      if (live) Xrow[k] = make_float2(X.x, X.y);
       y[e] = mk<float>(fmaf(h.x, X.x, fmaf(-h.y, X.y, yp.x)), fmaf(h.x, X.y, fmaf(h.y, X.x, yp.y)));
     }
   }
@@ -1519,16 +1427,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
       if (add) {                         // unconditional (clamped) loads of the tail stream, then selects
         const bool a0 = n >= a.add_from, a1 = n + 1 >= a.add_from;
         float u0, u1;
-        if constexpr (PK) {
-          const __amdgpu_buffer_rsrc_t radd = xk_rsrc(add);
-          if (wide) {       // (n and add_from are even: the pair is in or out together; requested at the top)
-            const float2 u2 = addv[P::out_is_low(e) ? 0 : addq];
-            u0 = u2.x; u1 = u2.y;
-          } else {
-            u0 = xk_ld(radd, (unsigned)((unsigned long long)(a0 ? n : a.add_from) & a.add_mask) * 4u);
-            u1 = xk_ld(radd, (unsigned)((unsigned long long)(a1 ? n + 1 : a.add_from) & a.add_mask) * 4u);
-          }
-        } else if (pre_add) {
+        if (pre_add) {       // (n and add_from are even: the pair is in or out together; requested at the top)
           const float2 u2 = addv[P::out_is_low(e) ? 0 : addq];
           u0 = u2.x; u1 = u2.y;
         } else {
@@ -1539,25 +1438,13 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
         t1 += a1 ? u1 : 0.f;
       }
       if (!P::out_is_low(e)) ++addq;
-      if constexpr (PK) {
-        const __amdgpu_buffer_rsrc_t rout = xk_rsrc(out);
-        if (wide) {
-          // (write-through also towards the pinned host buffer: plain stores would sit in the L2 until a release)
-          if (n >= a.n0 && n < a.n1) xk_st2(rout, (unsigned)(n - a.n0) * 4u, make_float2(t0, t1));
-        } else {
-          if (n >= a.n0 && n < a.n1) xk_st(rout, (unsigned)(n - a.n0) * 4u, t0);
-          if (n + 1 >= a.n0 && n + 1 < a.n1) xk_st(rout, (unsigned)(n + 1 - a.n0) * 4u, t1);
-        }
-      } else {
-        if (n >= a.n0 && n < a.n1) out[n - a.n0] = t0;
-        if (n + 1 >= a.n0 && n + 1 < a.n1) out[n + 1 - a.n0] = t1;
-      }
+      if (n >= a.n0 && n < a.n1) out[n - a.n0] = t0;
+      if (n + 1 >= a.n0 && n + 1 < a.n1) out[n + 1 - a.n0] = t1;
     }
   }
   }
   if (a.done_flag) {   // output is in (host-visible) memory: tell the polling host, do not make it wait for kernel end
-    if constexpr (PK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores: landed when acknowledged
-    else __threadfence_system();
+    __threadfence_system();
     core_sync<SOLO>();
     if (threadIdx.x == 0) __hip_atomic_store(a.done_flag + wg, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -1881,11 +1768,11 @@ __global__ void __launch_bounds__(256) k_fir_row(const FirArgs a) {
 // partitions (the input rows that arrived after the sweep that left Yadd). Streaming shape: a workgroup = 512 bins of
 // one channel, a thread = two bins (16 bytes), all 2 P row loads of a thread in flight at once, no LDS, no barrier.
 // ----------------------------------------------------------------------------------------
-constexpr int kPatchMax = kSweepRows - 1 + kSweepLagMax;   // (the persistent mode sweeps a few blocks early)
+constexpr int kPatchMax = kSweepRows - 1 + kSweepLagMax;   // (7 recent partitions + the zero-latency stage's two newest + margin)
 __device__ __forceinline__ bool fdl_is_patch(const FirArgs &a) { return a.Yadd != nullptr && a.P <= kPatchMax && a.P >= 1; }
 
 // NP = the number of partitions the code is unrolled for: exactly a.P when the caller dispatches on it (fdl_patch_any:
-// no request is issued twice), kPatchMax with clamped addresses otherwise (the resident kernel: one code path).
+// no request is issued twice), kPatchMax with clamped addresses otherwise (the patch workgroups of k_fused_block2).
 // streaming (non-temporal) 16-byte load: the rows a patch reads are far larger than any cache by the time they are read again
 typedef float patch_vf4 __attribute__((ext_vector_type(4)));
 static int g_patch_nt = 1, g_block_occ = 0;      // g_block_occ = 4: the lean 4-waves-per-SIMD per-block kernel for many-channel launches
@@ -1900,7 +1787,7 @@ template <bool NT> __device__ __forceinline__ float4 patch_ld(const float2 *p) {
   }
 }
 
-template <bool PK, int NP, bool NT = false>
+template <int NP, bool NT = false>
 __device__ __forceinline__ void fdl_patch_n(const FirArgs &a, const int bx, const int c) {
   const int bin = bx * 512 + (int)threadIdx.x * 2;
   if (bin >= a.B) return;
@@ -1915,15 +1802,12 @@ __device__ __forceinline__ void fdl_patch_n(const FirArgs &a, const int bx, cons
     const long long row = cbase - ii, rr = row < 0 ? 0 : row;
     hv[i] = patch_ld<NT>(Hc + (long long)ii * B);
     const float2 *xr = Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B;
-    if constexpr (PK)         // delay-line rows and sweep rows come from other workgroups / launches (see xk_ld)
-      xv[i] = xk_ld4(xk_rsrc(xr - bin), (unsigned)bin * 8u);
-    else xv[i] = patch_ld<NT>(xr);
+    xv[i] = patch_ld<NT>(xr);
   }
   float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.Yadd) {                                         // (uniform; nullptr: the plain sum, launch_fir's many-channel row form)
     const float2 *yr = a.Yadd + (long long)c * a.yadd_chan_stride;
-    if constexpr (PK) y = xk_ld4(xk_rsrc(yr), (unsigned)bin * 8u);
-    else y = patch_ld<NT>(yr + bin);
+    y = patch_ld<NT>(yr + bin);
   }
   const bool packed = (bin == 0);
 #pragma unroll
@@ -1943,26 +1827,24 @@ __device__ __forceinline__ void fdl_patch_n(const FirArgs &a, const int bx, cons
     }
   }
   float2 *yo = a.Y + (long long)c * a.y_chan_stride;
-  if constexpr (PK) xk_st4(xk_rsrc(yo), (unsigned)bin * 8u, y);
-  else *reinterpret_cast<float4 *>(yo + bin) = y;
+  *reinterpret_cast<float4 *>(yo + bin) = y;
 }
-template <bool PK = false>
-__device__ __forceinline__ void fdl_patch_body(const FirArgs &a, const int bx, const int c) { fdl_patch_n<PK, kPatchMax>(a, bx, c); }
+__device__ __forceinline__ void fdl_patch_body(const FirArgs &a, const int bx, const int c) { fdl_patch_n<kPatchMax>(a, bx, c); }
 // dispatch on the (launch-uniform) partition count
 template <bool NT>
 __device__ __forceinline__ void fdl_patch_any(const FirArgs &a, const int bx, const int c) {
   static_assert(kPatchMax == 10, "cases below");
   switch (a.P) {
-    case 1: fdl_patch_n<false, 1, NT>(a, bx, c); break;
-    case 2: fdl_patch_n<false, 2, NT>(a, bx, c); break;
-    case 3: fdl_patch_n<false, 3, NT>(a, bx, c); break;
-    case 4: fdl_patch_n<false, 4, NT>(a, bx, c); break;
-    case 5: fdl_patch_n<false, 5, NT>(a, bx, c); break;
-    case 6: fdl_patch_n<false, 6, NT>(a, bx, c); break;
-    case 7: fdl_patch_n<false, 7, NT>(a, bx, c); break;
-    case 8: fdl_patch_n<false, 8, NT>(a, bx, c); break;
-    case 9: fdl_patch_n<false, 9, NT>(a, bx, c); break;
-    default: fdl_patch_n<false, 10, NT>(a, bx, c); break;
+    case 1: fdl_patch_n<1, NT>(a, bx, c); break;
+    case 2: fdl_patch_n<2, NT>(a, bx, c); break;
+    case 3: fdl_patch_n<3, NT>(a, bx, c); break;
+    case 4: fdl_patch_n<4, NT>(a, bx, c); break;
+    case 5: fdl_patch_n<5, NT>(a, bx, c); break;
+    case 6: fdl_patch_n<6, NT>(a, bx, c); break;
+    case 7: fdl_patch_n<7, NT>(a, bx, c); break;
+    case 8: fdl_patch_n<8, NT>(a, bx, c); break;
+    case 9: fdl_patch_n<9, NT>(a, bx, c); break;
+    default: fdl_patch_n<10, NT>(a, bx, c); break;
   }
 }
 
@@ -1992,7 +1874,7 @@ k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int 
   } else {
     if (threadIdx.x >= 256) return;
     const int idx = (int)blockIdx.x - n_audio;
-    if (fdl_is_patch(f)) fdl_patch_body<false>(f, idx % fir_bx, idx / fir_bx);          // (fir_bx = 512-bin tiles per channel)
+    if (fdl_is_patch(f)) fdl_patch_body(f, idx % fir_bx, idx / fir_bx);          // (fir_bx = 512-bin tiles per channel)
     else fir_row_body(f, reinterpret_cast<float2 (*)[64]>(smem_raw), idx % fir_bx, idx / fir_bx);
   }
 }
@@ -2085,222 +1967,8 @@ __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, c
 template <int LOGB, bool NT, bool LEAN>
 __global__ void __launch_bounds__(128, LEAN ? 4 : 2) k_fused_block2w(const FusedArgs a, const FirArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (threadIdx.x < 64) fused_audio<LOGB, true, false, true, LEAN>(a, smem_raw, blockIdx.x);
+  if (threadIdx.x < 64) fused_audio<LOGB, true, true, LEAN>(a, smem_raw, blockIdx.x);
   else if (f.P > 0) fdl_patch_wave<LOGB, NT, LEAN ? 2 : 3>(f, blockIdx.x, a.channels);
-}
-
-// ----------------------------------------------------------------------------------------
-// Persistent block-synchronous kernel (rvc_internal.h, PkArgs): replaces one launch per 512-frame block by one
-// RESIDENT launch that is fed through a doorbell in pinned host memory -- the loop it serves is the reference's
-// per-block process() call (TwoStageFFTConvolver.cpp:151-233 with len <= head block). Workgroups [0, n_audio) are
-// audio workgroups, the rest patch workgroups (channel-major, patch_bx tiles of 512 bins per channel). No workgroup
-// ever waits for another one except an audio workgroup for the accumulator its channel's patch workgroups published
-// one step earlier; every wait is bounded (idle_ticks) and ends in a clean exit the host can see.
-// ----------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long pk_ld64(const volatile unsigned long long *p) {
-  return __hip_atomic_load(const_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned pk_ld32(const unsigned *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-template <int LOGB>
-__global__ void __launch_bounds__((Plan8<LOGB>::WG > 256 ? Plan8<LOGB>::WG : 256)) k_persist(const PkArgs pa) {
-  typedef Plan8<LOGB> P;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  __shared__ unsigned long long s_cmd[16];
-  __shared__ int s_exit;
-  const bool is_audio = (int)blockIdx.x < pa.n_audio;
-  if ((int)threadIdx.x >= (is_audio ? P::WG : 256)) return;
-  const int pidx = (int)blockIdx.x - pa.n_audio;                 // patch workgroup: channel-major
-  PkCtl *ctl = pa.ctl;
-  unsigned seq = pa.seq0;
-  bool pending = false;        // the previous step's stores are issued but its completion is not published yet
-  // completion of step `sq`: every wave has drained its (write-through) stores, then ONE lane publishes
-  auto publish = [&](const unsigned sq) {
-    if (threadIdx.x == 0) {
-      if (is_audio) {
-        __hip_atomic_store(pa.h_done + blockIdx.x, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(pa.x_seq + blockIdx.x, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      } else {
-        __hip_atomic_store(pa.ypre_seq + pidx, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(pa.h_pdone + pidx, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  };
-  for (;;) {
-    ++seq;
-    // ---- wait for command `seq`: the first 16 threads poll the 16 qwords of its ring slot (ONE PCIe round trip per
-    // poll; each 64-byte line of the slot ends with `seq` once the host has completed it); the other waves sleep at the
-    // barrier. The FIRST poll is in flight while every wave drains the previous step's stores: the round trip that finds
-    // the next command and the acknowledgement of the last step's write-through stores overlap, and the last step's
-    // completion is published as soon as both are in.
-    const volatile unsigned long long *slot = reinterpret_cast<const volatile unsigned long long *>(&ctl->ring[seq % kPkRing]);
-    unsigned long long q = threadIdx.x < 16 ? pk_ld64(slot + threadIdx.x) : 0ull;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (pending) { publish(seq - 1u); pending = false; }
-    if (threadIdx.x < 64) {
-      int ex = 0;
-      const long long t0 = wall_clock64();
-      for (unsigned spins = 0;; ++spins) {
-        if ((unsigned)__shfl(q, 7) == seq && (unsigned)__shfl(q, 15) == seq) {   // both lines complete
-          if (threadIdx.x < 16) s_cmd[threadIdx.x] = q;
-          break;
-        }
-        q = threadIdx.x < 16 ? pk_ld64(slot + threadIdx.x) : 0ull;
-        if ((spins & 31u) != 31u) continue;                      // (the slow checks: every 32nd poll)
-        if (pk_ld32(pa.park)) { ex = 1; break; }
-        if (wall_clock64() - t0 > pa.idle_ticks) {
-          if (blockIdx.x == 0) {                                 // workgroup 0 parks the whole kernel
-            if (threadIdx.x == 0) {
-              __hip_atomic_store(pa.park, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-              __hip_atomic_store(const_cast<unsigned long long *>(&ctl->parked), (unsigned long long)seq, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            ex = 1;
-            break;
-          }
-        }
-      }
-      if (threadIdx.x == 0) s_exit = ex;
-    }
-    __syncthreads();
-    if (s_exit) return;
-    // the command, as wave-uniform (scalar) values: what comes back from LDS is a vector register to the compiler, and
-    // buffer resources / row pointers built from those would be waterfall-looped and 64-bit vector arithmetic
-    PkCmd cmd;
-    {
-      unsigned long long *cq = reinterpret_cast<unsigned long long *>(&cmd);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const unsigned long long v = s_cmd[i];
-        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-        cq[i] = (unsigned long long)lo | ((unsigned long long)hi << 32);
-      }
-    }
-    const unsigned flags = cmd.flags;
-    if (flags & PK_QUIT) return;
-    if ((flags & PK_ACQUIRE) || ((flags & PK_IO_HOST) && is_audio)) {   // ordinary launches rewrote buffers this workgroup reads with
-                                           // plain loads / the host rewrote the staging buffer it reads with plain loads
-      if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __syncthreads();
-    }
-    if (flags & PK_EMPTY) {      // diagnostics: an empty step (hand-off round trip only)
-      __syncthreads();
-      publish(seq);
-      continue;
-    }
-    if (is_audio) {
-      if (cmd.ypre_wait) {                 // the accumulator of block k comes from the patch workgroups' previous step
-        if (threadIdx.x == 0) {
-          int ex = 0;
-          const int c_lo = (int)blockIdx.x * P::TPW;
-          const int c_hi = c_lo + P::TPW < pa.fa.channels ? c_lo + P::TPW : pa.fa.channels;
-          const long long t0 = wall_clock64();
-          for (int w = c_lo * pa.patch_bx; w < c_hi * pa.patch_bx && !ex; ++w) {
-            for (unsigned spins = 0; (int)(pk_ld32(pa.ypre_seq + w) - cmd.ypre_wait) < 0; ++spins) {
-              if ((spins & 31u) == 31u && (pk_ld32(pa.park) || wall_clock64() - t0 > pa.idle_ticks)) { ex = 1; break; }
-              __builtin_amdgcn_s_sleep(1);
-            }
-          }
-          if (ex)
-            __hip_atomic_store(const_cast<unsigned long long *>(&ctl->error), 0x200000000ull | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          s_exit = ex;
-        }
-        __syncthreads();
-        if (s_exit) return;
-      }
-      FusedArgs fa = pa.fa;
-      fa.in = reinterpret_cast<const float *>(cmd.in); fa.in_chan_stride = cmd.in_stride;
-      fa.out = reinterpret_cast<float *>(cmd.out); fa.out_chan_stride = cmd.out_stride;
-      fa.n0 = cmd.n0; fa.n1 = cmd.n1; fa.k = cmd.k;
-      fa.Ypre = reinterpret_cast<const float2 *>(cmd.ypre); fa.ypre_chan_stride = cmd.ypre_stride;
-      fa.done_flag = nullptr; fa.seq = seq; fa.io_host = (flags & PK_IO_HOST) ? 1 : 0;   // (completion: published above, next pass)
-      fused_audio<LOGB, true, true>(fa, smem_raw, blockIdx.x);
-      __syncthreads();                                               // s_cmd / the exchange buffer are reused next step
-    } else {
-      if ((flags & PK_BLOCK_DONE) && cmd.patch_P > 0) {
-        // the newest row the patch reads (block k-1) was written by this channel's audio workgroup one step ago: with
-        // commands queued ahead that step may still be running
-        if (threadIdx.x == 0) {
-          int ex = 0;
-          const unsigned *xs = pa.x_seq + pidx / pa.patch_bx;
-          const long long t0 = wall_clock64();
-          for (unsigned spins = 0; (int)(pk_ld32(xs) - (seq - 1u)) < 0; ++spins) {
-            if ((spins & 31u) == 31u && (pk_ld32(pa.park) || wall_clock64() - t0 > pa.idle_ticks)) { ex = 1; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (ex)
-            __hip_atomic_store(const_cast<unsigned long long *>(&ctl->error), 0x300000000ull | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          s_exit = ex;
-        }
-        __syncthreads();
-        if (s_exit) return;
-        FirArgs f = pa.pf;
-        f.P = (int)cmd.patch_P; f.k0 = cmd.k + 1; f.M = 1;
-        f.Yadd = reinterpret_cast<const float2 *>(cmd.patch_yadd); f.yadd_chan_stride = cmd.patch_yadd_stride;
-        f.Y = reinterpret_cast<float2 *>(cmd.patch_y); f.y_chan_stride = f.B;
-        fdl_patch_body<true>(f, pidx % pa.patch_bx, pidx / pa.patch_bx);
-      }
-    }
-    pending = true;
-  }
-}
-
-bool persist_supported(int logB) { return logB >= 9 && logB <= 12; }
-
-int persist_workgroups(int logB, int channels, int *n_audio, int *patch_bx) {
-  const int B = 1 << logB;
-  const int na = channels;                  // Plan8::TPW == 1 for logB >= 9
-  const int pb = (B + 511) / 512;
-  if (n_audio) *n_audio = na;
-  if (patch_bx) *patch_bx = pb;
-  return na + pb * channels;
-}
-
-// how many workgroups of k_persist the device holds at once (every one of them spins on the others: the whole grid
-// must be resident); a margin of one workgroup per CU is kept (the occupancy query can be one high, MI355X_MICROARCH.md)
-template <int LOGB> static int persist_capacity_t() {
-  typedef Plan8<LOGB> P;
-  constexpr int kThreads = P::WG > 256 ? P::WG : 256;
-  int per_cu = 0, dev = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_persist<LOGB>, kThreads, sizeof(cx<float>) * P::LDS_ELEMS * P::TPW) != hipSuccess) return 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  return per_cu > 1 ? (per_cu - 1) * cus : 0;
-}
-int persist_capacity(int logB) {
-  switch (logB) {
-    case 9: return persist_capacity_t<9>();
-    case 10: return persist_capacity_t<10>();
-    case 11: return persist_capacity_t<11>();
-    case 12: return persist_capacity_t<12>();
-    default: return 0;
-  }
-}
-
-template <int LOGB>
-static hipError_t launch_persist_t(const PkArgs &a, int channels, hipStream_t st) {
-  typedef Plan8<LOGB> P;
-  static_assert(P::TPW == 1, "one channel per audio workgroup");
-  PkArgs b = a;
-  b.fa.channels = channels;
-  const int total = persist_workgroups(LOGB, channels, &b.n_audio, &b.patch_bx);
-  const size_t lds = sizeof(cx<float>) * P::LDS_ELEMS * P::TPW;
-  constexpr int kThreads = P::WG > 256 ? P::WG : 256;
-  hipLaunchKernelGGL((k_persist<LOGB>), dim3(total), dim3(kThreads), lds, st, b);
-  return hipGetLastError();
-}
-
-hipError_t launch_persist(int logB, const PkArgs &a, int channels, hipStream_t st) {
-  switch (logB) {
-    case 9: return launch_persist_t<9>(a, channels, st);
-    case 10: return launch_persist_t<10>(a, channels, st);
-    case 11: return launch_persist_t<11>(a, channels, st);
-    case 12: return launch_persist_t<12>(a, channels, st);
-    default: return hipErrorInvalidValue;
-  }
 }
 
 // ----------------------------------------------------------------------------------------

@@ -3,7 +3,6 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests import test_gpu_parity as T
-from tests import test_gpu_persistent as TP
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
@@ -11,7 +10,7 @@ bad = runs = 0
 for seed in range(first, first + count):
     jobs = [(T.test_fuzz_geometry_and_call_pattern, (seed, "default")), (T.test_fuzz_geometry_and_call_pattern, (seed, "force")),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, False)), (T.test_fuzz_block_synchronous_time_tiling, (seed, True)),
-            (T.test_fuzz_block_synchronous_time_tiling, (seed, "force")), (T.test_fuzz_single_stage_sets, (seed,)), (TP.test_fuzz_call_patterns_persistent, (seed,)),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "force")), (T.test_fuzz_single_stage_sets, (seed,)),
             (T.test_fuzz_geometry_and_call_pattern, (seed, "force2")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "force2")),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "force2_k32")), (T.test_guard_bands_stay_intact_and_outputs_finite, (seed,))]
     for fn, a in jobs:

@@ -64,6 +64,24 @@ def test_reference_error_conventions_without_gpu(lib):
     assert f.init(1 << 20, ir) is (lib.rvc_device_count() > 0)    # huge block: clamped, so it only fails for want of a device
 
 
+def test_removed_persistent_flag_is_refused_not_ignored(lib):
+    """RVC_FLAG_PERSISTENT (the resident-kernel mode of rounds 2-3) was removed: a set created with the bit reports
+    RVC_ERR_UNSUPPORTED at once and every init on it fails with the same code -- with or without a device."""
+    from reevr_amd import _lib
+    h = lib.rvc_set_create(2, 0, _lib.RVC_FLAG_PERSISTENT)
+    assert h
+    try:
+        assert lib.rvc_last_error(h) == _lib.RVC_ERR_UNSUPPORTED
+        ir = np.ones(64, np.float32)
+        irs = (_lib.F32P * 2)(ir.ctypes.data_as(_lib.F32P), ir.ctypes.data_as(_lib.F32P))
+        lens = (ctypes.c_size_t * 2)(64, 64)
+        assert lib.rvc_set_init(h, 512, 8192, irs, lens, 512) == 0
+        assert lib.rvc_last_error(h) == _lib.RVC_ERR_UNSUPPORTED
+        assert b"RVC_FLAG_PERSISTENT" in lib.rvc_last_error_string(h)
+    finally:
+        lib.rvc_set_destroy(h)
+
+
 def test_cpp_shim_headers_compile():
     """The C++ drop-in classes (include/reevr_amd/Convolver.h, StereoConvolver.h) compile and
     link against the C ABI with plain g++ (no HIP headers needed on the host side)."""
