@@ -267,13 +267,20 @@ class Lockstep:
                 x[0, self.probe_at] = 1.0
         self.x = x
         self.synth_s = time.perf_counter() - t0
-        self.conv = reevr_amd.ConvolverSet(self.nch, device=local_rank, bg_stream=bg, time_tiling=tiling, child_sets=child_sets)
         t0 = time.perf_counter()
         max_len = self.frames_step if long_call else self.host_block
-        ok = (self.conv.init_uniform(self.host_block, self.irs, max_len=max_len) if self.single
-              else self.conv.init(self.host_block, self.tail, self.irs, max_len=max_len))
-        if not ok:
-            raise SystemExit(f"init failed: {self.conv.last_error_string}")
+        self.renderer = None
+        if long_call:      # BASELINE config 5 as written: the raw batch renderer (reevr_amd/render.py)
+            from reevr_amd.render import BatchRenderer
+            self.renderer = BatchRenderer(self.irs, self.host_block, max_len, device=local_rank)
+            self.conv = self.renderer.set
+            assert (self.renderer.head, self.renderer.tail) == (self.head, self.tail)
+        else:
+            self.conv = reevr_amd.ConvolverSet(self.nch, device=local_rank, bg_stream=bg, time_tiling=tiling, child_sets=child_sets)
+            ok = (self.conv.init_uniform(self.host_block, self.irs, max_len=max_len) if self.single
+                  else self.conv.init(self.host_block, self.tail, self.irs, max_len=max_len))
+            if not ok:
+                raise SystemExit(f"init failed: {self.conv.last_error_string}")
         self.conv.sync()
         self.init_ms = (time.perf_counter() - t0) * 1e3
         self.d_in = torch.from_numpy(self.x).to(self.dev)
@@ -293,7 +300,7 @@ class Lockstep:
         if out is not None:
             yo = out
         if self.long_call:
-            self.conv.process_device(xi, yo, sync=False, order=order)
+            self.renderer.process_device(xi, yo, sync=False, order=order)
         else:                                  # the host's per-block loop (in C): one call per host block
             self.conv.process_device_blocks(xi, self.host_block, yo, sync=False, order=order)
         self.last_out = yo

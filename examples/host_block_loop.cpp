@@ -24,6 +24,7 @@ int main(int argc, char **argv) {
   const int sr = 48000, ir_len = 10 * sr, blocks = argc > 2 ? std::atoi(argv[2]) : 4000;
   const bool quad = argc > 3 && std::atoi(argv[3]) != 0;
   const int gap_us = argc > 4 ? std::atoi(argv[4]) : 0;   // idle time between calls (a real host sleeps ~10 ms)
+  const bool f32 = argc > 5 && std::atoi(argv[5]) != 0;   // RVC_FLAG_FFT_F32: float transforms in every stage (rvc.h)
   if (rvc_device_count() < 1) { std::puts("no GPU: this engine has no CPU fallback"); return 2; }
 
   Impulse imp;
@@ -39,7 +40,7 @@ int main(int argc, char **argv) {
   imp.isQuad = quad;
   if (quad) { make_ir(imp.bufferLR); make_ir(imp.bufferRL); }
 
-  StereoConvolver conv(0, RVC_FLAG_BG_STREAM);
+  StereoConvolver conv(0, RVC_FLAG_BG_STREAM | (f32 ? RVC_FLAG_FFT_F32 : 0u));
   conv.prepare(block);
   auto t0 = std::chrono::steady_clock::now();
   conv.loadImpulse(imp);
@@ -70,9 +71,9 @@ int main(int argc, char **argv) {
   std::sort(us.begin(), us.end());
   double sum = 0;
   for (double u : us) sum += u;
-  std::printf("{\"block\": %d, \"gap_us\": %d, \"channels\": %d, \"loadImpulse_ms\": %.2f, \"reloadImpulse_ms\": %.2f, \"call_us_median\": %.1f, \"call_us_p99\": %.1f, "
+  std::printf("{\"fft_f32\": %d, \"block\": %d, \"gap_us\": %d, \"channels\": %d, \"loadImpulse_ms\": %.2f, \"reloadImpulse_ms\": %.2f, \"call_us_median\": %.1f, \"call_us_p99\": %.1f, "
               "\"call_us_max\": %.1f, \"Msamples_per_s\": %.2f, \"block_period_us\": %.1f, \"checksum\": %.6f}\n",
-              block, gap_us, quad ? 4 : 2, load_ms, reload_ms, us[blocks / 2], us[(size_t)(blocks * 0.99)], us.back(),
+              f32 ? 1 : 0, block, gap_us, quad ? 4 : 2, load_ms, reload_ms, us[blocks / 2], us[(size_t)(blocks * 0.99)], us.back(),
               (quad ? 4.0 : 2.0) * block * blocks / sum, 1e6 * block / sr, checksum);
   return 0;
 }

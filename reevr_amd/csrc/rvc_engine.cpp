@@ -1956,6 +1956,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   else if (k == "sweep_split") rvc::set_sweep_tuning(value);
   else if (k == "sweep_lw") rvc::set_sweep_lane_width(value);
   else if (k == "sweep_d") rvc::set_sweep_depth(value);
+  else if (k == "sweep_lds") rvc::set_sweep_lds_tuning(value);
   else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
   else if (k == "subsets") g_tune.subsets = value;
   else if (k == "patch_nt") rvc::set_patch_nt_tuning(value);

@@ -195,6 +195,7 @@ constexpr int kSweepLagMax = 3;   // a sweep may run up to this many blocks befo
 hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st);
 // measurement hook (rvc_debug_set_tuning): "sweep_split" -1 auto / 0 own-tile form / 1 partition-split form
 void set_sweep_tuning(int split);
+void set_sweep_lds_tuning(int v);  // "sweep_lds": LDS-fed first-level sweeps, accumulators split over waves (rvc_sweep.hip): -1 default / 0 off / 1 / 2 / 3
 void set_sweep_depth(int d);         // "sweep_d": 8 = eight row pairs requested ahead in the long-tile sweeps (default 4)
 void set_sweep_lane_width(int lw);   // "sweep_lw": 4 = 16-byte lanes for the 16-block first-level sweeps (default 8-byte)
 

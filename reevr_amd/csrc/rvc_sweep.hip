@@ -295,6 +295,201 @@ __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_til
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------
+// LDS-fed form (round 4) of the long first-level sweeps: K = KW * NKW output blocks, the K accumulators SPLIT OVER NKW
+// WAVES that share every fetched row through LDS.
+//
+// Why: one wave holding 32 accumulators + a 32-row window (fdl_sweep_own<32>) needs 179 VGPRs -> two waves per SIMD, and at
+// 16 flop per HBM byte that is bound by VALU issue (0.50 of the HBM peak, profiles/r3_fma_rate_ubench.txt). Here a
+// workgroup of 2 * NKW waves owns 128 bins (a 1 KiB piece of every row): wave (kw, bt) keeps the KW accumulators of
+// output blocks kw * KW .. kw * KW + KW - 1 for the 64 bins of half bt and a KW-row CIRCULAR window (the body is unrolled
+// over KW steps, so window indices are compile-time and nothing is ever moved): the register footprint of a KW-block
+// sweep. Per step the WORKGROUP needs one new IR row piece and one new delay-line row piece -- the row wave kw shifts in
+// at step s is the one wave kw - 1 shifted in KW steps earlier -- and both arrive by LDS-DMA (global_load_lds_dwordx4:
+// one wave instruction = one 1 KiB piece, no staging registers, no VALU) into rings that run A chunks of C = 4 steps
+// ahead of the arithmetic: H ring (A + 1) * C rows, X ring that + KW * (NKW - 1) rows of history. Same HBM bytes as the
+// one-wave K-block sweep, per-wave intensity and registers of a KW-block one, one barrier per 4 steps.
+//
+// The DMA requests are inline asm -- hipcc would otherwise put s_waitcnt vmcnt(0) in front of every LDS read that might
+// alias a pending DMA write (cdna_hip_programming.md, "Pipelining across barriers") and so drain the rings each chunk --
+// and are counted by hand: every wave issues exactly LPW pieces per chunk, so "my pieces of chunk j have landed" is
+// s_waitcnt vmcnt((A - 1) * LPW), then the barrier makes everybody's visible. Pieces past the last partition / rows
+// that do not count are still requested, from a clamped address (a row the walk reads anyway: an L2 hit), so that the
+// counts stay uniform; the READER drops rows that do not count (wave-uniform select).
+// ----------------------------------------------------------------------------------------------------------
+template <bool NT>
+__device__ __forceinline__ void sweep_glds16(const unsigned long long gbase, const unsigned lane_off, const unsigned lds_dst) {
+  unsigned keep;   // (M0 = the DMA's LDS base; compiler-reserved, so saved and restored inside the statement)
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void sweep_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int KW, int NKW, int A>
+struct SweepLdsCfg {
+  static constexpr int C = 4;                       // steps per chunk: one barrier per chunk
+  static constexpr int NW = 2 * NKW;                // waves: NKW along the output blocks x 2 halves of the 128-bin piece
+  static constexpr int NH = (A + 1) * C;            // rows of the IR ring
+  static constexpr int PRE = KW * (NKW - 1);        // delay-line rows of history the later waves still need
+  static constexpr int XR = NH + PRE;               // rows of the delay-line ring
+  static constexpr int LPW = 2 * C / NW;            // pieces a wave requests per chunk
+  static constexpr int PIECE = 1024;                // bytes: 128 bins
+  static constexpr int LDS_BYTES = (NH + XR) * PIECE;
+  static_assert((2 * C) % NW == 0 && C % LPW == 0 && KW % C == 0 && (KW & (KW - 1)) == 0, "chunk / window indexing");
+  static_assert(PRE == 0 || PRE % NW == 0, "history rows split evenly over the waves");
+  static_assert((A - 1) * LPW <= 63, "vmcnt immediate");
+};
+
+template <int KW, int NKW, int A, int STAGE, bool NT, int LB>
+__global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a, const int rot) {
+  typedef SweepLdsCfg<KW, NKW, A> G;
+  constexpr int C = G::C, NH = G::NH, PRE = G::PRE, XR = G::XR, LPW = G::LPW, PIECE = G::PIECE;
+  typedef float2 V;
+  __shared__ __attribute__((aligned(1024))) char ring[G::LDS_BYTES];   // [NH] IR pieces, then [XR] delay-line pieces
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kw = wave >> 1, bt = wave & 1;
+  const int bx = rot ? (int)((blockIdx.x + blockIdx.y * (unsigned)rot) % gridDim.x) : (int)blockIdx.x;
+  const int c = blockIdx.y;
+  const int bin0 = bx * 128;                        // the workgroup's piece of every row: bins [bin0, bin0 + 128)
+  const int bin = bin0 + bt * 64 + lane;            // (B is a multiple of 128: launch_stage)
+  const int P = a.P;
+  const long long B = a.B;
+  const unsigned long long rowb = (unsigned long long)B * sizeof(float2);
+  const unsigned long long Hg = reinterpret_cast<unsigned long long>(a.H + (long long)c * a.h_chan_stride + bin0);
+  const unsigned long long Xg = reinterpret_cast<unsigned long long>(a.X + (long long)c * a.x_chan_stride + bin0);
+  const long long cbase = a.k0 - a.delay;           // input row meeting partition 0 for output row 0
+  const long long cb = cbase + (long long)kw * KW;   // ... for this wave's first output row
+  const bool packed = (bin == 0);
+  const long long lo = a.x_from > 0 ? a.x_from : 0;
+  const long long safe = a.x_hi >= lo ? a.x_hi : lo;
+  auto validX = [&](long long row) -> bool { return row >= lo && row <= a.x_hi; };
+  // The delay-line row that ENTERS the first wave's window behind step s (s < 0: history) is row cbase - s - 1; it counts
+  // iff vs_lo <= s <= vs_hi (32-bit scalars: the steps of a walk are small numbers whatever the absolute row index is)
+  auto clamp_i = [](long long v) -> int { return v < -(1 << 30) ? -(1 << 30) : (v > (1 << 30) ? (1 << 30) : (int)v); };
+  const int vs_lo = clamp_i(cbase - 1 - a.x_hi), vs_hi = clamp_i(cbase - 1 - lo);
+  auto valid_step = [&](int s) -> bool { return s >= vs_lo && s <= vs_hi; };
+  const unsigned lds0 = (unsigned)reinterpret_cast<unsigned long long>(ring);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto req_x = [&](int s, int slot) {
+    const long long rr = valid_step(s) ? cbase - s - 1 : safe;
+    sweep_glds16<NT>(Xg + ((unsigned long long)rr & a.x_row_mask) * rowb, lane16, lds0 + (unsigned)(NH + slot) * PIECE);
+  };
+  // this wave's LPW pieces of the chunk that starts at step sc; hs / xs = ring slots of that chunk's first step. The first
+  // half of the waves fetch IR pieces, the second half delay-line ones (scalar selects, one request statement)
+  const bool ld_h = wave * LPW < C;
+  const int ld_q = (wave * LPW) % C;
+  auto req_chunk = [&](int sc, int hs, int xs) {
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+      const int s = sc + ld_q + i;
+      const int hi = s < P ? s : P - 1;
+      const long long rr = valid_step(s) ? cbase - s - 1 : safe;
+      const unsigned long long g = ld_h ? Hg + (unsigned long long)hi * rowb : Xg + ((unsigned long long)rr & a.x_row_mask) * rowb;
+      const int slot = (ld_h ? hs : NH + xs) + ld_q + i;
+      sweep_glds16<NT>(g, lane16, lds0 + (unsigned)slot * PIECE);
+    }
+  };
+
+  V acc[KW], w[KW];
+#pragma unroll
+  for (int t = 0; t < KW; ++t) acc[t] = make_float2(0.f, 0.f);
+  // the window at step 0: rows cb .. cb + KW - 1, straight from global (ordinary loads; rows that do not count -- for a
+  // first-level sweep nearly all of them: they have not arrived yet -- are not requested: wave-uniform branches)
+  {
+    const float2 *Xl = a.X + (long long)c * a.x_chan_stride + bin;
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+      w[t] = make_float2(0.f, 0.f);
+      if (validX(cb + t)) w[t] = sweep_ld<NT>(Xl + (long long)((unsigned long long)(cb + t) & a.x_row_mask) * B);
+    }
+  }
+  // rings: the history rows (steps -PRE .. -1) and the first A chunks
+  if constexpr (PRE > 0) {
+#pragma unroll
+    for (int i = 0; i < PRE / G::NW; ++i) {
+      const int s = -PRE + wave + i * G::NW;
+      req_x(s, s + PRE);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < A; ++j) req_chunk(j * C, j * C, PRE + j * C);
+  // (the compiler waits for its own window loads with vmcnt(0) wherever they are first used -- make that HERE, where it
+  //  means "everything requested so far", not behind the next chunk's requests)
+#pragma unroll
+  for (int t = 0; t < KW; ++t) asm volatile("" : "+v"(w[t].x), "+v"(w[t].y));
+
+  const V *ldsH = reinterpret_cast<const V *>(ring) + bt * 64 + lane;
+  const V *ldsX = reinterpret_cast<const V *>(ring + NH * PIECE) + bt * 64 + lane;
+  constexpr int RV = PIECE / (int)sizeof(V);        // ring row stride in V
+  int hrow = 0, xrow = PRE;                         // ring slots of the current chunk's first step (first wave's view)
+  // one chunk of C steps starting at step sc = s0 + cc * C (cc compile-time: the window indices are). GUARD: the walk's
+  // last, partial body -- steps past the last partition are skipped (workgroup-uniform)
+  auto chunk = [&](const int sc, auto cc_tag, auto guard_tag) {
+    constexpr int cc = decltype(cc_tag)::value;
+    constexpr bool GUARD = decltype(guard_tag)::value;
+    sweep_wait_vm<(A - 1) * LPW>();                 // my pieces of this chunk have landed ...
+    __builtin_amdgcn_s_barrier();                   // ... everybody's have, and everybody is done with the previous chunk,
+    {                                               // whose slots chunk + A now takes
+      const int hs = hrow >= C ? hrow - C : hrow - C + NH;
+      const int xs = xrow + A * C >= XR ? xrow + A * C - XR : xrow + A * C;
+      req_chunk(sc + A * C, hs, xs);
+    }
+    const int xr = xrow - kw * KW >= 0 ? xrow - kw * KW : xrow - kw * KW + XR;   // this wave reads KW * kw steps behind
+    const V *hq = ldsH + hrow * RV, *xq = ldsX + xr * RV;
+#pragma unroll
+    for (int q = 0; q < C; ++q) {
+      constexpr int u0 = cc * C;
+      const int u = u0 + q;                         // step mod KW: compile-time
+      const int s = sc + q;
+      if (GUARD && s >= P) continue;
+      const V h = hq[q * RV];
+      const V xl = xq[q * RV];
+      const V xin = valid_step(s - kw * KW) ? xl : make_float2(0.f, 0.f);
+      const float hz = packed ? 0.f : h.y;          // first bin: ordinary (re, re, im) / packed (DC gain, Nyquist gain, 0)
+      const float h3 = packed ? h.y : h.x;
+#pragma unroll
+      for (int t = 0; t < KW; ++t) sweep_mac(acc[t], h, w[(t - u) & (KW - 1)], hz, h3);
+      w[(KW - 1 - u) & (KW - 1)] = xin;             // (the slot of the row that just left the window)
+    }
+    hrow = hrow + C == NH ? 0 : hrow + C;
+    xrow = xrow + C == XR ? 0 : xrow + C;
+  };
+  auto body = [&](const int s0, auto guard_tag) {
+    constexpr bool GUARD = decltype(guard_tag)::value;
+    static_assert(KW / C <= 4, "chunks per body");
+    if (!GUARD || s0 < P) chunk(s0, std::integral_constant<int, 0>(), guard_tag);
+    if constexpr (KW / C > 1) { if (!GUARD || s0 + C < P) chunk(s0 + C, std::integral_constant<int, 1>(), guard_tag); }
+    if constexpr (KW / C > 2) { if (!GUARD || s0 + 2 * C < P) chunk(s0 + 2 * C, std::integral_constant<int, 2>(), guard_tag); }
+    if constexpr (KW / C > 3) { if (!GUARD || s0 + 3 * C < P) chunk(s0 + 3 * C, std::integral_constant<int, 3>(), guard_tag); }
+  };
+  int s0 = 0;
+  for (; s0 + KW <= P; s0 += KW) body(s0, std::false_type());
+  if (s0 < P) body(s0, std::true_type());
+  sweep_wait_vm<0>();                               // (no DMA piece may land after this workgroup's LDS has been handed on)
+  float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
+  const long long k1 = a.k0 + (long long)kw * KW;
+  if (a.Ybase) {                                    // (+ rows of a level below: all requests first, then the stores)
+    const float2 *Yb = a.Ybase + (long long)c * a.ybase_chan_stride + bin;
+    V yb[KW];
+#pragma unroll
+    for (int t = 0; t < KW; ++t) yb[t] = Yb[(long long)((unsigned)(k1 + t) & a.ybase_row_mask) * B];
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+      V r = acc[t];
+      sweep_add(r, yb[t]);
+      Yc[(long long)((unsigned)(k1 + t) & a.y_row_mask) * B] = r;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < KW; ++t) Yc[(long long)((unsigned)(k1 + t) & a.y_row_mask) * B] = acc[t];
+  }
+}
+
 // grid (bin tiles, channels), block 256. STAGE names the instantiation for profilers (0 head, 1 tail).
 template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
 __global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a, const int rot) {
@@ -327,7 +522,22 @@ static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
   else hipLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a, rot);
 }
 
+template <int KW, int NKW, int A, int STAGE, bool NT, int LB>
+static void launch_lds_variant(const FirArgs &a, int channels, hipStream_t st) {
+  const dim3 grid(a.B / 128, channels), block(128 * NKW);
+  const int rot = (grid.x >= 8 && g_tile_rot) ? 1 : 0;
+  hipEvent_t ea, eb;
+  get_launch_events(&ea, &eb);
+  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep_lds<KW, NKW, A, STAGE, NT, LB>), grid, block, 0, st, ea, eb, 0, a, rot);
+  else hipLaunchKernelGGL((k_fdl_sweep_lds<KW, NKW, A, STAGE, NT, LB>), grid, block, 0, st, a, rot);
+}
+
 static int g_sweep_split = -1, g_sweep_lw = 0, g_sweep_depth = 0;
+// "sweep_lds": the LDS-fed form (accumulators split over waves) for first-level sweeps: -1 = where it is the default (32-block
+// tiles as 2 x 16, rings one chunk ahead), 0 = never (the one-wave forms), 1 = 2 x 16 with rings three chunks ahead, 2 = 32-block
+// tiles as 4 x 8, 3 = also 16-block tiles (2 x 8)
+static int g_sweep_lds = -1;
+void set_sweep_lds_tuning(int v) { g_sweep_lds = v; }
 void set_sweep_tuning(int split) { g_sweep_split = split; }
 void set_sweep_lane_width(int lw) { g_sweep_lw = lw; }
 void set_sweep_depth(int d) { g_sweep_depth = d; }
@@ -345,7 +555,19 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
   // measured against 8 B per lane, deeper queues, 2 / 4 waves per SIMD on MI355X (profiles/r2_sweep_variants.txt).
   // K = 16 / 32 (first level of long delay lines): 8 B per lane -- 2 K registers of accumulators, 2 K of window.
   const bool deep = g_sweep_depth == 8;           // (measurement: 8 row pairs requested ahead instead of 4)
-  if (a.M == 32) {
+  const bool lds_ok = a.B >= 128 && a.Ybase == nullptr && g_sweep_lds != 0;
+  if (a.M == 32 && lds_ok) {
+    // Measured on MI355X (profiles/r4_sweep_lds.txt): rings ONE chunk ahead (32 KiB: five workgroups = 20 waves per CU) beat
+    // three chunks ahead (48 KiB, three workgroups) on 512-bin rows -- config 1's 94-partition line 1.50 (one-wave form) / 1.47 /
+    // 1.35 ms per 8192-channel launch -- and tie on 8192-bin rows (config 3's 350 partitions: 23.6 / 23.3 / 23.2 ms), where every
+    // form executes 63-64 TFLOP/s of FMAs at a core clock the power limit holds at 1.70 GHz: that launch is bound by VALU work
+    // and power, not by HBM or occupancy.
+    if (g_sweep_lds == 2) launch_lds_variant<8, 4, 3, STAGE, true, 4>(a, channels, st);
+    else if (g_sweep_lds == 1) launch_lds_variant<16, 2, 3, STAGE, true, 3>(a, channels, st);
+    else launch_lds_variant<16, 2, 1, STAGE, true, 4>(a, channels, st);
+  } else if (a.M == 16 && lds_ok && g_sweep_lds == 3) {
+    launch_lds_variant<8, 2, 3, STAGE, true, 4>(a, channels, st);
+  } else if (a.M == 32) {
     if (deep) launch_variant<32, 1, STAGE, 2, 8, 2, true>(a, channels, st);
     else launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);
   } else if (a.M == 16) {

@@ -5,6 +5,8 @@
   * size-independent properties at BASELINE.json's full sizes.
 Tolerance: RMS(out - ref) <= 1e-5 relative to the output RMS (north_star: 1e-5 RMS, float32).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1172,6 +1174,19 @@ def _fdl_case(rng, nch, B, P, M, rows):
     (1, 3, 256, 64, 16, 0, 128, "own"),
     (1, 2, 512, 94, 32, 0, 128, "own"),
     (1, 2, 8192, 11, 16, 2, 3, "own_early"),       # the clock has just started: most rows do not exist yet
+    # round 4: the LDS-fed first-level sweeps (accumulators split over waves that share every fetched row through LDS-DMA rings)
+    (1, 2, 512, 94, 32, 0, 128, "lds32"),          # 2 x 16 blocks (the default form of 32-block tiles), config 1's line
+    (1, 3, 8192, 37, 32, 2, 200, "lds32"),         # tail-stage rows, a partial last body (37 = 2 x 16 + 5), three channels
+    (1, 2, 128, 5, 32, 0, 64, "lds32"),            # one 128-bin piece per row, fewer partitions than a ring holds
+    (1, 2, 256, 1, 32, 2, 64, "lds32"),            # a single partition
+    (1, 2, 512, 40, 32, 2, 7, "lds32_early"),      # the clock has just started: rows before block 0 read as zero
+    (1, 2, 512, 50, 32, 0, 96, "lds32_allrows"),   # every window row counts (x_hi beyond the tile): the windows' own loads
+    (1, 2, 1024, 45, 32, 2, 96, "lds32_4x8"),      # 4 x 8 blocks (512-thread workgroups)
+    (1, 2, 512, 50, 32, 0, 96, "lds32_4x8_allrows"),
+    (1, 2, 512, 41, 32, 2, 96, "lds32_deep"),      # rings three chunks ahead (48 KiB)
+    (1, 2, 8192, 57, 16, 2, 128, "lds16"),         # 16-block tiles as 2 x 8
+    (1, 3, 256, 23, 16, 0, 40, "lds16_allrows"),
+    (1, 2, 512, 94, 32, 0, 128, "one_wave32"),     # the one-wave 32-block form (sweep_lds = 0)
 ])
 def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant):
     """The complex multiply-accumulate kernels ALONE (SURVEY a-12): one launch of the general delay-line launcher / a sweep
@@ -1191,7 +1206,7 @@ def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant)
     second = variant == "second"
     has_add = variant in ("patch", "second")
     Are, Aim = split((nch, M if kind == 1 else 1)) if has_add else (None, None)
-    x_hi = k0 + M - 1 - delay if kind == 0 else (k0 - 2 if variant != "second" else k0 + 3)
+    x_hi = k0 + M - 1 - delay if kind == 0 else (k0 + M if variant.endswith("allrows") else (k0 - 2 if variant != "second" else k0 + 3))
     x_from = (k0 - 9) if second else 0
     want_re = np.zeros((nch, M, B + 1), np.float32)
     want_im = np.zeros((nch, M, B + 1), np.float32)
@@ -1211,12 +1226,15 @@ def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant)
     got = np.empty((nch, M, B, 2), np.float32)
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
     tune = {"split": 1, "own": 0, "own_early": 0, "second": 0}.get(variant)
+    lds = 2 if variant.startswith("lds32_4x8") else (3 if variant.startswith("lds16") else (0 if variant == "one_wave32" else (1 if variant.endswith("deep") else -1)))
     if tune is not None:
         reevr_amd.set_tuning("sweep_split", tune)
+    reevr_amd.set_tuning("sweep_lds", lds)
     try:
         ok = L.lib().rvc_debug_fdl(0, kind, nch, B, P, M, delay, k0, rows, fp(H), fp(X), fp(A), fp(got), x_hi, x_from)
     finally:
         reevr_amd.set_tuning("sweep_split", -1)
+        reevr_amd.set_tuning("sweep_lds", -1)
     assert ok == 1
     if kind == 1:                                   # output row j sits in slot (k0 + j) & (M - 1)
         got = np.stack([got[:, (k0 + j) & (M - 1)] for j in range(M)], axis=1)
@@ -1226,3 +1244,42 @@ def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant)
     assert np.abs(d).max() <= 1e-5 * scale, (variant, float(np.abs(d).max()), scale)
     assert np.sqrt(np.mean(d ** 2)) <= 2e-6 * np.sqrt(np.mean(want.astype(np.float64) ** 2))
 
+
+
+@pytest.mark.parametrize("block,nblocks,ir_len,quad", [(512, 40, 30000, True), (480, 30, 20000, False), (64, 50, 900, True)])
+def test_reference_stereo_convolver_glue_on_the_drop_in(tmp_path, block, nblocks, ir_len, quad):
+    """INTEGRATION.md's "compiles unchanged" claim, run: the REFERENCE's own src/dsp/StereoConvolver.cpp (compiled where it lies
+    against include/reevr_amd/Convolver.h by __graft_entry__.build() -> oracle/_ref/ref_glue; tests/test_abi.py has the recipe)
+    drives four drop-in Convolvers through prepare -> loadImpulse -> process per block -> clear -> process, and its public
+    buffers must be what four oracle TwoStageFFTConvolvers give (StereoConvolver.cpp:22-62; LR <- L, RL <- R; with a stereo
+    impulse the LR / RL buffers stay untouched)."""
+    import subprocess
+    from tests import test_abi
+    exe = test_abi.GLUE_EXE
+    if not os.path.exists(exe):
+        if not os.path.exists(test_abi.REF_SC):
+            pytest.skip("oracle/_ref/ref_glue was not built (needs /root/reference at build time)")
+        exe = test_abi.build_reference_glue(str(tmp_path))
+    pin, pout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    irs, x = test_abi.glue_operands(pin, block, nblocks, ir_len, quad)
+    r = subprocess.run([exe, pin, pout], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    got = np.fromfile(pout, np.float32).reshape(nblocks, 4, block).transpose(1, 0, 2).reshape(4, nblocks * block)
+    head = 1
+    while head < block:
+        head *= 2
+    cut = (nblocks // 2 + 1) * block                       # clear() behind block nblocks / 2
+    for c, src in enumerate([0, 1, 0, 1]):                 # LL <- L, RR <- R, LR <- L, RL <- R
+        if c >= 2 and not quad:
+            assert np.all(got[c] == 0)
+            continue
+        o = O.TwoStageFFTConvolver()
+        assert o.init(head, max(8192, 2 * head), irs[c])
+        want = np.concatenate([_stream(o, x[src, :cut], block), (o.clear(), _stream(o, x[src, cut:], block))[1]])
+        if cut % head:                                     # (a clear() inside a head block: the reference's stale-accumulator quirk,
+            continue                                       #  SURVEY a-11 -- not part of the parity contract)
+        assert rel_rms(got[c], want) <= 1e-5, (c, rel_rms(got[c], want))
+
+
+def _stream(o, x, block):
+    return np.concatenate([o.process(x[a:a + block]) for a in range(0, len(x), block)]) if len(x) else np.zeros(0, np.float32)

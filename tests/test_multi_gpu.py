@@ -65,6 +65,46 @@ def test_bench_two_ranks(extra):
         assert rec["config"]["channels_per_gpu"] == 32         # 64 mono channels over 2 ranks
 
 
+@pytest.mark.parametrize("extra", [["--config", "2", "--channels", "4", "--blocks-per-step", "16"],
+                                   ["--config", "4", "--blocks-per-step", "16"],
+                                   ["--config", "5"]], ids=["cfg2", "cfg4", "cfg5"])
+def test_bench_eight_ranks_control_flow(extra):
+    """The N = 8 control flow the driver's 8-GPU node will meet, before it meets it: eight ranks under torch.distributed.run
+    (one device each over RCCL when eight are visible, else all on device 0 over gloo): units_for_rank 8-way, the
+    strong-scaling totals of configs 4 / 5 (one stereo instance / four channel pairs per rank), the gather buffer shapes,
+    max-over-ranks timing, one JSON line. No request for a hardware curve."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if _ndev() < 8:
+        env["REEVR_BENCH_SAME_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--cpu-seconds", "0", "--side", "0", "--watchdog", "300"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["steps"] == 2 and rec["value"] > 0
+    assert rec["config"]["gather"] is True and rec["config"]["gather_matches_output"] is True
+    if extra[1] == "2":
+        assert rec["scaling"] == "weak"
+        assert rec["config"]["channels_per_gpu"] == 4 and rec["config"]["instances_total"] == 16
+        assert rec["probe"]["ok"] is True, rec["probe"]
+        # whole-job aggregate: 8 ranks x 4 channels x frames per step x steps / the slowest rank's time
+        frames = rec["config"]["frames_per_channel_per_step"]
+        assert abs(rec["value"] - 8 * 4 * frames * 2 / (rec["ms_per_step"] * 2e-3) / 1e6) <= 1e-3 * rec["value"]
+    if extra[1] == "4":
+        assert rec["scaling"] == "strong"
+        assert rec["config"]["channels_per_gpu"] == 2 and rec["config"]["instances_total"] == 8     # one stereo instance per rank
+        assert rec["config"]["gathered_channels_per_gpu"] == 2
+        assert rec["probe"]["ok"] is True, rec["probe"]
+    if extra[1] == "5":
+        assert rec["scaling"] == "strong"
+        assert rec["config"]["channels_per_gpu"] == 8 and rec["config"]["instances_total"] == 32    # 64 mono channels = 32 pairs, 4 pairs per rank
+        assert rec["config"]["gathered_channels_per_gpu"] == 8
+
+
 def test_bench_refuses_gpus_without_launcher():
     """`python bench.py --gpus 8` outside torch.distributed.run must fail, not report a 1-GPU number."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
