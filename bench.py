@@ -20,9 +20,17 @@ is used before the block has arrived) and both with the reference's partition si
     FFTConvolver.cpp:176-187: physical bytes = SURVEY.md 8d's algorithmic bytes, frac <= 1. Its
     fraction of the HBM peak is `roofline.alg_frac_reference_schedule`.
 
-The set runs on ONE queue (the engine's default): every launch has the device to itself, so `roofline` = bytes per
-launch / mean launch duration of the dominant kernel is an efficiency. The side entry `child_sets` is the same loop with
-RVC_FLAG_CHILD_SETS (child sets of ~2048 channels on their own streams: +4-5 % throughput, launches overlap).
+The set is the engine's default: thousands of block-synchronous channels are served by child sets of ~2048 channels on their
+own streams (fenced internally against the set's one stream), so two launches of a kernel family share the device. `roofline`
+is the dominant family: `frac` = its executed bytes over the UNION of its launch intervals (HIP events on one clock),
+`frac_per_launch` / `avg_launch_ms` the literal per-launch figures a profiler's kernel average corresponds to, and
+`one_queue_frac` / `one_queue_avg_launch_ms` the same family in the side run `one_queue` (RVC_FLAG_NO_SUBSETS: every launch has
+the device to itself, bytes per launch / mean launch duration is an efficiency).
+
+Small regimes (entry `regimes`, summary in `config`): the headline loop at 2 / 16 / 64 / 256 / 1024 channels (16 channels = the
+literal BASELINE config 4 on one GPU: 8 stereo instances), the literal config 5 (64 mono channels, one long call per step,
+through reevr_amd.render.BatchRenderer) and the headline set with RVC_FLAG_FFT_F64 (every transform in double like the
+reference's Ooura: the price of its precision at 4096 channels).
 
 The other BASELINE configurations run in the SAME lock-step regime in the same default run
 (`--configs 1,3,5`; entries `config1` / `config3` / `config5` of the line): config 1 (mono, 1 s IR,
@@ -72,7 +80,7 @@ SR = 48000
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3  # vector fp32 (same guide)
 K2 = 8                    # rvc::kSweepRows: the tile the per-block patches work on
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r4_traffic.json")
 
 # BASELINE.json configurations as lock-step workloads: IR length, host block, single-stage?, default channels per GPU,
 # host blocks per step (whole tail periods)
@@ -143,7 +151,10 @@ def cpu_baseline(irs, x, head_block: int, tail: int, budget_s: float, what: str)
     by a pthread loop in C (oracle/cpu_bench.c -- no Python in the loop). Bounded to ~budget_s."""
     from oracle import oracle_py as O
     which = "ref" if O.have_ref() else "orc"
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))          # the CPUs this process may run on (a container's share of the host)
+    except AttributeError:
+        cores = os.cpu_count() or 1
     model = ""
     try:
         for ln in open("/proc/cpuinfo"):
@@ -161,8 +172,11 @@ def cpu_baseline(irs, x, head_block: int, tail: int, budget_s: float, what: str)
                   f"tail inline: {n1} samples in {w1:.1f} s on 1 thread (C loop, oracle/cpu_bench.c)",
         "cpu_model": model, "flags": "g++ -O3 (SSE2 MAC as shipped, Utilities.cpp:62-111)",
         "all_cores": {"value": round(nm / wm / 1e6, 3), "cores": cores,
+                      "median_thread_Msamples_s": round(float(np.median(per)) / wm / 1e6, 3),
                       "sample": f"{cores} independent mono instances ({len(irs)} distinct IRs), one pthread each, "
-                                f"{nm} samples in {wm:.1f} s; slowest / fastest thread {min(per)} / {max(per)} samples"},
+                                f"{nm} samples in {wm:.1f} s; slowest / fastest thread {min(per)} / {max(per)} samples "
+                                "(a fixed wall budget on a shared host: the spread between threads and between runs is the "
+                                "host's scheduling, quote the 1-thread figure)"},
     }
 
 
@@ -243,7 +257,8 @@ class Lockstep:
     """One lock-step workload on this rank: the set, its resident input / output batches, the step function."""
 
     def __init__(self, torch, reevr_amd, synth, cfg: int, instances, local_rank: int, tiling: bool, bg: bool,
-                 blocks_per_step: int, long_call: bool = False, distinct: int = 0, irs=None, x=None, child_sets: bool = False):
+                 blocks_per_step: int, long_call: bool = False, distinct: int = 0, irs=None, x=None, child_sets=None,
+                 fft_f64: bool = False):
         self.torch, self.cfg = torch, cfg
         w = WORKLOADS[cfg if cfg in WORKLOADS else 2]
         self.ir_len, self.host_block, self.single = w["ir_len"], w["host_block"], w["single"]
@@ -276,7 +291,8 @@ class Lockstep:
             self.conv = self.renderer.set
             assert (self.renderer.head, self.renderer.tail) == (self.head, self.tail)
         else:
-            self.conv = reevr_amd.ConvolverSet(self.nch, device=local_rank, bg_stream=bg, time_tiling=tiling, child_sets=child_sets)
+            self.conv = reevr_amd.ConvolverSet(self.nch, device=local_rank, bg_stream=bg, time_tiling=tiling, child_sets=child_sets,
+                                               fft_f64=fft_f64)
             ok = (self.conv.init_uniform(self.host_block, self.irs, max_len=max_len) if self.single
                   else self.conv.init(self.host_block, self.tail, self.irs, max_len=max_len))
             if not ok:
@@ -365,7 +381,20 @@ class Lockstep:
         self.conv.kernel_time_reset()
         return kern
 
-    def timed(self, steps: int, warmup: int):
+    def tile_period_steps(self) -> int:
+        """steps one first-level tile of the longest-tiled stage spans: a first-level sweep runs once per tile, so only a whole
+        number of tiles is a fair average (config 3: 32 tail blocks = 4 steps of 8; configs 1 / 2 / 5: 1)"""
+        if self.long_call:
+            return 1
+        span = self.tail if self.tail else self.head
+        k1 = self.conv.tile_rows(1 if self.tail else 0) or 1
+        return max(1, -(-k1 * span // self.frames_step))
+
+    def timed(self, steps: int, warmup: int, whole_tiles: bool = False):
+        if whole_tiles:                        # (side measurements: round the step count up to whole first-level tiles)
+            p = self.tile_period_steps()
+            steps = -(-steps // p) * p
+        self.timed_steps = steps
         for _ in range(warmup):
             self.step()
         self.conv.sync()
@@ -404,15 +433,20 @@ def roofline_tables(kern: dict, exe: dict, traffic: dict):
     return roof_all, exe_bytes_step
 
 
-def load_traffic(nch: int, cfg: int, tiled: bool):
+def load_traffic(nch_per_launch: int, cfg: int, tiled: bool):
+    """Counter-measured HBM bytes per launch of each kernel family (profiles/r4_traffic.json: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes of this command, gfx950-corrected). An entry only applies to launches of exactly the
+    channel count it was measured with (`channels_per_launch`: the set's channels / its child sets): anything else is
+    refused -- a figure taken at another launch size reads like a model error."""
     if not os.path.exists(TRAFFIC_JSON):
         return {}, None
     tj = json.load(open(TRAFFIC_JSON))
     ent = tj.get("config%d" % cfg, tj if tj.get("config") == cfg else None)
-    if not ent or ent.get("channels") != nch or bool(ent.get("time_tiling", 0)) != tiled:
+    if not ent or ent.get("channels_per_launch") != nch_per_launch or bool(ent.get("time_tiling", 0)) != tiled:
         return {}, None
     return ({k: v["traffic_bytes"] for k, v in ent.get("kernels", {}).items()},
-            "profiles/r3_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected)")
+            "profiles/r4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected; "
+            "%d channels per launch)" % nch_per_launch)
 
 
 def side_config(torch, reevr_amd, synth, KERNEL_NAMES, cfg: int, channels: int, local_rank: int, steps: int, cpu_s: float):
@@ -422,12 +456,13 @@ def side_config(torch, reevr_amd, synth, KERNEL_NAMES, cfg: int, channels: int, 
     inst = list(range(channels // 2))
     ls = Lockstep(torch, reevr_amd, synth, cfg, inst, local_rank, True, False, w["blocks"], distinct=128)
     pre = ls.preroll()
-    rate, ms = ls.timed(steps, 2)
+    rate, ms = ls.timed(steps, 2, whole_tiles=True)
+    steps = ls.timed_steps
     probe = ls.check_probe()
     ls.conv.check()
     kern = ls.kernel_times(KERNEL_NAMES)
     exe = executed_bytes(ls.conv, ls.nch, ls.head, ls.tail, ls.ir_len, ls.host_block, ls.tiled)
-    traffic, tsrc = load_traffic(ls.nch, cfg, ls.tiled)
+    traffic, tsrc = load_traffic(ls.nch // max(1, ls.conv.subsets), cfg, ls.tiled)
     roof_all, exe_step = roofline_tables(kern, exe, traffic)
     bps = alg_bytes_per_sample(ls.head, ls.tail, ls.ir_len)
     exe_bps = exe_step / (ls.nch * ls.frames_step) if exe_step else None
@@ -458,22 +493,78 @@ def side_config(torch, reevr_amd, synth, KERNEL_NAMES, cfg: int, channels: int, 
                                  "ms_per_step": round(rms, 4), "achieved_GBs": round(rrate * bps / 1e9, 1),
                                  "alg_frac": round(rrate * bps / 1e9 / HBM_PEAK_GBS, 4)}
     out["alg_frac_reference_schedule"] = out["reference_schedule"]["alg_frac"]
-    # ... and with RVC_FLAG_CHILD_SETS (the throughput option: child sets of ~2048 channels on their own streams)
-    cs = Lockstep(torch, reevr_amd, synth, cfg, inst, local_rank, True, False, w["blocks"], irs=irs, x=x, child_sets=True)
-    if cs.conv.subsets > 1:
-        cs.preroll()
-        csteps = max(2, steps // 2)
-        crate, cms = cs.timed(csteps, 1)
-        cprobe = cs.check_probe()
-        cs.conv.check()
-        out["child_sets"] = {"value": round(crate / 1e6, 3), "unit": "Msamples/s", "steps": csteps, "ms_per_step": round(cms, 4),
-                             "subsets": cs.conv.subsets, "probe_ok": bool(cprobe and cprobe["ok"])}
-    cs.close()
+    # ... and on ONE queue (RVC_FLAG_NO_SUBSETS): every launch has the device to itself, bytes per launch / mean launch duration
+    # is then an efficiency per family (what a profiler's per-kernel average corresponds to)
+    if out["subsets"] > 1:
+        oq = Lockstep(torch, reevr_amd, synth, cfg, inst, local_rank, True, False, w["blocks"], irs=irs, x=x, child_sets=False)
+        oq.preroll()
+        osteps = max(2, steps // 2)
+        orate, oms = oq.timed(osteps, 1, whole_tiles=True)
+        osteps = oq.timed_steps
+        oprobe = oq.check_probe()
+        oq.conv.check()
+        okern = oq.kernel_times(KERNEL_NAMES)
+        oexe = executed_bytes(oq.conv, oq.nch, oq.head, oq.tail, oq.ir_len, oq.host_block, oq.tiled)
+        otraffic, _ = load_traffic(oq.nch, cfg, oq.tiled)
+        oroof, _ = roofline_tables(okern, oexe, otraffic)
+        out["one_queue"] = {"value": round(orate / 1e6, 3), "unit": "Msamples/s", "steps": osteps, "ms_per_step": round(oms, 4),
+                            "probe_ok": bool(oprobe and oprobe["ok"]),
+                            "roofline_all": {k: {"launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"],
+                                                 "bytes_per_launch": v["bytes_per_launch"], "frac": v["frac"], "traffic": v["traffic"]}
+                                             for k, v in oroof.items()}}
+        oq.close()
     if cpu_s > 0:
         cores = os.cpu_count() or 1
         n_ir = min(len(irs), max(2, cores))
         xin = [np.ascontiguousarray(x[1 + c % (len(x) - 1)]) for c in range(n_ir)]      # (channel 0 carries the probe)
         out["cpu_baseline"] = cpu_baseline(irs[:n_ir], xin, ls.host_block, ls.tail, cpu_s, w["text"])
+    return out
+
+
+def small_regimes(torch, reevr_amd, synth, KERNEL_NAMES, local_rank: int, steps: int, irs4096=None, x4096=None, instances=None):
+    """The regimes between one stereo pair and the headline's thousands of channels (where BASELINE configs 4 and 5 live on
+    an 8-GPU node), each with the impulse probe; plus the literal config 5 and the headline set with double transforms."""
+    out = {"channel_sweep": {}}
+    for ch in (2, 16, 64, 256, 1024):
+        ls = Lockstep(torch, reevr_amd, synth, 2, list(range(ch // 2)), local_rank, True, False, WORKLOADS[2]["blocks"], distinct=min(64, ch // 2))
+        pre = ls.preroll()
+        rate, ms = ls.timed(steps, 1)
+        probe = ls.check_probe()
+        ls.conv.check()
+        kern = ls.kernel_times(KERNEL_NAMES)
+        exe = executed_bytes(ls.conv, ls.nch, ls.head, ls.tail, ls.ir_len, ls.host_block, ls.tiled)
+        _, exe_step = roofline_tables(kern, exe, {})
+        exe_bps = exe_step / (ls.nch * ls.frames_step) if exe_step else None
+        out["channel_sweep"][str(ch)] = {
+            "value": round(rate / 1e6, 2), "unit": "Msamples/s", "us_per_block": round(ms * 1e3 / (ls.frames_step // ls.host_block), 3),
+            "frac_of_hbm_peak_executed_bytes": round(rate * exe_bps / 1e9 / HBM_PEAK_GBS, 4) if exe_bps else None,
+            "time_tiled": ls.tiled, "subsets": ls.conv.subsets, "probe_ok": bool(probe and probe["ok"]), "pre_roll_steps": pre}
+        ls.close()
+    out["channel_sweep"]["note"] = ("the headline loop (config 2's geometry, one process_device() per 512-frame block) at other channel counts; "
+                                    "16 channels = BASELINE config 4 on ONE GPU (8 stereo instances); on the 8-GPU node configs 4 / 5 put 2 / 8 "
+                                    "channels on each GPU")
+    # BASELINE config 5 as written: 64 parallel mono channels, 5 s IR, block 4096, one long call per step (the raw batch renderer)
+    l5 = Lockstep(torch, reevr_amd, synth, 5, list(range(32)), local_rank, True, False, 0, long_call=True)
+    l5.preroll()
+    rate5, ms5 = l5.timed(max(steps, 10), 2)
+    l5.conv.check()
+    out["config5_literal"] = {"value": round(rate5 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(ms5, 4), "channels": 64,
+                              "frames_per_channel_per_step": l5.frames_step,
+                              "workload": "64 mono channels, 5 s IR @ 48 kHz, block 4096, ONE process() of 20 s per step through "
+                                          "reevr_amd.render.BatchRenderer (the raw many-channel renderer, SURVEY 8f f-4)"}
+    l5.close()
+    # the headline set with every transform in double (RVC_FLAG_FFT_F64): the reference's transform precision at 4096 channels
+    if instances is not None:
+        lf = Lockstep(torch, reevr_amd, synth, 2, instances, local_rank, True, False, WORKLOADS[2]["blocks"], irs=irs4096, x=x4096, fft_f64=True)
+        lf.preroll()
+        ratef, msf = lf.timed(2, 1)
+        pf = lf.check_probe()
+        lf.conv.check()
+        out["fft_f64"] = {"value": round(ratef / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(msf, 4), "channels": lf.nch,
+                          "probe_ok": bool(pf and pf["ok"]), "probe_rms_error": pf["rms_error"] if pf else None,
+                          "note": "RVC_FLAG_FFT_F64: every transform in double (the reference's Ooura precision, AudioFFT.cpp:114-159); the "
+                                  "per-block call then takes the general path (the one-launch block kernel is float only)"}
+        lf.close()
     return out
 
 
@@ -495,8 +586,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the headline's CPU baseline leg (0 = skip)")
     ap.add_argument("--config-cpu-seconds", type=float, default=8.0, help="budget of each other configuration's CPU leg")
     ap.add_argument("--side", type=int, default=1, help="0: skip the side measurements")
+    ap.add_argument("--regimes", type=int, default=1, help="0: skip the small-regime entries (channel sweep, literal config 5, double transforms)")
     ap.add_argument("--distinct", type=int, default=0, help="synthesise only this many different stereo IRs and cycle them (0: all different; config 3: 128)")
-    ap.add_argument("--child-sets", type=int, default=0, help="1: RVC_FLAG_CHILD_SETS for the measured set (throughput option)")
+    ap.add_argument("--child-sets", type=int, default=1, help="0: RVC_FLAG_NO_SUBSETS for the measured set (one set on one queue; the "
+                    "default serves thousands of block-synchronous channels by child sets on their own streams, fenced internally)")
     ap.add_argument("--tune", type=str, default="", help="rvc_debug_set_tuning knobs, e.g. k1=32,subsets=2 (measurement hook)")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a stuck run dumps every thread's stack and exits (0: off)")
@@ -568,7 +661,7 @@ def main():
         raise SystemExit("--blocks-per-step must cover whole tail periods (a multiple of %d)" % ((tail or head) // host_block))
 
     ls = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, bool(args.time_tiling), bool(args.bg_stream), blocks,
-                  long_call=long_call, distinct=args.distinct or (128 if wcfg == 3 else 0), child_sets=bool(args.child_sets))
+                  long_call=long_call, distinct=args.distinct or (128 if wcfg == 3 else 0), child_sets=None if args.child_sets else False)
     conv, nch, frames_step, nbuf, ir_len = ls.conv, ls.nch, ls.frames_step, ls.nbuf, ls.ir_len
     do_gather = bool(args.gather and dist is not None)
     # The output batch of every step is gathered with ONE all_gather, overlapped with the next step's compute:
@@ -608,6 +701,7 @@ def main():
             torch.cuda.synchronize()
 
     pre = ls.preroll()
+    ls_period = ls.tile_period_steps()     # (a fair average needs --steps to be a multiple of this: 1 except for --config 3, where it is 4)
     for _ in range(args.warmup):
         step()
     fence()
@@ -647,7 +741,7 @@ def main():
     PA, PT = conv.partitions(0), conv.partitions(1)
     tiled = ls.tiled
     exe = {} if long_call else executed_bytes(conv, nch, head, tail, ir_len, host_block, tiled)
-    traffic_all, tsrc = ({}, None) if long_call else load_traffic(nch, args.config, tiled)
+    traffic_all, tsrc = ({}, None) if long_call else load_traffic(nch // max(1, conv.subsets), args.config, tiled)
     roof_all, exe_bytes_step = roofline_tables(kern, exe, traffic_all)
     bps = alg_bytes_per_sample(head, tail, ir_len)
     fps = flops_per_sample(head, tail, ir_len)
@@ -659,9 +753,9 @@ def main():
         roof = {"bound": "hbm", "kernel": dominant, "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": r["frac"], "traffic": r["traffic"], "bytes_per_launch": r["bytes_per_launch"],
                 "avg_launch_ms": r["avg_launch_ms"], "traffic_source": tsrc,
-                # one queue (the default): every launch has the device to itself, `achieved` = bytes per launch / mean launch
-                # duration (HIP events on the launching stream), concurrency 1. With --child-sets 1 launches of the family run
-                # side by side: `achieved` is then bytes over the UNION of the launch intervals, the literal frac_per_launch
+                # child sets (the default for thousands of channels): launches of the family run side by side, `achieved` = bytes
+                # over the UNION of the launch intervals; frac_per_launch / avg_launch_ms are the literal per-launch figures. On one
+                # queue (--child-sets 0, side entry one_queue) every launch has the device to itself and the two coincide
                 "concurrency": r["concurrency"], "frac_per_launch": r["frac_per_launch"], "busy_ms_per_step": r["ms_per_step"],
                 # SURVEY.md 8d's numerator (1497 B per channel-sample of the REFERENCE's loop nest): as a fraction of the
                 # peak only where the executed schedule moves those bytes (reference_schedule, filled in below); with
@@ -716,31 +810,29 @@ def main():
                         "partition (FFTConvolver.cpp:176-187): physical bytes = SURVEY.md 8d algorithmic bytes"}
             if roof is not None:
                 roof["alg_frac_reference_schedule"] = side["reference_schedule"]["frac_of_hbm_peak"]
-        if not args.tune and not args.child_sets:
-            # the same loop with RVC_FLAG_CHILD_SETS: the set served by child sets of ~2048 channels on their own streams (the
-            # engine's throughput option). Launches of different children overlap, so a family's efficiency is its bytes over
-            # the UNION of its launch intervals; bytes per launch / mean launch duration is then NOT an efficiency (the
-            # device is shared) -- which is why the headline and its roofline are measured on one queue.
-            cs = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, True, bool(args.bg_stream), blocks, irs=irs, x=x,
-                          child_sets=True)
-            cs.preroll()
-            csteps = max(2, args.steps // 2)
-            crate, cms = cs.timed(csteps, 1)
-            cprobe = cs.check_probe()
-            cs.conv.check()
-            ckern = cs.kernel_times(KERNEL_NAMES)
-            cexe = executed_bytes(cs.conv, nch, head, tail, ir_len, host_block, cs.tiled)
-            croof, _ = roofline_tables(ckern, cexe, {})
-            csub = cs.conv.subsets
-            cs.close()
-            side["child_sets"] = {
-                "value": round(crate / 1e6, 3), "unit": "Msamples/s", "steps": csteps, "ms_per_step": round(cms, 4),
-                "subsets": csub, "probe_ok": bool(cprobe and cprobe["ok"]),
+        if subsets > 1:
+            # the same loop on ONE queue (RVC_FLAG_NO_SUBSETS): every launch has the device to itself, so per family bytes per
+            # launch / mean launch duration is an efficiency -- the per-kernel figure a rocprofv3 kernel-stats average corresponds to
+            oq = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, True, bool(args.bg_stream), blocks, irs=irs, x=x,
+                          child_sets=False)
+            oq.preroll()
+            osteps = max(2, args.steps // 2)
+            orate, oms = oq.timed(osteps, 1)
+            oprobe = oq.check_probe()
+            oq.conv.check()
+            okern = oq.kernel_times(KERNEL_NAMES)
+            oexe = executed_bytes(oq.conv, nch, head, tail, ir_len, host_block, oq.tiled)
+            otraffic, _ = load_traffic(nch, args.config, oq.tiled)
+            oroof, _ = roofline_tables(okern, oexe, otraffic)
+            oq.close()
+            side["one_queue"] = {
+                "value": round(orate / 1e6, 3), "unit": "Msamples/s", "steps": osteps, "ms_per_step": round(oms, 4),
+                "probe_ok": bool(oprobe and oprobe["ok"]),
                 "roofline_all": {k: {"launches_per_step": v["launches_per_step"], "avg_launch_ms": v["avg_launch_ms"],
-                                     "concurrency": v["concurrency"], "bytes_per_launch": v["bytes_per_launch"],
-                                     "frac_over_union": v["frac"], "frac_per_launch": v["frac_per_launch"]} for k, v in croof.items()},
-                "note": "RVC_FLAG_CHILD_SETS run of the headline loop (same channels, inputs, call pattern): child sets on their "
-                        "own streams; frac_over_union = the family's bytes / the union of its launch intervals / 8 TB/s"}
+                                     "bytes_per_launch": v["bytes_per_launch"], "frac": v["frac"], "traffic": v["traffic"]}
+                                 for k, v in oroof.items()},
+                "note": "RVC_FLAG_NO_SUBSETS run of the headline loop (same channels, inputs, call pattern): one set on one queue; "
+                        "frac = bytes per launch / mean launch duration / 8 TB/s"}
         if args.config == 2:
             side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
     if world == 1 and args.cpu_seconds > 0 and lockstep_cfg:
@@ -748,12 +840,51 @@ def main():
         n_cpu_irs = min(len(irs), max(2, cores))
         xin = [np.ascontiguousarray(x[1 + c % (nch - 1)]) for c in range(n_cpu_irs)]          # (channel 0 carries the probe)
         cpu = cpu_baseline(irs[:n_cpu_irs], xin, host_block, tail, args.cpu_seconds, WORKLOADS[wcfg]["text"])
+    regimes = None
+    if args.config == 2 and world == 1 and args.side and args.regimes:
+        regimes = small_regimes(torch, reevr_amd, synth, KERNEL_NAMES, local_rank, 4, irs4096=irs, x4096=x, instances=instances)
     if args.config == 2 and world == 1 and args.side:
         del irs, x
         for c in [int(v) for v in args.configs.split(",") if v.strip()]:
             if c in WORKLOADS and c != 2:
                 others["config%d" % c] = side_config(torch, reevr_amd, synth, KERNEL_NAMES, c, WORKLOADS[c]["channels"],
                                                      local_rank, args.config_steps, args.config_cpu_seconds)
+
+    # Compact scalar summary of everything the line holds elsewhere in nested form (the driver keeps the scalar entries of
+    # `config` / `roofline`): per side configuration its rate, executed-bytes fraction of the HBM peak, SURVEY 8d fraction of
+    # the reference-order run and 1-thread CPU rate; the small regimes; the one-queue run.
+    summary = {}
+    for key, ent in others.items():
+        c = key.replace("config", "c")
+        summary[c + "_Msamples_s"] = ent["value"]
+        summary[c + "_exec_frac"] = ent["frac_of_hbm_peak_executed_bytes"]
+        summary[c + "_alg_frac_ref_schedule"] = ent["alg_frac_reference_schedule"]
+        summary[c + "_one_queue_Msamples_s"] = ent.get("one_queue", {}).get("value")
+        summary[c + "_cpu_1thread_Msamples_s"] = (ent.get("cpu_baseline") or {}).get("value")
+        summary[c + "_probe_ok"] = bool(ent["probe"] and ent["probe"]["ok"])
+    if regimes:
+        for ch, ent in regimes["channel_sweep"].items():
+            if isinstance(ent, dict):
+                summary["ch%s_Msamples_s" % ch] = ent["value"]
+                summary["ch%s_us_per_block" % ch] = ent["us_per_block"]
+                summary["ch%s_exec_frac" % ch] = ent["frac_of_hbm_peak_executed_bytes"]
+        summary["config4_literal_1gpu_Msamples_s"] = regimes["channel_sweep"]["16"]["value"]
+        summary["config5_literal_Msamples_s"] = regimes["config5_literal"]["value"]
+        if "fft_f64" in regimes:
+            summary["fft_f64_Msamples_s"] = regimes["fft_f64"]["value"]
+    if "one_queue" in side:
+        summary["one_queue_Msamples_s"] = side["one_queue"]["value"]
+        oq = side["one_queue"]["roofline_all"].get(roof["kernel"]) if roof else None
+        if oq:
+            roof["one_queue_frac"] = oq["frac"]
+            roof["one_queue_avg_launch_ms"] = oq["avg_launch_ms"]
+            roof["one_queue_bytes_per_launch"] = oq["bytes_per_launch"]
+            roof["one_queue_traffic"] = oq["traffic"]
+    if roof is not None:
+        roof["probe_ok"] = bool(probe and probe["ok"])
+        roof["frac_whole_step_executed_bytes"] = path["frac_of_hbm_peak"]
+        if roof.get("traffic") and roof.get("bytes_per_launch"):
+            roof["traffic_over_model"] = round(roof["traffic"] / roof["bytes_per_launch"], 4)
 
     line = {
         "metric": "Msamples/s convolved (stereo, 10s IR, block=512); % HBM roofline",
@@ -772,8 +903,8 @@ def main():
                    "call": ("one process() per step" if long_call else
                             "one process_device() per %d-frame host block for all channels (rvc_set_process_device_blocks), "
                             "device-resident I/O, %d input/output batches rotated" % (host_block, nbuf)),
-                   "pre_roll_steps": pre, "gather": do_gather, "gathered_channels_per_gpu": gch if do_gather else 0,
-                   "gather_matches_output": gather_ok, "tune": args.tune,
+                   "tile_period_steps": ls_period, "pre_roll_steps": pre, "gather": do_gather, "gathered_channels_per_gpu": gch if do_gather else 0,
+                   "gather_matches_output": gather_ok, "tune": args.tune, **summary,
                    "sharding": "instances dealt to ranks, equal shards, no data-path collective"
                                + (f"; one RCCL all_gather of the output blocks of {gch} channels per GPU per step, overlapped with the next step" if do_gather else "")},
         "roofline": roof,
@@ -782,6 +913,7 @@ def main():
         "path_roofline": path,
         "kernels_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()},
         **side,
+        "regimes": regimes,
         "cpu_baseline": cpu,
         **others,
         "init_ms": round(init_ms, 2), "synth_s": round(synth_s, 2),

@@ -86,13 +86,13 @@ enum {
                                    RVC_ERR_UNSUPPORTED and every init on it fails -- never silently ignored. */
 #define RVC_FLAG_FORCE_TIME_TILING 32u /* testing: time-tile every stage that has partitions to tile, however small
                                    (by default only stages whose per-block sweep is long enough to be bandwidth-bound) */
-#define RVC_FLAG_CHILD_SETS 1024u /* throughput option for sets of >= 2048 block-synchronous channels: serve the set by child sets
-                                   of ~2048 channels each on their own streams (rvc_set_subsets; two, four from 8192 channels
-                                   on). The latency-bound ends of one child's launches run under the bandwidth-bound middle of
-                                   another's: +4-5 % (MI355X, BASELINE config 2: 15.2 -> 15.9 Gsamples/s). Bit-identical
-                                   results. Work on device buffers must then be ordered against EVERY child's stream
-                                   (rvc_set_stream(s, 2 k)); off by default: one set, one foreground stream. */
-#define RVC_FLAG_NO_SUBSETS 512u  /* never child sets, whatever else asks for them (wins over RVC_FLAG_CHILD_SETS) */
+#define RVC_FLAG_CHILD_SETS 1024u /* (accepted, no effect: the default since round 4) sets of >= 2048 block-synchronous channels are
+                                   served by child sets of ~2048 channels each on their own streams (rvc_set_subsets; two, four
+                                   from 8192 channels on). The latency-bound ends of one child's launches run under the
+                                   bandwidth-bound middle of another's: +4-5 % (MI355X, BASELINE config 2). Bit-identical
+                                   results. The device-pointer calls fence the children against the set's own stream
+                                   (rvc_set_stream(s, 0)) on the way in and out: the caller orders against ONE stream as ever. */
+#define RVC_FLAG_NO_SUBSETS 512u  /* never child sets: one set, one foreground queue (per-launch profiling, A/B runs) */
 #define RVC_FLAG_FORCE_TWO_LEVEL 128u  /* testing: the same with two-level tiles whatever the partition count */
 
 /* ---- lifetime ---------------------------------------------------------------------- */
@@ -156,12 +156,6 @@ void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride,
 void rvc_set_process_device_blocks(rvc_set *s, const float *d_in, size_t in_stride, float *d_out,
                                    size_t out_stride, size_t len, size_t block);
 
-/* The same loop over HOST buffers (rvc_set_process per block, block <= max_len), with a stopwatch around every call:
- * us_per_call (may be NULL) receives ceil(len / block) durations in microseconds -- the per-call latency the plug-in's
- * audio thread sees, without host-language overhead. */
-void rvc_set_process_host_blocks_timed(rvc_set *s, const float *const *in, float *const *out, size_t len, size_t block,
-                                       double *us_per_call);
-
 /* ---- state ------------------------------------------------------------------------- */
 
 /* Replaces TwoStageFFTConvolver::clear / FFTConvolver::clear (TwoStageFFTConvolver.cpp:69-84,
@@ -189,13 +183,14 @@ int rvc_set_partitions(const rvc_set *s, int stage /*0 = head, 1 = tail, 2 = wid
 /* blocks per first-level sweep tile of the time-tiled delay line of a stage (0 head, 1 tail): 0 = not tiled, 8 = one level,
  * 16 / 32 = two levels (RVC_FLAG_NO_TIME_TILING) */
 int rvc_set_tile_rows(const rvc_set *s, int stage);
-/* hipStream_t of the foreground stream, as void*; (which = 1: the tail stream). A set of very many channels may be served
- * by rvc_set_subsets() child sets with streams of their own: child k's are which = 2 k and 2 k + 1 (NULL beyond the last),
- * and work on device buffers must be ordered against EVERY child's foreground stream. */
+/* hipStream_t of the foreground stream, as void*: THE stream device-pointer calls are asynchronous on and callers order their
+ * own work against (which = 1: the tail stream). A set of very many channels is served by rvc_set_subsets() child sets with
+ * streams of their own (which = 2 + 2 k and 3 + 2 k for child k, NULL beyond the last: diagnostics); every device-pointer call
+ * makes the children wait for what was ordered before stream 0 and stream 0 wait for the children's work of the call. */
 void *rvc_set_stream(rvc_set *s, int which);
 /* number of child sets (1: the set runs on its own two streams; n > 1: channels [k n_channels/n, (k+1) n_channels/n) are child
- * k's). With RVC_FLAG_CHILD_SETS, chosen at init for sets of thousands of lock-step channels: the latency-bound ends of one
- * child's per-block launch overlap the bandwidth-bound middle of another's. */
+ * k's). Chosen at init for sets of thousands of lock-step block-synchronous channels (RVC_FLAG_NO_SUBSETS: never): the
+ * latency-bound ends of one child's per-block launch overlap the bandwidth-bound middle of another's. */
 int rvc_set_subsets(const rvc_set *s);
 int rvc_last_error(const rvc_set *s);
 const char *rvc_last_error_string(const rvc_set *s);
@@ -330,42 +325,8 @@ int rvc_send_pre_device(int device, void *stream, const rvc_send_params *p);
 
 /* ---- library ----------------------------------------------------------------------- */
 
-/* Known-answer entries for the transforms alone: one n-point real transform (n = 2 * partition size, a power
- * of two, 2 <= n <= 2 * RVC_MAX_BLOCK; half that with f64) through the SAME forward / inverse kernels and twiddle
- * tables the convolver stages use, with the reference facade's conventions (AudioFFT::fft / ifft,
- * libs/FFTConvolver/AudioFFT.cpp:114-159, :988-1016): split-complex re / im of n/2 + 1 bins, unscaled forward,
- * 1/n total on the inverse. Host buffers; synchronous; for tests, not for the audio path. 1 = ok. */
-int rvc_debug_rfft(int device, size_t n, int f64, const float *data, float *re, float *im);
-int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re, const float *im);
-
-/* Development / tests: ONE launch of a frequency-domain delay-line kernel on caller-provided rows -- the complex
- * multiply-accumulate of Utilities.cpp:62-111 as FFTConvolver.cpp:176-187 applies it, in isolation:
- *   Y[m] = (Yadd) + sum_{i < P} H[i] * X[(k0 + m - delay - i) & (ring_rows - 1)],  m < M,  rows before block 0 read as zero.
- * Rows are B interleaved (re, im) bins, bin 0 holding the packed (DC, Nyquist) pair (two real products). H: [channels][P][B],
- * X: [channels][ring_rows][B], Y: [channels][M][B]. kind 0: the general launcher (LDS-tiled, row or patch kernel by shape;
- * Yadd = [channels][B], M = 1 only); kind 1: a sweep of the time-tiled delay line, M = 8 / 16 / 32, input rows outside
- * [x_from, x_hi] read as zero, output row j in slot (k0 + j) & (M - 1), Yadd = [channels][M][B] first-level rows or NULL.
- * Returns 1 on success. */
-int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int delay, long long k0, int ring_rows,
-                  const float *H, const float *X, const float *Yadd, float *Y, long long x_hi, long long x_from);
-
-/* Measurement hook (bench.py, tools/): process-wide schedule knobs, read when a set is initialised. Returns 1 if the
- * key is known. Keys: "k1" first-level tile of long delay lines (8 = one level, 16 default, 32); "sweep_split" -1 auto /
- * 0 own-tile / 1 partition-split sweeps; "fft_loop" -1 auto / 0 / 1 row-looping 8192-bin transforms; "subsets" -1 auto /
- * n children of a many-channel set; "guard" 0 / 1 guard bands around every device allocation (see rvc_debug_guard_check) / 2 every
- * allocation END-aligned against an unmapped address range (an out-of-bounds access faults: tools/fence_fuzz.py only);
- * "two_level_min_p" delay lines with more partitions than this get two tiling levels (-1: default 24); "tile_rot" 1 (default) /
- * 0 sweeps and patches on long rows take channel c's bin tiles in the order rotated by c; "sweep_lw", "sweep_d", "patch_nt",
- * "block_occ": kernel variants (rvc_internal.h). */
-int rvc_debug_set_tuning(const char *key, int value);
-/* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set
- * is initialised, every device allocation of the set lies between two 256 KiB guard bands filled with 0xFF and starts out
- * 0xFF-filled itself (0xFFFFFFFF is a NaN: a value read out of bounds, or never written, and USED shows in the output).
- * Returns the number of guard bytes that changed (0 = no out-of-bounds write so far), -1 if the set has no guards. */
-long rvc_debug_guard_check(rvc_set *s);
-/* Fence mode ("guard" = 2) self-check: 1 if the last bytes of the set's first allocation can be copied out and the bytes
- * right behind it cannot (the range is reserved but unmapped), 0 if both succeed, -1 if the set is not fenced. */
-int rvc_debug_fence_probe(rvc_set *s);
+/* (The measurement / development entries -- rvc_debug_*, rvc_set_process_host_blocks_timed -- are declared in rvc_debug.h: this
+ * header is the reference's surface plus the set API.) */
 
 /* Number of visible HIP devices (0 when there is none or the runtime cannot start). */
 int rvc_device_count(void);

@@ -1,0 +1,61 @@
+/* rvc_debug.h -- measurement and development entries of libreevr_amd.so: known-answer hooks for single kernels, the
+ * schedule knobs bench.py's A/B runs use, the out-of-bounds nets, a stopwatch loop. NOT part of the drop-in surface
+ * (that is rvc.h: the reference's init / process / clear / reset plus the batched set API); nothing here is needed to use
+ * the engine, and none of it is on the audio path. */
+#ifndef REEVR_AMD_RVC_DEBUG_H
+#define REEVR_AMD_RVC_DEBUG_H
+
+#include "rvc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The host's per-block loop of rvc_set_process_device_blocks over HOST buffers (rvc_set_process per block, block <= max_len), with a stopwatch around every call:
+ * us_per_call (may be NULL) receives ceil(len / block) durations in microseconds -- the per-call latency the plug-in's
+ * audio thread sees, without host-language overhead. */
+void rvc_set_process_host_blocks_timed(rvc_set *s, const float *const *in, float *const *out, size_t len, size_t block,
+                                       double *us_per_call);
+
+/* Known-answer entries for the transforms alone: one n-point real transform (n = 2 * partition size, a power
+ * of two, 2 <= n <= 2 * RVC_MAX_BLOCK; half that with f64) through the SAME forward / inverse kernels and twiddle
+ * tables the convolver stages use, with the reference facade's conventions (AudioFFT::fft / ifft,
+ * libs/FFTConvolver/AudioFFT.cpp:114-159, :988-1016): split-complex re / im of n/2 + 1 bins, unscaled forward,
+ * 1/n total on the inverse. Host buffers; synchronous; for tests, not for the audio path. 1 = ok. */
+int rvc_debug_rfft(int device, size_t n, int f64, const float *data, float *re, float *im);
+int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re, const float *im);
+
+/* Development / tests: ONE launch of a frequency-domain delay-line kernel on caller-provided rows -- the complex
+ * multiply-accumulate of Utilities.cpp:62-111 as FFTConvolver.cpp:176-187 applies it, in isolation:
+ *   Y[m] = (Yadd) + sum_{i < P} H[i] * X[(k0 + m - delay - i) & (ring_rows - 1)],  m < M,  rows before block 0 read as zero.
+ * Rows are B interleaved (re, im) bins, bin 0 holding the packed (DC, Nyquist) pair (two real products). H: [channels][P][B],
+ * X: [channels][ring_rows][B], Y: [channels][M][B]. kind 0: the general launcher (LDS-tiled, row or patch kernel by shape;
+ * Yadd = [channels][B], M = 1 only); kind 1: a sweep of the time-tiled delay line, M = 8 / 16 / 32, input rows outside
+ * [x_from, x_hi] read as zero, output row j in slot (k0 + j) & (M - 1), Yadd = [channels][M][B] first-level rows or NULL.
+ * Returns 1 on success. */
+int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int delay, long long k0, int ring_rows,
+                  const float *H, const float *X, const float *Yadd, float *Y, long long x_hi, long long x_from);
+
+/* Measurement hook (bench.py, tools/): process-wide schedule knobs, read when a set is initialised. Returns 1 if the
+ * key is known. Keys: "k1" first-level tile of long delay lines (8 = one level, 16 default, 32); "sweep_split" -1 auto /
+ * 0 own-tile / 1 partition-split sweeps; "fft_loop" -1 auto / 0 / 1 row-looping 8192-bin transforms; "subsets" -1 auto /
+ * n children of a many-channel set; "guard" 0 / 1 guard bands around every device allocation (see rvc_debug_guard_check) / 2 every
+ * allocation END-aligned against an unmapped address range (an out-of-bounds access faults: tools/fence_fuzz.py only);
+ * "two_level_min_p" delay lines with more partitions than this get two tiling levels (-1: default 24); "tile_rot" 1 (default) /
+ * 0 sweeps and patches on long rows take channel c's bin tiles in the order rotated by c; "sweep_lw", "sweep_d", "patch_nt",
+ * "block_occ": kernel variants (rvc_internal.h). */
+int rvc_debug_set_tuning(const char *key, int value);
+/* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set
+ * is initialised, every device allocation of the set lies between two 256 KiB guard bands filled with 0xFF and starts out
+ * 0xFF-filled itself (0xFFFFFFFF is a NaN: a value read out of bounds, or never written, and USED shows in the output).
+ * Returns the number of guard bytes that changed (0 = no out-of-bounds write so far), -1 if the set has no guards. */
+long rvc_debug_guard_check(rvc_set *s);
+/* Fence mode ("guard" = 2) self-check: 1 if the last bytes of the set's first allocation can be copied out and the bytes
+ * right behind it cannot (the range is reserved but unmapped), 0 if both succeed, -1 if the set is not fenced. */
+int rvc_debug_fence_probe(rvc_set *s);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* REEVR_AMD_RVC_DEBUG_H */

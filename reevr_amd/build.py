@@ -21,7 +21,8 @@ SOURCES = ["rvc_kernels.hip", "rvc_sweep.hip", "rvc_impulse.hip", "rvc_engine.cp
 # the 8192-bin inverse transform 614 -> 679 instructions but 239 packed + 168 moves -> 424 scalar + 36 moves, 56 -> 40 registers,
 # 115 -> 108 us per 4096 rows; no kernel spills any more)
 EXTRA_FLAGS = {"rvc_sweep.hip": ["-fno-slp-vectorize"], "rvc_kernels.hip": ["-fno-slp-vectorize"]}
-HEADERS = ["rvc_internal.h", "rvc_fft_lds.hpp", os.path.join("..", "..", "include", "reevr_amd", "rvc.h")]
+HEADERS = ["rvc_internal.h", "rvc_fft_lds.hpp", os.path.join("..", "..", "include", "reevr_amd", "rvc.h"),
+           os.path.join("..", "..", "include", "reevr_amd", "rvc_debug.h")]
 
 
 def _hipcc() -> str:

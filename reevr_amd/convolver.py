@@ -34,10 +34,11 @@ class ConvolverSet:
 
     def __init__(self, n_channels: int, device: int = 0, bg_stream: bool = False, timing: bool = False,
                  fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True,
-                 fft_f32: bool = False, child_sets: bool = False):
+                 fft_f32: bool = False, child_sets=None):
         """time_tiling: True (by size) / False / "force" (every stage, one level unless long) / "force2" (two levels).
         fft_f64 / fft_f32: every transform in double / in float (default: rvc.h, RVC_FLAG_FFT_F64).
-        child_sets: RVC_FLAG_CHILD_SETS (throughput option of sets of thousands of lock-step channels)."""
+        child_sets: None / True = the engine's default (sets of thousands of block-synchronous channels are served by child sets on
+        their own streams, fenced internally), False = RVC_FLAG_NO_SUBSETS (one set on one queue: per-launch profiling)."""
         self._lib = L.lib()
         flags = ((L.RVC_FLAG_BG_STREAM if bg_stream else 0) | (L.RVC_FLAG_TIMING if timing else 0)
                  | (L.RVC_FLAG_FFT_F64 if fft_f64 else 0) | (L.RVC_FLAG_FFT_F32 if fft_f32 else 0)
@@ -45,7 +46,7 @@ class ConvolverSet:
                  | (0 if time_tiling else L.RVC_FLAG_NO_TIME_TILING)
                  | (L.RVC_FLAG_FORCE_TIME_TILING if time_tiling == "force" else 0)
                  | (L.RVC_FLAG_FORCE_TWO_LEVEL if time_tiling == "force2" else 0)
-                 | (L.RVC_FLAG_CHILD_SETS if child_sets else 0))
+                 | (L.RVC_FLAG_NO_SUBSETS if child_sets is False else 0))
         self.n_channels = int(n_channels)
         self.device = int(device)
         self._h = self._lib.rvc_set_create(self.n_channels, self.device, flags)
@@ -140,10 +141,10 @@ class ConvolverSet:
 
     def _order_after_torch(self):
         """The engine runs on its own (non-blocking) HIP streams: make them wait for whatever torch's
-        current stream has queued (the kernels still producing d_in). Returns the wrapped streams (one per child set)."""
+        current stream has queued (the kernels still producing d_in). Returns the wrapped stream: stream 0 of the set is the
+        one callers order against also when child sets serve it (the library fences them internally, rvc.h rvc_set_stream)."""
         import torch
-        ptrs = [self._lib.rvc_set_stream(self._h, 2 * k) for k in range(max(1, self._lib.rvc_set_subsets(self._h)))]
-        ptrs = [p for p in ptrs if p]
+        ptrs = [p for p in [self._lib.rvc_set_stream(self._h, 0)] if p]
         if not ptrs:
             return None
         if getattr(self, "_ext_ptrs", None) != ptrs:

@@ -44,6 +44,7 @@
 #include <vector>
 
 #include "../../include/reevr_amd/rvc.h"
+#include "../../include/reevr_amd/rvc_debug.h"
 #include "rvc_internal.h"
 
 namespace {
@@ -108,6 +109,7 @@ struct Tuning {
   int two_min_p = -1;     // "two_level_min_p": delay lines with MORE partitions than this get two levels (-1: kTwoLevelMinP)
   int fft_loop = -1;      // row-looping form of the 8192-bin transforms: -1 by size, 0 never, 1 always
   int subsets = -1;       // children of a many-channel set: -1 by size, else the count
+  int kid_fence = 1;      // "kid_fence" (measurement): 0 = no fences between a set's stream and its child sets', 2 = fences but no parent stream work
   int guard = 0;          // 1: NaN-filled guard bands around (and NaN poison inside) every device allocation of a set
 };
 Tuning g_tune;
@@ -167,6 +169,7 @@ struct rvc_set {
   hipStream_t st_main = nullptr, st_bg = nullptr;
   bool streams_ok = false;
   hipEvent_t ev_ingest = nullptr;
+  hipEvent_t ev_fence = nullptr;  // child sets: "this child's work of the call is enqueued" (the parent's stream waits for it)
   // Tail jobs enqueued on st_bg, oldest first. Fixed capacity and a pre-created event pool: nothing on the
   // process() / clear() path allocates (the reference's real-time rule, FFTConvolver.h:44-47).
   struct Job { long long m_lo, m_hi; hipEvent_t ev; };   // produced the tail contributions of output blocks [m_lo, m_hi)
@@ -202,7 +205,8 @@ struct rvc_set {
   // sets measure against their parent's base event, so that the intervals of all children share one clock)
   hipEvent_t timed_base = nullptr;
   rvc_set *timed_parent = nullptr;
-  std::vector<std::pair<float, float>> timed_iv[kNumKernelIds];
+  std::vector<std::pair<double, double>> timed_iv[kNumKernelIds];   // (the base event is re-recorded by every
+                                                                      //  rvc_set_kernel_time_reset: offsets stay small)
 };
 
 namespace {
@@ -310,9 +314,14 @@ bool ensure_streams(rvc_set *s) {
   // (Measured for the many-channel lock-step loop, profiles/r2_bg_overlap.txt: a high-priority foreground stream and a
   //  background stream confined to 192 / 128 / 64 CUs by a CU mask change the step time by less than 2 % either way.)
   RVC_CK(hipStreamCreateWithFlags(&s->st_main, hipStreamNonBlocking));
-  RVC_CK(hipStreamCreateWithFlags(&s->st_bg, hipStreamNonBlocking));
+  // The tail stream only where it is asked for: the runtime multiplexes streams onto a few hardware queues (4 by default), and
+  // two child sets whose foreground streams land on ONE queue serialise (measured: six streams for a two-child set -- the
+  // children's launches did not overlap at all, 14.0 instead of 15.5 Gsamples/s). Without the flag st_bg is st_main.
+  if ((s->flags & RVC_FLAG_BG_STREAM) != 0) RVC_CK(hipStreamCreateWithFlags(&s->st_bg, hipStreamNonBlocking));
+  else s->st_bg = s->st_main;
   RVC_CK(hipEventCreateWithFlags(&s->ev_ingest, hipEventDisableTiming));
   RVC_CK(hipEventCreateWithFlags(&s->ev_out, hipEventDisableTiming));
+  RVC_CK(hipEventCreateWithFlags(&s->ev_fence, hipEventDisableTiming));
   for (s->ev_free = 0; s->ev_free < rvc_set::kMaxJobs; ++s->ev_free)
     RVC_CK(hipEventCreateWithFlags(&s->ev_pool[s->ev_free], hipEventDisableTiming));
   s->streams_ok = true;
@@ -345,7 +354,7 @@ void fold_timing(rvc_set *s, int id) {
       const hipEvent_t base = s->timed_parent ? s->timed_parent->timed_base : s->timed_base;
       float st = 0.f;
       if (base && s->timed_iv[id].size() < ((size_t)1 << 16) && hipEventElapsedTime(&st, base, t.a) == hipSuccess)
-        s->timed_iv[id].push_back({st, st + ms});
+        s->timed_iv[id].push_back({(double)st, (double)st + (double)ms});
     }
     hipEventDestroy(t.a); hipEventDestroy(t.b);
   }
@@ -1176,7 +1185,11 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   // rebuild of the head delay line. (With the tail on the second stream the job may outlive the
   // caller's buffer, so everything is copied; those calls are short.)
   const long long keep = s->keep;
-  const bool fuse_in = !bg && (long long)len > keep;
+  // (Also the per-block call of many channels with a large head block -- block_general, BASELINE config 5's geometry: one
+  //  whole block on its boundary. The head transform reads the block from the caller's buffer and appends it to the ring
+  //  itself: no separate copy launch in front of it -- 4 % of that step, a 0.49-of-peak copy feeding the transform.)
+  const bool block_call = s->block_general && !bg && k0 == k1 && n0 % hb == 0 && n1 % hb == 0;
+  const bool fuse_in = !bg && ((long long)len > keep || block_call);
   // (the adaptive long-call path below lets its forward transform append the history: no ingest launch)
   const bool has_long = T.PF > 0;                 // a whole-IR table at block T exists (two-stage sets; long-call stage of single-stage sets)
   const long long tbq = has_long ? (long long)T.B : 1;
@@ -1190,7 +1203,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   const bool head_ingests = !adaptive && fuse_in && rvc::fwd_appends_ring(A.logB);
   if (!fft_ingests && !head_ingests) {
     rvc::IngestArgs a{};
-    const long long skip = fuse_in ? (long long)len - keep : 0;
+    const long long skip = (fuse_in && (long long)len > keep) ? (long long)len - keep : 0;
     a.src = d_in + skip; a.src_chan_stride = (long long)in_stride;
     a.ring = s->xring; a.ring_chan_stride = (long long)s->ring_cap; a.ring_mask = s->ring_cap - 1;
     a.n0 = n0 + skip; a.len = (long long)len - skip;
@@ -1326,23 +1339,23 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
 
   // 3. two-stage path: tail job one period ahead, then the zero-latency stage over the whole call
   if (has_tail && !run_tail_job(s, n0, n1, src2, in_stride, bg)) return false;
-  if (!head_stage(s, n0, n0, n1, src2, in_stride, d_out, out_stride, bg, head_ingests ? n1 - keep : -1)) return false;
+  if (!head_stage(s, n0, n0, n1, src2, in_stride, d_out, out_stride, bg, head_ingests ? std::max(n0, n1 - keep) : -1)) return false;
   mark_long_stage_stale(s, n1);
   s->n = n1;
   return true;
 }
 
-// How many children a set of nch channels gets at this init (1: none; RVC_FLAG_CHILD_SETS asks for them, the measurement
+// How many children a set of nch channels gets at this init (1: none; RVC_FLAG_NO_SUBSETS forbids them, the measurement
 // hook's "subsets" forces a count). Measured on MI355X (profiles/r3_tuning.txt).
 int subset_count(const rvc_set *s, size_t head_block, size_t max_len) {
   if ((s->flags & RVC_FLAG_NO_SUBSETS) != 0) return 1;
   int n = g_tune.subsets;
-  // RVC_FLAG_CHILD_SETS: two children for sets of thousands of lock-step channels served block by block, four from 8192 on
-  // (measured on MI355X, BASELINE config 2: 4096 channels 13.2 -> 14.3 Gsamples/s with two, 13.1 with four; 8192 channels
-  // 14.4 -> 14.7 with two -> 15.2 with four; config 1's 8192 channels 25.6 -> 25.8: children of ~2048 channels:
+  // Default since round 4 (the calls fence the children against the set's own stream, fence_children_in / _out, so the caller
+  // still orders against ONE stream): two children for sets of thousands of lock-step channels served block by block, four
+  // from 8192 on (measured on MI355X, BASELINE config 2: 4096 channels 13.2 -> 14.3 Gsamples/s with two, 13.1 with four; 8192
+  // channels 14.4 -> 14.7 with two -> 15.2 with four; config 1's 8192 channels 25.6 -> 25.8: children of ~2048 channels:
   // profiles/r3_tuning.txt); long calls gain nothing from it
-  if (n < 0) n = ((s->flags & RVC_FLAG_CHILD_SETS) != 0 && s->nch >= 2048 && max_len <= 2 * next_pow2(head_block ? head_block : 1))
-                     ? (s->nch >= 8192 ? 4 : 2) : 1;
+  if (n < 0) n = (s->nch >= 2048 && max_len <= 2 * next_pow2(head_block ? head_block : 1)) ? (s->nch >= 8192 ? 4 : 2) : 1;
   if (n > 8) n = 8;
   while (n > 1 && (s->nch % n != 0 || s->nch / n < 2)) --n;
   return n < 1 ? 1 : n;
@@ -1367,6 +1380,38 @@ bool make_kids(rvc_set *s, int n) {
     s->kid_c0.push_back(k * per);
   }
   return true;
+}
+
+// Child sets run on their own streams; the CALLER of a device-pointer entry still sees one: child 0's foreground stream is
+// the set's (rvc_set_stream(s, 0)) -- no further stream, the runtime has few hardware queues to map them on. Going in, every
+// other child's foreground stream waits for what the caller has ordered before that stream (the producer of d_in); going
+// out, that stream waits for every other child's work of this call (so an event / a kernel behind it sees d_out
+// complete). One event record + one wait per further child and direction; rvc_set_process_device_blocks fences ONCE around
+// its whole loop, so inside it the children still run unsynchronised (which is where their gain comes from).
+bool fence_children_in(rvc_set *s) {
+  rvc_set *f = s->kids[0];
+  if (g_tune.kid_fence == 0 || !f->streams_ok) return true;
+  if (!use_device(s)) return false;
+  RVC_CK(hipEventRecord(f->ev_fence, f->st_main));
+  for (size_t k = 1; k < s->kids.size(); ++k)
+    if (s->kids[k]->streams_ok) RVC_CK(hipStreamWaitEvent(s->kids[k]->st_main, f->ev_fence, 0));
+  return true;
+}
+bool fence_children_out(rvc_set *s) {
+  rvc_set *f = s->kids[0];
+  if (g_tune.kid_fence == 0 || !f->streams_ok) return true;
+  for (size_t k = 1; k < s->kids.size(); ++k) {
+    rvc_set *c = s->kids[k];
+    if (!c->streams_ok) continue;
+    RVC_CK(hipEventRecord(c->ev_fence, c->st_main));
+    RVC_CK(hipStreamWaitEvent(f->st_main, c->ev_fence, 0));
+  }
+  return true;
+}
+void forward_device_call(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len) {
+  for (size_t k = 0; k < s->kids.size(); ++k)
+    rvc_set_process_device(s->kids[k], d_in + (size_t)s->kid_c0[k] * in_stride, in_stride,
+                           d_out + (size_t)s->kid_c0[k] * out_stride, out_stride, len);
 }
 // the parent mirrors what its accessors report
 void adopt_kid_geometry(rvc_set *s, bool ok) {
@@ -1428,7 +1473,8 @@ void rvc_set_destroy(rvc_set *s) {
     for (int i = 0; i < s->ev_free; ++i) hipEventDestroy(s->ev_pool[i]);
     hipEventDestroy(s->ev_ingest);
     hipEventDestroy(s->ev_out);
-    hipStreamDestroy(s->st_bg);
+    hipEventDestroy(s->ev_fence);
+    if (s->st_bg != s->st_main) hipStreamDestroy(s->st_bg);
     hipStreamDestroy(s->st_main);
   }
   delete s;
@@ -1501,9 +1547,9 @@ void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride, flo
                             size_t out_stride, size_t len) {
   if (!s || len == 0) return;
   if (!s->kids.empty()) {
-    for (size_t k = 0; k < s->kids.size(); ++k)
-      rvc_set_process_device(s->kids[k], d_in + (size_t)s->kid_c0[k] * in_stride, in_stride,
-                             d_out + (size_t)s->kid_c0[k] * out_stride, out_stride, len);
+    (void)fence_children_in(s);
+    forward_device_call(s, d_in, in_stride, d_out, out_stride, len);
+    (void)fence_children_out(s);
     return;
   }
   if (!s->live || s->err != RVC_OK) {   // not initialised / empty IR / failed: zeros
@@ -1525,6 +1571,13 @@ void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride, flo
 void rvc_set_process_device_blocks(rvc_set *s, const float *d_in, size_t in_stride, float *d_out,
                                    size_t out_stride, size_t len, size_t block) {
   if (!s || block == 0) return;
+  if (!s->kids.empty()) {        // one fence around the whole loop: the buffers are complete before and read after it
+    (void)fence_children_in(s);
+    for (size_t done = 0; done < len; done += block)
+      forward_device_call(s, d_in + done, in_stride, d_out + done, out_stride, std::min(block, len - done));
+    (void)fence_children_out(s);
+    return;
+  }
   for (size_t done = 0; done < len; done += block)
     rvc_set_process_device(s, d_in + done, in_stride, d_out + done, out_stride, std::min(block, len - done));
 }
@@ -1672,6 +1725,7 @@ int rvc_set_is_finished(rvc_set *s) {
     if (!rvc_set_is_finished(k)) return 0;
   if (!s->live) return 1;
   hipSetDevice(s->device);
+  if (s->st_bg == s->st_main) return 1;      // no tail stream: the tail job runs inline, nothing is ever in the background
   return hipStreamQuery(s->st_bg) == hipSuccess ? 1 : 0;
 }
 
@@ -1705,8 +1759,9 @@ int rvc_set_tile_rows(const rvc_set *s, int stage) {
 int rvc_set_subsets(const rvc_set *s) { return !s ? 0 : (s->kids.empty() ? 1 : (int)s->kids.size()); }
 void *rvc_set_stream(rvc_set *s, int which) {
   if (!s || which < 0) return nullptr;
-  if (!s->kids.empty()) {               // child k's streams are 2 k (foreground) and 2 k + 1 (tail)
-    const size_t k = (size_t)which / 2;
+  if (!s->kids.empty()) {               // 0: the stream the caller orders against; child k's streams are 2 + 2 k (foreground)
+    if (which < 2) return which == 0 ? rvc_set_stream(s->kids[0], 0) : nullptr;   // and 3 + 2 k (tail): diagnostics
+    const size_t k = (size_t)(which - 2) / 2;
     return k < s->kids.size() ? rvc_set_stream(s->kids[k], which % 2) : nullptr;
   }
   return which == 0 ? (void *)s->st_main : (which == 1 ? (void *)s->st_bg : nullptr);
@@ -1959,6 +2014,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   else if (k == "sweep_lds") rvc::set_sweep_lds_tuning(value);
   else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
   else if (k == "subsets") g_tune.subsets = value;
+  else if (k == "kid_fence") g_tune.kid_fence = value;
   else if (k == "patch_nt") rvc::set_patch_nt_tuning(value);
   else if (k == "block_occ") rvc::set_block_occ3_tuning(value);
   else if (k == "tile_rot") rvc::set_tile_rot_tuning(value);

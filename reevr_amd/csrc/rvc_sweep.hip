@@ -566,7 +566,11 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
     else if (g_sweep_lds == 1) launch_lds_variant<16, 2, 3, STAGE, true, 3>(a, channels, st);
     else launch_lds_variant<16, 2, 1, STAGE, true, 4>(a, channels, st);
   } else if (a.M == 16 && lds_ok && g_sweep_lds == 3) {
-    launch_lds_variant<8, 2, 3, STAGE, true, 4>(a, channels, st);
+    // (measurement only: 16-block tiles through the LDS-fed form lose to the one-wave 16-byte-lane form on config 2's 57 x
+    //  8192-bin tail -- 6.38 ms per launch against 6.64 (2 x 8, one chunk ahead), 6.98 (2 x 8, three chunks), 6.87 / 7.17 (one
+    //  wave of 16 fed through the rings, one / three chunks ahead): at 8 flop per byte that sweep is not VALU-bound, and the
+    //  one-wave form's 16-byte lanes move twice the bytes per request; profiles/r4_sweep_lds.txt)
+    launch_lds_variant<8, 2, 1, STAGE, true, 4>(a, channels, st);
   } else if (a.M == 32) {
     if (deep) launch_variant<32, 1, STAGE, 2, 8, 2, true>(a, channels, st);
     else launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);

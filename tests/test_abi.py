@@ -10,6 +10,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "reevr_amd", "rvc.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "reevr_amd", "rvc_debug.h")     # measurement / development entries
 
 
 @pytest.fixture(scope="module")
@@ -20,8 +21,8 @@ def lib():
     return _lib.lib()
 
 
-def declared_symbols():
-    text = open(HEADER).read()
+def declared_symbols(header=None):
+    text = open(header).read() if header else open(HEADER).read() + open(DEBUG_HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(rvc_[a-z_0-9]+)\s*\(", text)))
 
@@ -35,6 +36,9 @@ def test_header_symbols_all_exported(lib):
         assert hasattr(raw, n), f"{n} declared in rvc.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
+    # rvc.h is the reference's surface plus the set API: no measurement / development entry in it
+    assert not [n for n in declared_symbols(HEADER) if n.startswith("rvc_debug_") or n.endswith("_timed")]
+    assert all(n.startswith("rvc_debug_") or n.endswith("_timed") for n in declared_symbols(DEBUG_HEADER))
 
 
 def test_no_cpu_fallback_without_gpu(lib):

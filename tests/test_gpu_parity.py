@@ -928,15 +928,15 @@ def test_two_level_tiling_at_config3_geometry():
 
 
 def test_child_sets_flag():
-    """RVC_FLAG_CHILD_SETS: off by default (one set, one queue); with it, 2048 block-synchronous channels run as two child
-    sets -- same bits; sets below 2048 channels and long-call sets stay single."""
+    """Child sets are the default since round 4: 2048 block-synchronous channels run as two child sets, RVC_FLAG_NO_SUBSETS keeps
+    one set on one queue -- same bits; sets below 2048 channels and long-call sets stay single."""
     import torch
     nch, head, nblk = 2048, 64, 24
     irs = [synth.synth_ir(300 + c % 17, 1, 700 + c % 29)[0] for c in range(nch)]
     x = np.stack([synth.synth_input(head * nblk, 70 + c % 11) for c in range(nch)])
     dx = torch.from_numpy(x).cuda()
     outs = []
-    for flag, want in ((False, 1), (True, 2)):
+    for flag, want in ((False, 1), (None, 2)):
         s = reevr_amd.ConvolverSet(nch, child_sets=flag)
         assert s.init_uniform(head, irs, max_len=head), s.last_error_string
         assert s.subsets == want
@@ -944,6 +944,29 @@ def test_child_sets_flag():
         assert s.last_error == 0, s.last_error_string
         s.close()
     assert np.array_equal(outs[0], outs[1])
+    # The caller orders against ONE stream (rvc_set_stream(s, 0)) although the children run on their own: the producer of d_in
+    # and the consumer of d_out live on torch's current stream, nothing synchronises on the host in between (sync=False), the
+    # input buffer is overwritten right behind the call -- per-block calls (a fence per call) and the C block loop (one fence).
+    s = reevr_amd.ConvolverSet(nch)
+    assert s.init_uniform(head, irs, max_len=head) and s.subsets == 2
+    for form in ("calls", "loop"):
+        s.clear()
+        buf = torch.empty_like(dx)
+        acc = torch.zeros_like(dx)
+        big = torch.empty((64, 1 << 20), device="cuda")
+        big.normal_()                                       # (keeps torch's stream busy: the copy below completes late)
+        buf.copy_(dx, non_blocking=True)                    # producer of d_in, on torch's stream
+        if form == "loop":
+            y = s.process_device_blocks(buf, head, sync=False)
+        else:
+            y = torch.empty_like(buf)
+            for b in range(nblk):
+                s.process_device(buf[:, b * head:(b + 1) * head], y[:, b * head:(b + 1) * head], sync=False)
+        acc += y                                            # consumer of d_out, on torch's stream
+        buf.fill_(float("nan"))                             # the input is dead the moment the call's work is ordered
+        torch.cuda.synchronize()
+        assert np.array_equal(acc.cpu().numpy(), outs[0]), form
+    s.close()
     for c in (0, 1023, 1024, 2047):
         o = O.FFTConvolver("orc")
         assert o.init(head, irs[c])

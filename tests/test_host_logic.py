@@ -114,6 +114,8 @@ def test_pmc_summary_kernel_families():
     assert fam("void rvc::k_fdl_sweep<8, 4, 1, 4, 4, 3, false>(rvc::FirArgs, int)") == "sweep_tail"
     assert fam("void rvc::k_fdl_sweep<16, 1, 1, 4, 4, 2, true>(rvc::FirArgs, int)") == "sweep_tail"
     assert fam("void rvc::k_fdl_sweep<8, 1, 1, 4, 4, 3, false>(rvc::FirArgs, int)") == "sweep2_tail"
+    assert fam("void rvc::k_fdl_sweep_lds<16, 2, 1, 1, true, 4>(rvc::FirArgs, int)") == "sweep_tail"
+    assert fam("void rvc::k_fdl_sweep_lds<16, 2, 1, 0, true, 4>(rvc::FirArgs, int)") == "sweep_head"
     assert fam("void rvc::k_fdl_patch<1, true>(rvc::FirArgs, int)") == "fir_tail"
     assert fam("void rvc::k_fft8_inv<13, float, false>(rvc::InvArgs)") == "fft_inv_tail"
     assert fam("void rvc::k_fft8_fwd_loop<13>(rvc::FwdArgs, int)") == "fft_fwd_tail"

@@ -22,6 +22,10 @@ CALIB_BYTES = 4 * (1 << 28)      # tools/pmc_calib.py copies 1 GiB per dispatch:
 
 
 
+PATCH0_FAMILY = "premultiply"     # k_fdl_patch<0, ..>: the zero-latency stage's patch; "fir_head" for sets whose per-block call takes
+                                  # the general path (many channels with a large head block: BASELINE config 5's geometry)
+
+
 def family(name: str, head_log: int, tail_log: int):
     if "k_fused_block" in name or "k_block_step" in name:
         return "fused_block"
@@ -31,6 +35,9 @@ def family(name: str, head_log: int, tail_log: int):
         # second-level sweeps are exactly the own-tile K = 8 instantiation with ordinary loads (rvc_sweep.hip launch_stage)
         second = m.group(1) == "8" and m.group(2) == "1" and m.group(4) == "false"
         return ("sweep2_" if second else "sweep_") + st
+    m = re.search(r"k_fdl_sweep_lds<\d+, \d+, \d+, (\d), (?:true|false), \d+>", name)   # <KW, NKW, A, STAGE, NT, LB>: first level only
+    if m:
+        return "sweep_head" if m.group(1) == "0" else "sweep_tail"
     m = re.search(r"k_fft8_(fwd|inv)_loop<(\d+)>", name)
     if m:
         return f"fft_{m.group(1)}_tail"
@@ -39,7 +46,7 @@ def family(name: str, head_log: int, tail_log: int):
         return "premultiply" if m.group(1) == "0" else "fir_tail"
     m = re.search(r"k_fdl_patch<(\d)", name)
     if m:
-        return "premultiply" if m.group(1) == "0" else "fir_tail"
+        return PATCH0_FAMILY if m.group(1) == "0" else "fir_tail"
     m = re.search(r"k_fir(?:_lds)?<(?:\d+, )?(\d)>", name)
     if m:
         return "fir_head" if m.group(1) == "0" else "fir_tail"   # <1> tail stage, <2> whole-IR line (timed as fir_tail)
@@ -89,9 +96,12 @@ def main():
     ap.add_argument("--k1-head", type=int, default=16, help="(recorded only)")
     ap.add_argument("--k1-tail", type=int, default=16, help="(recorded only)")
     ap.add_argument("--subsets", type=int, default=1, help="child sets (bench.py --child-sets 1): every launch covers channels / subsets")
+    ap.add_argument("--patch0-family", default="premultiply", help="family of k_fdl_patch<0,..>: premultiply, or fir_head (general per-block path)")
     ap.add_argument("--command", default="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --side 0")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
+    global PATCH0_FAMILY
+    PATCH0_FAMILY = a.patch0_family
     fe = per_family(a.fetch_csv, a.head_log, a.tail_log)
     wr = per_family(a.write_csv, a.head_log, a.tail_log)
     ff, fk = calib_factor(a.calib_fetch, 2.0)

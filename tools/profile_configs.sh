@@ -1,0 +1,71 @@
+#!/bin/bash
+# Round 4: the rocprofv3 evidence behind bench.py's `roofline*.traffic` and the per-kernel durations, for BASELINE configs
+# 2 (headline), 1, 3 and 5 in the lock-step regime AT THE BENCH'S OWN LAUNCH SIZES (the engine's default: child sets).
+#   per config:  --kernel-trace --stats   -> <out>/config<C>/kernel_stats.csv, kernel_union.txt (union of dispatch intervals)
+#                --pmc FETCH_SIZE         -> FETCH_SIZE_per_kernel.csv   (own pass, MI355X_MICROARCH.md HBM section)
+#                --pmc WRITE_SIZE         -> WRITE_SIZE_per_kernel.csv   (own pass)
+#   once:        the same two counters over a 1 GiB copy (tools/pmc_calib.py) -> calib_*_per_kernel.csv
+# then tools/pmc_summarize.py -> <out>/config<C>/traffic.json, merged into <out>/traffic.json (= profiles/r4_traffic.json).
+#   usage (GPU box, repo root): tools/profile_configs.sh <out dir> [configs, default "2 1 3 5"]
+set -u
+OUT=$(realpath -m "${1:-gpurun_out/prof}")
+CONFIGS="${2:-2 1 3 5}"
+ROOT=$(pwd)
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+compact() {   # per-kernel mean of a counter_collection.csv -> small CSV
+python - "$1" "$2" <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+with open(sys.argv[2], "w") as f:
+    f.write("Kernel_Name,Dispatches,Mean_KiB,Min_KiB,Max_KiB\n")
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        f.write('"%s",%d,%.3f,%.3f,%.3f\n' % (k, len(v), sum(v) / len(v), min(v), max(v)))
+PY
+}
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d "$OUT/calib_$c" -o pmc -- python "$ROOT/tools/pmc_calib.py" > /dev/null 2> "$OUT/calib_$c.err"
+  find "$OUT/calib_$c" -name '*counter_collection.csv' -exec cp {} "$OUT/calib_$c.csv" \;
+  compact "$OUT/calib_$c.csv" "$OUT/calib_${c}_per_kernel.csv"
+  rm -rf "$OUT/calib_$c"
+done
+for C in $CONFIGS; do
+  D="$OUT/config$C"; mkdir -p "$D"
+  case $C in
+    1) GEO="--channels 8192 --subsets 4 --head-log 9 --tail-log 13 --k1-head 32 --k1-tail 0" ;;
+    2) GEO="--channels 4096 --subsets 2 --head-log 9 --tail-log 13 --k1-head 16 --k1-tail 16" ;;
+    3) GEO="--channels 2048 --subsets 2 --head-log 8 --tail-log 13 --k1-head 16 --k1-tail 32" ;;
+    5) GEO="--channels 4096 --subsets 2 --head-log 12 --tail-log 13 --k1-head 0 --k1-tail 16 --patch0-family fir_head" ;;
+  esac
+  ARGS="--config $C --steps 3 --warmup 1 --cpu-seconds 0 --side 0 --distinct 64"
+  KT_ARGS="--config $C --steps 20 --warmup 5 --cpu-seconds 0 --side 0 --distinct 64"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$D/kt" -o kt -- python "$ROOT/bench.py" $KT_ARGS > "$D/bench_under_rocprof.json" 2> "$D/kt.err"
+  find "$D/kt" -name '*kernel_stats.csv' -exec cp {} "$D/kernel_stats.csv" \;
+  find "$D/kt" -name '*kernel_trace.csv' -exec python "$ROOT/tools/trace_union.py" {} \; > "$D/kernel_union.txt" 2>&1
+  rm -rf "$D/kt"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d "$D/pmc_$c" -o pmc -- python "$ROOT/bench.py" $ARGS > /dev/null 2> "$D/pmc_$c.err"
+    find "$D/pmc_$c" -name '*counter_collection.csv' -exec cp {} "$D/$c.csv" \;
+    rm -rf "$D/pmc_$c"
+  done
+  python "$ROOT/tools/pmc_summarize.py" "$D/FETCH_SIZE.csv" "$D/WRITE_SIZE.csv" --calib-fetch "$OUT/calib_FETCH_SIZE.csv" \
+    --calib-write "$OUT/calib_WRITE_SIZE.csv" --command "python bench.py $ARGS" --config $C $GEO -o "$D/traffic.json" > "$D/traffic.txt" 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do compact "$D/$c.csv" "$D/${c}_per_kernel.csv"; rm -f "$D/$c.csv"; done
+done
+rm -f "$OUT"/calib_FETCH_SIZE.csv "$OUT"/calib_WRITE_SIZE.csv
+python - "$OUT" $CONFIGS <<'PY'
+import json, os, sys
+out, cfgs = sys.argv[1], sys.argv[2:]
+merged = {}
+for c in cfgs:
+    p = os.path.join(out, "config" + c, "traffic.json")
+    if os.path.exists(p):
+        merged.update(json.load(open(p)))
+json.dump(merged, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print({k: v["channels_per_launch"] for k, v in merged.items()})
+PY
+cd "$ROOT"
+du -sh "$OUT"
