@@ -21,11 +21,12 @@ is used before the block has arrived) and both with the reference's partition si
     fraction of the HBM peak is `roofline.alg_frac_reference_schedule`.
 
 The set is the engine's default: thousands of block-synchronous channels are served by child sets of ~2048 channels on their
-own streams (fenced internally against the set's one stream), so two launches of a kernel family share the device. `roofline`
-is the dominant family: `frac` = its executed bytes over the UNION of its launch intervals (HIP events on one clock),
-`frac_per_launch` / `avg_launch_ms` the literal per-launch figures a profiler's kernel average corresponds to, and
-`one_queue_frac` / `one_queue_avg_launch_ms` the same family in the side run `one_queue` (RVC_FLAG_NO_SUBSETS: every launch has
-the device to itself, bytes per launch / mean launch duration is an efficiency).
+own streams (fenced internally against the set's one stream), so launches of the children -- of one kernel family and of
+different ones -- share the device: `value` is that run. There a launch's duration depends on what else is running, so the
+contract's per-launch `roofline` (bytes per launch / mean launch duration of the dominant kernel) is taken in the `one_queue` leg
+of the same run (RVC_FLAG_NO_SUBSETS, same channels / inputs / call pattern: every launch has the device to itself), with the
+default run's own figures beside it as `roofline.default_run_*` (frac = the family's bytes over the UNION of its launch
+intervals, HIP events on one clock) and the whole step's executed-bytes fraction as `roofline.frac_whole_step_executed_bytes`.
 
 Small regimes (entry `regimes`, summary in `config`): the headline loop at 2 / 16 / 64 / 256 / 1024 channels (16 channels = the
 literal BASELINE config 4 on one GPU: 8 stereo instances), the literal config 5 (64 mono channels, one long call per step,
@@ -225,8 +226,11 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
     else:                                                    # zero-latency stage not tiled: every block reads all of it
         exe["fused_block"] = 5 * row_h + io_blk + (2.0 * max(PA - 2, 0) + 1) * row_h
         # (many channels with a large head block: the per-block call is transform / delay line / inverse launches)
-        exe.update({"ingest": float(n1 * 8 * host_block), "fft_fwd_head": float(n1 * (4 * 2 * head + 8 * head)),
-                    "fir_head": (2.0 * PA + 1) * row_h, "fft_inv_head": float(n1 * (8 * head + 12 * head))})
+        # (the head transform reads the block from the caller's buffer and appends it to the ring itself: + 4 * head, no ingest launch)
+        exe.update({"fft_fwd_head": float(n1 * (4 * 2 * head + 8 * head + 4 * head)),
+                    "fir_head": (2.0 * PA + 1) * row_h,
+                    # (spectrum row in, the tail stage's stream in, samples out)
+                    "fft_inv_head": float(n1 * (8 * head + (4 * head if tail and PT else 0) + 4 * head))})
     exe["premultiply"] = 2.0 * max(PA - 2, 0) * row_h + row_h
     if tail and PT:
         if KT:
@@ -441,9 +445,11 @@ def load_traffic(nch_per_launch: int, cfg: int, tiled: bool):
     if not os.path.exists(TRAFFIC_JSON):
         return {}, None
     tj = json.load(open(TRAFFIC_JSON))
-    ent = tj.get("config%d" % cfg, tj if tj.get("config") == cfg else None)
-    if not ent or ent.get("channels_per_launch") != nch_per_launch or bool(ent.get("time_tiling", 0)) != tiled:
+    ents = [e for e in tj.values() if isinstance(e, dict) and e.get("config") == cfg and
+            e.get("channels_per_launch") == nch_per_launch and bool(e.get("time_tiling", 0)) == tiled]
+    if not ents:
         return {}, None
+    ent = ents[0]
     return ({k: v["traffic_bytes"] for k, v in ent.get("kernels", {}).items()},
             "profiles/r4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected; "
             "%d channels per launch)" % nch_per_launch)
@@ -574,6 +580,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", type=int, default=2, choices=(1, 2, 3, 4, 5), help="BASELINE.json configuration (1-based index)")
+    ap.add_argument("--lockstep", type=int, default=0, help="with --config 5: 1 = config 5's GEOMETRY (5 s IR, block 4096 -> head 4096 / tail 8192) in the "
+                    "lock-step regime as the headline (the entry `config5` of the default line) instead of the literal 64-channel offline render")
     ap.add_argument("--channels", type=int, default=0, help="lock-step channels per GPU (2 per stereo instance; 0: the config's default)")
     ap.add_argument("--time-tiling", type=int, default=1, help="0: RVC_FLAG_NO_TIME_TILING (the reference's per-block sweep order)")
     ap.add_argument("--blocks-per-step", type=int, default=0, help="block-synchronous configs: host blocks per step (0: the config's default)")
@@ -631,7 +639,7 @@ def main():
     # ---- workload ----------------------------------------------------------------------------
     long_call = False
     wcfg = args.config
-    if args.config in (1, 2, 3):
+    if args.config in (1, 2, 3) or (args.config == 5 and args.lockstep):
         w = WORKLOADS[args.config]
         channels = args.channels or w["channels"]
         if channels < 2 or channels % 2:
@@ -667,7 +675,7 @@ def main():
     # The output batch of every step is gathered with ONE all_gather, overlapped with the next step's compute:
     # the collective is ordered behind this step's kernels (torch's current stream waits for the set's streams) and runs
     # on the communicator's stream; a batch buffer is reused only after its own gather has completed.
-    gch = nch if (args.gather >= 2 or args.config in (4, 5)) else min(nch, 16)      # channels per rank that are gathered
+    gch = nch if (args.gather >= 2 or args.config == 4 or long_call) else min(nch, 16)      # channels per rank that are gathered
     g_out = [torch.empty((world,) + (gch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
     g_stage = [torch.empty((gch, frames_step), dtype=torch.float32, device=dev) for _ in range(nbuf)] if do_gather else None
     pending = [None] * nbuf
@@ -725,7 +733,7 @@ def main():
         src = g_stage[lb] if gch == nch else yo[:gch]
         gather_ok = bool(torch.equal(mine, src))
     elapsed = shard.max_over_ranks(elapsed, dist, dev)    # slowest rank
-    total_ch = nch * world if args.config in (1, 2, 3) else (16 if args.config == 4 else 64)
+    total_ch = nch * world if (args.config in (1, 2, 3) or not long_call and args.config == 5) else (16 if args.config == 4 else 64)
     total_samples = total_ch * frames_step * args.steps
     value = total_samples / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
@@ -788,8 +796,8 @@ def main():
                     "this exceeds the physical traffic by the tiling's byte saving and is a throughput equivalent, not an "
                     "efficiency; the `reference_schedule` entry is the run where the two coincide."}
 
-    side, cpu, others = {}, None, {}
-    lockstep_cfg = args.config in (1, 2, 3)
+    side, cpu, others, otsrc = {}, None, {}, None
+    lockstep_cfg = args.config in (1, 2, 3) or (args.config == 5 and not long_call)
     irs, x = ls.irs, ls.x
     init_ms, synth_s, subsets = ls.init_ms, ls.synth_s, conv.subsets
     tiles = {"zero-latency stage": conv.tile_rows(0), "tail stage": conv.tile_rows(1)}
@@ -822,7 +830,7 @@ def main():
             oq.conv.check()
             okern = oq.kernel_times(KERNEL_NAMES)
             oexe = executed_bytes(oq.conv, nch, head, tail, ir_len, host_block, oq.tiled)
-            otraffic, _ = load_traffic(nch, args.config, oq.tiled)
+            otraffic, otsrc = load_traffic(nch, args.config, oq.tiled)
             oroof, _ = roofline_tables(okern, oexe, otraffic)
             oq.close()
             side["one_queue"] = {
@@ -876,15 +884,28 @@ def main():
         summary["one_queue_Msamples_s"] = side["one_queue"]["value"]
         oq = side["one_queue"]["roofline_all"].get(roof["kernel"]) if roof else None
         if oq:
-            roof["one_queue_frac"] = oq["frac"]
-            roof["one_queue_avg_launch_ms"] = oq["avg_launch_ms"]
-            roof["one_queue_bytes_per_launch"] = oq["bytes_per_launch"]
-            roof["one_queue_traffic"] = oq["traffic"]
+            # The headline `value` is the DEFAULT run, whose child sets run two launches of a family (and of other families) side
+            # by side: there a launch's duration depends on what else is running, and bytes per launch / mean launch duration is not an
+            # efficiency. The contract's per-launch roofline of the dominant kernel therefore comes from the `one_queue` leg of
+            # this same run (RVC_FLAG_NO_SUBSETS: every launch has the device to itself; its rocprofv3 average:
+            # profiles/r4_config2/kernel_stats_one_queue.csv); the default run's own figures stay beside it as default_run_*
+            # (bytes over the UNION of the family's launch intervals; rocprofv3 side: profiles/r4_config2/kernel_union.txt).
+            for k in ("achieved", "frac", "traffic", "bytes_per_launch", "avg_launch_ms", "concurrency", "frac_per_launch",
+                      "busy_ms_per_step", "traffic_source"):
+                roof["default_run_" + k] = roof[k]
+            roof.update({"achieved": round(oq["bytes_per_launch"] / (oq["avg_launch_ms"] * 1e-3) / 1e9, 1), "frac": oq["frac"],
+                         "traffic": oq["traffic"], "bytes_per_launch": oq["bytes_per_launch"], "avg_launch_ms": oq["avg_launch_ms"],
+                         "concurrency": 1.0, "frac_per_launch": oq["frac"],
+                         "busy_ms_per_step": round(oq["avg_launch_ms"] * oq["launches_per_step"], 5),
+                         "traffic_source": otsrc, "measured_in": "one_queue leg of this run (RVC_FLAG_NO_SUBSETS, same channels / inputs / "
+                                                                 "call pattern); value / ms_per_step: the default run (child sets)"})
     if roof is not None:
         roof["probe_ok"] = bool(probe and probe["ok"])
         roof["frac_whole_step_executed_bytes"] = path["frac_of_hbm_peak"]
         if roof.get("traffic") and roof.get("bytes_per_launch"):
             roof["traffic_over_model"] = round(roof["traffic"] / roof["bytes_per_launch"], 4)
+        if roof.get("default_run_traffic") and roof.get("default_run_bytes_per_launch"):
+            roof["default_run_traffic_over_model"] = round(roof["default_run_traffic"] / roof["default_run_bytes_per_launch"], 4)
 
     line = {
         "metric": "Msamples/s convolved (stereo, 10s IR, block=512); % HBM roofline",

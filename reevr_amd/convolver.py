@@ -293,6 +293,34 @@ def set_tuning(key: str, value: int) -> bool:
     return bool(L.lib().rvc_debug_set_tuning(key.encode(), int(value)))
 
 
+# the engine's defaults of the process-wide knobs (rvc_debug_set_tuning): what `tuning` restores on exit
+TUNING_DEFAULTS = {"k1": 0, "two_level_min_p": -1, "fft_loop": -1, "subsets": -1, "guard": 0, "kid_fence": 1, "sweep_split": -1,
+                   "sweep_lw": 0, "sweep_d": 0, "sweep_lds": -1, "patch_nt": 1, "block_occ": 0, "tile_rot": 1}
+
+
+class tuning:
+    """`with reevr_amd.tuning(sweep_lds=0, k1=32): ...` -- set process-wide schedule knobs for the sets initialised inside the
+    block and put the engine's defaults back on the way out, also when the block raises (a test that fails between a
+    set_tuning and its reset would otherwise leak the knob into every later set of the process)."""
+
+    def __init__(self, **knobs):
+        unknown = [k for k in knobs if k not in TUNING_DEFAULTS]
+        if unknown:
+            raise KeyError(f"unknown tuning knob(s) {unknown}")
+        self.knobs = knobs
+
+    def __enter__(self):
+        for k, v in self.knobs.items():
+            if not set_tuning(k, v):
+                raise KeyError(k)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.knobs:
+            set_tuning(k, TUNING_DEFAULTS[k])
+        return False
+
+
 class _Mono:
     """One mono convolver: the reference's per-object surface on a 1-channel set."""
 

@@ -86,6 +86,21 @@ def test_removed_persistent_flag_is_refused_not_ignored(lib):
         lib.rvc_set_destroy(h)
 
 
+def test_tuning_knobs_and_context_manager(lib):
+    """Every knob reevr_amd.tuning can restore is known to the library (rvc_debug_set_tuning returns 1), unknown ones are
+    refused on both sides, and the context manager puts the defaults back when its block raises."""
+    import reevr_amd
+    from reevr_amd.convolver import TUNING_DEFAULTS
+    for k, v in TUNING_DEFAULTS.items():
+        assert reevr_amd.set_tuning(k, v), k
+    assert not reevr_amd.set_tuning("no_such_knob", 1)
+    with pytest.raises(KeyError):
+        reevr_amd.tuning(no_such_knob=1)
+    with pytest.raises(RuntimeError):
+        with reevr_amd.tuning(subsets=4, sweep_lds=0):
+            raise RuntimeError("boom")
+
+
 def test_cpp_shim_headers_compile():
     """The C++ drop-in classes (include/reevr_amd/Convolver.h, StereoConvolver.h) compile and
     link against the C ABI with plain g++ (no HIP headers needed on the host side)."""

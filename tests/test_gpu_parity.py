@@ -1250,14 +1250,8 @@ def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant)
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
     tune = {"split": 1, "own": 0, "own_early": 0, "second": 0}.get(variant)
     lds = 2 if variant.startswith("lds32_4x8") else (3 if variant.startswith("lds16") else (0 if variant == "one_wave32" else (1 if variant.endswith("deep") else -1)))
-    if tune is not None:
-        reevr_amd.set_tuning("sweep_split", tune)
-    reevr_amd.set_tuning("sweep_lds", lds)
-    try:
+    with reevr_amd.tuning(sweep_lds=lds, **({"sweep_split": tune} if tune is not None else {})):
         ok = L.lib().rvc_debug_fdl(0, kind, nch, B, P, M, delay, k0, rows, fp(H), fp(X), fp(A), fp(got), x_hi, x_from)
-    finally:
-        reevr_amd.set_tuning("sweep_split", -1)
-        reevr_amd.set_tuning("sweep_lds", -1)
     assert ok == 1
     if kind == 1:                                   # output row j sits in slot (k0 + j) & (M - 1)
         got = np.stack([got[:, (k0 + j) & (M - 1)] for j in range(M)], axis=1)

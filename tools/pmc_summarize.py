@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--k1-tail", type=int, default=16, help="(recorded only)")
     ap.add_argument("--subsets", type=int, default=1, help="child sets (bench.py --child-sets 1): every launch covers channels / subsets")
     ap.add_argument("--patch0-family", default="premultiply", help="family of k_fdl_patch<0,..>: premultiply, or fir_head (general per-block path)")
+    ap.add_argument("--key", default="", help="key of the entry in the output (default config<C>)")
     ap.add_argument("--command", default="python bench.py --steps 3 --warmup 1 --cpu-seconds 0 --side 0")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
@@ -118,7 +119,7 @@ def main():
         w = fw * wr.get(k, (0.0, 0))[0] * 1024.0
         out["kernels"][k] = {"fetch_bytes": f, "write_bytes": w, "traffic_bytes": f + w,
                              "dispatches_seen": max(fe.get(k, (0, 0))[1], wr.get(k, (0, 0))[1])}
-    json.dump({"config%d" % a.config: out}, open(a.out, "w"), indent=1)
+    json.dump({a.key or "config%d" % a.config: out}, open(a.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -40,8 +40,10 @@ for C in $CONFIGS; do
     3) GEO="--channels 2048 --subsets 2 --head-log 8 --tail-log 13 --k1-head 16 --k1-tail 32" ;;
     5) GEO="--channels 4096 --subsets 2 --head-log 12 --tail-log 13 --k1-head 0 --k1-tail 16 --patch0-family fir_head" ;;
   esac
-  ARGS="--config $C --steps 3 --warmup 1 --cpu-seconds 0 --side 0 --distinct 64"
-  KT_ARGS="--config $C --steps 20 --warmup 5 --cpu-seconds 0 --side 0 --distinct 64"
+  LS=""; [ "$C" = "5" ] && LS="--lockstep 1"     # (config 5's geometry in the lock-step regime: the entry `config5` of the default line)
+  [ "$C" = "3" ] && STEPS=4 || STEPS=3          # (config 3: whole first-level tiles of the tail stage = 4 steps)
+  ARGS="--config $C $LS --steps $STEPS --warmup 1 --cpu-seconds 0 --side 0 --distinct 64"
+  KT_ARGS="--config $C $LS --steps 20 --warmup 5 --cpu-seconds 0 --side 0 --distinct 64"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$D/kt" -o kt -- python "$ROOT/bench.py" $KT_ARGS > "$D/bench_under_rocprof.json" 2> "$D/kt.err"
   find "$D/kt" -name '*kernel_stats.csv' -exec cp {} "$D/kernel_stats.csv" \;
   find "$D/kt" -name '*kernel_trace.csv' -exec python "$ROOT/tools/trace_union.py" {} \; > "$D/kernel_union.txt" 2>&1
@@ -54,6 +56,18 @@ for C in $CONFIGS; do
   python "$ROOT/tools/pmc_summarize.py" "$D/FETCH_SIZE.csv" "$D/WRITE_SIZE.csv" --calib-fetch "$OUT/calib_FETCH_SIZE.csv" \
     --calib-write "$OUT/calib_WRITE_SIZE.csv" --command "python bench.py $ARGS" --config $C $GEO -o "$D/traffic.json" > "$D/traffic.txt" 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do compact "$D/$c.csv" "$D/${c}_per_kernel.csv"; rm -f "$D/$c.csv"; done
+  # the same two counter passes with the set on ONE queue (--child-sets 0: every launch covers all the channels): the traffic
+  # behind the `one_queue` entries of the bench line
+  GEO1=$(echo "$GEO" | sed 's/--subsets [0-9]*/--subsets 1/')
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d "$D/pmc1_$c" -o pmc -- python "$ROOT/bench.py" $ARGS --child-sets 0 > /dev/null 2> "$D/pmc1_$c.err"
+    find "$D/pmc1_$c" -name '*counter_collection.csv' -exec cp {} "$D/one_queue_$c.csv" \;
+    rm -rf "$D/pmc1_$c"
+  done
+  python "$ROOT/tools/pmc_summarize.py" "$D/one_queue_FETCH_SIZE.csv" "$D/one_queue_WRITE_SIZE.csv" --calib-fetch "$OUT/calib_FETCH_SIZE.csv" \
+    --calib-write "$OUT/calib_WRITE_SIZE.csv" --command "python bench.py $ARGS --child-sets 0" --config $C $GEO1 --key "config${C}_one_queue" \
+    -o "$D/traffic_one_queue.json" > "$D/traffic_one_queue.txt" 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do compact "$D/one_queue_$c.csv" "$D/one_queue_${c}_per_kernel.csv"; rm -f "$D/one_queue_$c.csv"; done
 done
 rm -f "$OUT"/calib_FETCH_SIZE.csv "$OUT"/calib_WRITE_SIZE.csv
 python - "$OUT" $CONFIGS <<'PY'
@@ -61,9 +75,10 @@ import json, os, sys
 out, cfgs = sys.argv[1], sys.argv[2:]
 merged = {}
 for c in cfgs:
-    p = os.path.join(out, "config" + c, "traffic.json")
-    if os.path.exists(p):
-        merged.update(json.load(open(p)))
+    for name in ("traffic.json", "traffic_one_queue.json"):
+        p = os.path.join(out, "config" + c, name)
+        if os.path.exists(p):
+            merged.update(json.load(open(p)))
 json.dump(merged, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print({k: v["channels_per_launch"] for k, v in merged.items()})
 PY
