@@ -89,8 +89,9 @@ enum {
 #define RVC_FLAG_CHILD_SETS 1024u /* (accepted, no effect: the default since round 4) sets of >= 2048 block-synchronous channels are
                                    served by child sets of ~2048 channels each on their own streams (rvc_set_subsets; two, four
                                    from 8192 channels on). The latency-bound ends of one child's launches run under the
-                                   bandwidth-bound middle of another's: +4-5 % (MI355X, BASELINE config 2). Bit-identical
-                                   results. The device-pointer calls fence the children against the set's own stream
+                                   bandwidth-bound middle of another's: +5-7 % (MI355X, BASELINE config 2). Same samples (bit
+                                   for bit when every child's delay lines have the set's partition counts, else to the last
+                                   bit or two: the partition-split sweeps associate differently). The device-pointer calls fence the children against the set's own stream
                                    (rvc_set_stream(s, 0)) on the way in and out: the caller orders against ONE stream as ever. */
 #define RVC_FLAG_NO_SUBSETS 512u  /* never child sets: one set, one foreground queue (per-launch profiling, A/B runs) */
 #define RVC_FLAG_FORCE_TWO_LEVEL 128u  /* testing: the same with two-level tiles whatever the partition count */

@@ -658,6 +658,87 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
                                   f"tiling {tiling} clear@{start}: rel rms {err / ref:.3e}")
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_fuzz_child_sets_call_patterns(seed):
+    """The same call patterns with the set served by TWO CHILD SETS (forced: the default only does that from 2048 channels on):
+    per-block calls through host pointers and through the device entry (per call and as the C block loop, torch's stream as
+    producer and consumer, nothing synchronised on the host), ragged and multi-block calls, a block-aligned clear() -- every
+    output sample of every channel against the oracle and against the same set without children."""
+    import torch
+    rng = np.random.RandomState(9100 + seed)
+    head = int(rng.choice([64, 128, 256]))
+    tail = int(rng.choice([2 * head, 4 * head, 16 * head]))
+    nch = int(rng.choice([4, 6, 8]))
+    n_tail_parts = int(rng.choice([1, 3, 9, 20]))
+    base = 2 * tail + n_tail_parts * tail - int(rng.randint(0, tail // 2))
+    irs = [synth.synth_ir(max(1, base - c * int(rng.randint(0, tail))), 1, 600 + 3 * seed + c)[0] for c in range(nch)]
+    total = int(min(max(40 * tail, 30 * 8 * head), 200000))
+    total -= total % head
+    sched, done = [], 0
+    while done < total:
+        r = rng.randint(0, 30)
+        if r == 0:
+            n, how = int(rng.randint(1, head)), "host"                        # ragged ...
+        elif r == 1 and done % head:
+            n, how = head - done % head, "host"                                # ... and back to the grid
+        elif r == 2:
+            n, how = int(rng.randint(2, 5)) * head, "device"                   # a multi-block call
+        elif r == 3 and done % head == 0:
+            n, how = int(rng.randint(3, 12)) * head, "loop"                    # the C block loop over several blocks
+        else:
+            n = head if done % head == 0 else head - done % head
+            how = "device" if rng.randint(0, 2) else "host"
+        n = max(1, min(n, total - done))
+        sched.append((n, how))
+        done += n
+    bg = bool(rng.randint(0, 2))
+    tiling = ["force", "force2", True][seed % 3]
+    x = np.stack([synth.synth_input(total, 13 * seed + c) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    clear_at = int(rng.randint(len(sched) // 4, len(sched))) if rng.randint(0, 2) == 0 else -1
+    outs, start = [], 0
+    for kids in (2, 1):
+        with reevr_amd.tuning(subsets=kids):
+            s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling=tiling)
+            assert s.init(head, tail, irs, max_len=max(n for n, _ in sched)), s.last_error_string
+        assert s.subsets == kids
+        got = torch.zeros_like(dx)
+        pos = start = 0
+        for i, (n, how) in enumerate(sched):
+            if i >= clear_at >= 0 and pos % head == 0 and start == 0:
+                s.sync()
+                s.clear()
+                start = pos
+            if how == "host":
+                torch.cuda.synchronize()
+                got[:, pos:pos + n] = torch.from_numpy(s.process(x[:, pos:pos + n])).cuda()
+            elif how == "loop":
+                s.process_device_blocks(dx[:, pos:pos + n], head, got[:, pos:pos + n], sync=False)
+            else:
+                s.process_device(dx[:, pos:pos + n], got[:, pos:pos + n], sync=False)
+            pos += n
+        s.sync()
+        torch.cuda.synchronize()
+        assert s.last_error == 0, s.last_error_string
+        outs.append(got.cpu().numpy())
+        s.close()
+    # (Same samples up to the last bit or two: a child whose channels all carry shorter impulses than the set's longest has
+    #  fewer partitions in its delay lines, and the partition-split sweeps then associate their partial sums differently --
+    #  bit identity for equal partition counts is test_child_sets_match_single_set's claim.)
+    for c in range(nch):
+        assert rel_rms(outs[0][c], outs[1][c]) <= 1e-6, f"seed {seed}: child sets differ from the single set, channel {c}"
+    for c in range(nch):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        want = np.empty(total, np.float32)
+        want[:start] = o.process(x[c, :start]) if start else want[:0]
+        if start:
+            o.clear()
+        want[start:] = o.process(x[c, start:])
+        assert rel_rms(outs[0][c], want) <= TOL, (f"seed {seed}: head {head} tail {tail} nch {nch} bg {bg} tiling {tiling} "
+                                                  f"clear@{start}: {rel_rms(outs[0][c], want):.3e}")
+
+
 def test_time_tiling_many_channels_device_blocks():
     """64 lock-step channels (the size at which the zero-latency stage tiles by default), block-synchronous through the
     device entry, tiling on vs off vs the oracle on three channels."""
