@@ -4,7 +4,7 @@
 // src/PluginProcessor.cpp:1793-1797) turned into one batched call. Inputs and outputs stay on the device.
 //   hipcc -O2 -std=c++17 -I include examples/lockstep_instances.cpp -L reevr_amd/csrc -lreevr_amd \
 //         -Wl,-rpath,$PWD/reevr_amd/csrc -o lockstep_instances
-//   ./lockstep_instances [stereo instances = 256] [blocks = 512]
+//   ./lockstep_instances [stereo instances = 256] [blocks = 512] [flags = 0, e.g. 512 = RVC_FLAG_NO_SUBSETS] [1 = the whole loop as ONE rvc_set_process_device_blocks call]
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -22,6 +22,8 @@ static float noise(unsigned &s) {   // xorshift32 -> [-1, 1)
 
 int main(int argc, char **argv) {
   const int instances = argc > 1 ? std::atoi(argv[1]) : 256, blocks = argc > 2 ? std::atoi(argv[2]) : 512;
+  const unsigned flags = argc > 3 ? (unsigned)std::atoi(argv[3]) : 0u;
+  const bool one_call = argc > 4 && std::atoi(argv[4]) != 0;
   const int channels = 2 * instances, block = 512, sr = 48000, ir_len = 10 * sr;
   if (rvc_device_count() < 1) { std::puts("no GPU: this engine has no CPU fallback"); return 2; }
 
@@ -38,14 +40,14 @@ int main(int argc, char **argv) {
     ir_ptr[c] = irs[c].data();
   }
 
-  rvc_set *set = rvc_set_create(channels, /*device=*/0, /*flags=*/0);
+  rvc_set *set = rvc_set_create(channels, /*device=*/0, flags);
   const size_t tail = 8192;                                            // max(8192, 2 * head): StereoConvolver.cpp:11-15
   if (!rvc_set_init(set, block, tail, ir_ptr.data(), ir_lens.data(), /*max_len=*/block)) {
     std::printf("init failed: %s\n", rvc_last_error_string(set));
     return 1;
   }
-  std::printf("%d stereo instances = %d channels, head %zu x %d + tail %zu x %d partitions\n", instances, channels,
-              rvc_set_head_block(set), rvc_set_partitions(set, 0), rvc_set_tail_block(set), rvc_set_partitions(set, 1));
+  std::printf("%d stereo instances = %d channels, head %zu x %d + tail %zu x %d partitions, %d child set(s)\n", instances, channels,
+              rvc_set_head_block(set), rvc_set_partitions(set, 0), rvc_set_tail_block(set), rvc_set_partitions(set, 1), rvc_set_subsets(set));
 
   // device-resident audio: [channel][frames]
   const size_t frames = (size_t)block * blocks;
@@ -57,8 +59,17 @@ int main(int argc, char **argv) {
 
   // the block loop: one call per host block for ALL instances; asynchronous on the set's stream
   const auto t0 = std::chrono::steady_clock::now();
-  for (int b = 0; b < blocks; ++b)
-    rvc_set_process_device(set, d_in + (size_t)b * block, frames, d_out + (size_t)b * block, frames, block);
+  // (a set of thousands of channels is served by child sets on their own streams: every device-pointer call fences them against
+  //  the set's one stream -- per call here, once around the whole loop with rvc_set_process_device_blocks)
+  if (one_call) rvc_set_process_device_blocks(set, d_in, frames, d_out, frames, frames, block);
+  else {
+    // RVC_FLAG_CHILD_SETS (1024): the calls do not fence -- ONE fork in front of the run of calls and ONE join behind it
+    // (no-ops without the flag's unfenced children: the default forks and joins inside every call)
+    rvc_set_fork(set);
+    for (int b = 0; b < blocks; ++b)
+      rvc_set_process_device(set, d_in + (size_t)b * block, frames, d_out + (size_t)b * block, frames, block);
+    rvc_set_join(set);
+  }
   rvc_set_sync(set);
   const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rvc_last_error(set) != RVC_OK) { std::printf("error: %s\n", rvc_last_error_string(set)); return 1; }

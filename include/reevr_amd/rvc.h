@@ -86,13 +86,20 @@ enum {
                                    RVC_ERR_UNSUPPORTED and every init on it fails -- never silently ignored. */
 #define RVC_FLAG_FORCE_TIME_TILING 32u /* testing: time-tile every stage that has partitions to tile, however small
                                    (by default only stages whose per-block sweep is long enough to be bandwidth-bound) */
-#define RVC_FLAG_CHILD_SETS 1024u /* (accepted, no effect: the default since round 4) sets of >= 2048 block-synchronous channels are
+#define RVC_FLAG_CHILD_SETS 1024u /* Child sets UNFENCED. Background: sets of >= 2048 block-synchronous channels are by DEFAULT
                                    served by child sets of ~2048 channels each on their own streams (rvc_set_subsets; two, four
                                    from 8192 channels on). The latency-bound ends of one child's launches run under the
                                    bandwidth-bound middle of another's: +5-7 % (MI355X, BASELINE config 2). Same samples (bit
                                    for bit when every child's delay lines have the set's partition counts, else to the last
-                                   bit or two: the partition-split sweeps associate differently). The device-pointer calls fence the children against the set's own stream
-                                   (rvc_set_stream(s, 0)) on the way in and out: the caller orders against ONE stream as ever. */
+                                   bit or two: the partition-split sweeps associate differently). By default the device-pointer
+                                   calls fence the children against the set's own stream (rvc_set_stream(s, 0)) on the way in
+                                   and out: the caller orders against ONE stream as ever. rvc_set_process_device_blocks fences
+                                   once around its whole loop (the full gain); a caller making ONE device-pointer call per block
+                                   pays the fence -- a barrier between the children -- per block and is better off on one queue
+                                   (RVC_FLAG_NO_SUBSETS: 15.5 against 13.9 Gsamples/s at 4096 channels) or WITH THIS FLAG: no
+                                   fences inside the calls (16.2 per call too): the caller brackets any run of device-pointer
+                                   calls between which it touches neither buffer with rvc_set_fork / rvc_set_join (or orders its
+                                   own work against EVERY child's foreground stream, rvc_set_stream(s, 2 + 2 k)). */
 #define RVC_FLAG_NO_SUBSETS 512u  /* never child sets: one set, one foreground queue (per-launch profiling, A/B runs) */
 #define RVC_FLAG_FORCE_TWO_LEVEL 128u  /* testing: the same with two-level tiles whatever the partition count */
 
@@ -189,6 +196,13 @@ int rvc_set_tile_rows(const rvc_set *s, int stage);
  * streams of their own (which = 2 + 2 k and 3 + 2 k for child k, NULL beyond the last: diagnostics); every device-pointer call
  * makes the children wait for what was ordered before stream 0 and stream 0 wait for the children's work of the call. */
 void *rvc_set_stream(rvc_set *s, int which);
+/* Sets created with RVC_FLAG_CHILD_SETS (child sets without fences inside the device-pointer calls): rvc_set_fork makes every
+ * child's stream wait for what has been ordered before the set's stream (rvc_set_stream(s, 0)) -- call it once the producer of the
+ * input buffers is ordered there, before the first of a run of calls --, rvc_set_join makes that stream wait for every child's
+ * work so far -- call it behind the last call of the run, before anything consumes the outputs there. Two event operations per
+ * further child each. No-ops for sets without children; sets without the flag fork and join inside every call anyway. */
+void rvc_set_fork(rvc_set *s);
+void rvc_set_join(rvc_set *s);
 /* number of child sets (1: the set runs on its own two streams; n > 1: channels [k n_channels/n, (k+1) n_channels/n) are child
  * k's). Chosen at init for sets of thousands of lock-step block-synchronous channels (RVC_FLAG_NO_SUBSETS: never): the
  * latency-bound ends of one child's per-block launch overlap the bandwidth-bound middle of another's. */

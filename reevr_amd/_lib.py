@@ -50,6 +50,8 @@ SIGNATURES = {
     "rvc_set_max_len": (C.c_size_t, [C.c_void_p]),
     "rvc_set_partitions": (C.c_int, [C.c_void_p, C.c_int]),
     "rvc_set_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "rvc_set_fork": (None, [C.c_void_p]),
+    "rvc_set_join": (None, [C.c_void_p]),
     "rvc_set_subsets": (C.c_int, [C.c_void_p]),
     "rvc_set_tile_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "rvc_last_error": (C.c_int, [C.c_void_p]),

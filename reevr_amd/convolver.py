@@ -38,7 +38,8 @@ class ConvolverSet:
         """time_tiling: True (by size) / False / "force" (every stage, one level unless long) / "force2" (two levels).
         fft_f64 / fft_f32: every transform in double / in float (default: rvc.h, RVC_FLAG_FFT_F64).
         child_sets: None / True = the engine's default (sets of thousands of block-synchronous channels are served by child sets on
-        their own streams, fenced internally), False = RVC_FLAG_NO_SUBSETS (one set on one queue: per-launch profiling)."""
+        their own streams, fenced internally), False = RVC_FLAG_NO_SUBSETS (one set on one queue: per-launch profiling),
+        "unfenced" = RVC_FLAG_CHILD_SETS (no fences inside the calls: rvc_set_fork / rvc_set_join around each ordered call here)."""
         self._lib = L.lib()
         flags = ((L.RVC_FLAG_BG_STREAM if bg_stream else 0) | (L.RVC_FLAG_TIMING if timing else 0)
                  | (L.RVC_FLAG_FFT_F64 if fft_f64 else 0) | (L.RVC_FLAG_FFT_F32 if fft_f32 else 0)
@@ -46,7 +47,8 @@ class ConvolverSet:
                  | (0 if time_tiling else L.RVC_FLAG_NO_TIME_TILING)
                  | (L.RVC_FLAG_FORCE_TIME_TILING if time_tiling == "force" else 0)
                  | (L.RVC_FLAG_FORCE_TWO_LEVEL if time_tiling == "force2" else 0)
-                 | (L.RVC_FLAG_NO_SUBSETS if child_sets is False else 0))
+                 | (L.RVC_FLAG_NO_SUBSETS if child_sets is False else 0) | (L.RVC_FLAG_CHILD_SETS if child_sets == "unfenced" else 0))
+        self.unfenced = child_sets == "unfenced"
         self.n_channels = int(n_channels)
         self.device = int(device)
         self._h = self._lib.rvc_set_create(self.n_channels, self.device, flags)
@@ -153,11 +155,15 @@ class ConvolverSet:
         cur = torch.cuda.current_stream(self.device)
         for e in self._ext:
             e.wait_stream(cur)
+        if self.unfenced:         # RVC_FLAG_CHILD_SETS: no fences inside the calls -- fork here, join in _order_torch_after
+            self._lib.rvc_set_fork(self._h)
         return self._ext
 
     def _order_torch_after(self, ext):
         import torch
         if ext is not None:
+            if self.unfenced:
+                self._lib.rvc_set_join(self._h)
             cur = torch.cuda.current_stream(self.device)
             for e in ext:
                 cur.wait_stream(e)

@@ -1017,21 +1017,21 @@ def test_child_sets_flag():
     x = np.stack([synth.synth_input(head * nblk, 70 + c % 11) for c in range(nch)])
     dx = torch.from_numpy(x).cuda()
     outs = []
-    for flag, want in ((False, 1), (None, 2)):
+    for flag, want in ((False, 1), (None, 2), ("unfenced", 2)):     # one queue / the default (fenced) / RVC_FLAG_CHILD_SETS
         s = reevr_amd.ConvolverSet(nch, child_sets=flag)
         assert s.init_uniform(head, irs, max_len=head), s.last_error_string
         assert s.subsets == want
         outs.append(s.process_device_blocks(dx, head).cpu().numpy())
         assert s.last_error == 0, s.last_error_string
         s.close()
-    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     # The caller orders against ONE stream (rvc_set_stream(s, 0)) although the children run on their own: the producer of d_in
     # and the consumer of d_out live on torch's current stream, nothing synchronises on the host in between (sync=False), the
     # input buffer is overwritten right behind the call -- per-block calls (a fence per call) and the C block loop (one fence).
-    s = reevr_amd.ConvolverSet(nch)
-    assert s.init_uniform(head, irs, max_len=head) and s.subsets == 2
-    for form in ("calls", "loop"):
-        s.clear()
+    # (with RVC_FLAG_CHILD_SETS -- no fences inside -- the Python mirror orders against every child's stream instead)
+    for mode, form in ((None, "calls"), (None, "loop"), ("unfenced", "calls"), ("unfenced", "loop")):
+        s = reevr_amd.ConvolverSet(nch, child_sets=mode)
+        assert s.init_uniform(head, irs, max_len=head) and s.subsets == 2
         buf = torch.empty_like(dx)
         acc = torch.zeros_like(dx)
         big = torch.empty((64, 1 << 20), device="cuda")
@@ -1046,8 +1046,8 @@ def test_child_sets_flag():
         acc += y                                            # consumer of d_out, on torch's stream
         buf.fill_(float("nan"))                             # the input is dead the moment the call's work is ordered
         torch.cuda.synchronize()
-        assert np.array_equal(acc.cpu().numpy(), outs[0]), form
-    s.close()
+        assert np.array_equal(acc.cpu().numpy(), outs[0]), (mode, form)
+        s.close()
     for c in (0, 1023, 1024, 2047):
         o = O.FFTConvolver("orc")
         assert o.init(head, irs[c])
