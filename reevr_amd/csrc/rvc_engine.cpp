@@ -2037,6 +2037,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   else if (k == "sweep_lds") rvc::set_sweep_lds_tuning(value);
   else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
   else if (k == "subsets") g_tune.subsets = value;
+  else if (k == "fft_many") rvc::set_fft_many_tuning(value);
   else if (k == "kid_fence") g_tune.kid_fence = value;
   else if (k == "patch_nt") rvc::set_patch_nt_tuning(value);
   else if (k == "block_occ") rvc::set_block_occ3_tuning(value);

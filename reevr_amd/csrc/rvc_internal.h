@@ -160,6 +160,7 @@ void get_launch_events(hipEvent_t *a, hipEvent_t *b);   // (for launchers in oth
 hipError_t prepare_kernels();
 // measurement hook (rvc_debug_set_tuning "fft_loop"): -1 row-looping 8192-bin transforms by size, 0 never, 1 whenever legal
 void set_fft_loop_tuning(int mode);
+void set_fft_many_tuning(int mode);   // "fft_many": -1 auto / 0 never / 1 always the many-rows form of the 4096-bin transforms (twiddles per pass, 4 workgroups per CU)
 void set_tile_rot_tuning(int on);    // "tile_rot": sweeps / patches on long rows take channel c's bin tiles in the order rotated by c (XCD spread)
 int tile_rot_tuning();
 void set_block_occ3_tuning(int on);  // "block_occ": 4 = the lean 4-waves-per-SIMD per-block kernel for many-channel launches (measurement)

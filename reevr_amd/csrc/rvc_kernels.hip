@@ -586,10 +586,15 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const TW &T, con
   }
 }
 
-template <int LOGB, typename R>
-__global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
+// MANY (launches of thousands of rows of a 4096-bin transform: the head stage of many lock-step channels, BASELINE config 5's
+// geometry): the twiddles are fetched per pass, one pass ahead, instead of being held in registers from the top of the kernel
+// -- the latency form's choice, right for a handful of rows --: <= 64 instead of 83 / 92 registers, FOUR workgroups per CU
+// instead of two, and a launch of thousands of rows is a matter of how many rows a CU overlaps.
+template <int LOGB, typename R, bool MANY = false>
+__global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_fwd(const FwdArgs a) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
+  typedef Tw8<LOGB, R, false, false, false, MANY> TW;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int B = P::B;
   const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;   // sub-transform of this workgroup
@@ -616,7 +621,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
   const C *tw8 = reinterpret_cast<const C *>(a.tw8);
   const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
 
-  Tw8<LOGB, R> T;
+  TW T;
   T.load(tw8, tw, tid);
   C v[P::E];
   // z[m] = x[2m] + i x[2m+1], m = in_idx(e). Fast path: the whole 2B segment is valid input
@@ -718,7 +723,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
       if (P::out_is_low(e)) ws[q++] = wsplit[(unsigned)P::out_idx(tid, e)];
   };
   load_ws();   // requested before the transform: the latency hides behind it
-  fft8_core<LOGB, false, R>(v, lds, T, tid);
+  fft8_core<LOGB, false, R, false, TW>(v, lds, T, tid);
 
   constexpr bool kLin = P::kLin;
   const int lt = lpad(tid), ln = lpad_neg(tid);
@@ -784,10 +789,11 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_fwd(const FwdArgs a) {
 
 // ADD: the launch has a stream to add (InvArgs::add); without one the kernel carries no registers for its prefetch (the
 // 8192-bin tail inverse of many channels: 54 instead of 64 registers)
-template <int LOGB, typename R, bool ADD = true>
-__global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
+template <int LOGB, typename R, bool ADD = true, bool MANY = false>
+__global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_inv(const InvArgs a) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
+  typedef Tw8<LOGB, R, false, false, false, MANY> TW;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int B = P::B;
   const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;
@@ -807,7 +813,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
   // thread's indices are "low" (k < B/2). For each low k it loads Y[k], Y[B-k] and one twiddle and
   // forms BOTH Z[k] = E + iO (kept) and Z[B-k] = conj(E) + i conj(O) (handed to its owner through
   // LDS). One exchange instead of loading every Y twice and every twiddle once per bin.
-  Tw8<LOGB, R> T;
+  TW T;
   T.load(tw8, tw, tid);
   C v[P::E];
   const R sc = (R)0.5 / (R)B;
@@ -885,7 +891,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv(const InvArgs a) {
     for (int e = 0; e < P::E; ++e)
       if (!P::out_is_low(e)) addv[q++] = ab[(unsigned)P::out_idx(tid, e)];
   }
-  fft8_core<LOGB, true, R>(v, lds, T, tid);
+  fft8_core<LOGB, true, R, false, TW>(v, lds, T, tid);
 
   if (!live) return;                                        // (after the last barrier)
   if (flat) {
@@ -1985,6 +1991,10 @@ __global__ void __launch_bounds__(256) k_ingest(const IngestArgs a) {
 // ----------------------------------------------------------------------------------------
 // launchers
 // ----------------------------------------------------------------------------------------
+static int g_fft_many = -1;                      // "fft_many": -1 = the MANY form of the 4096-bin transforms from 2048 rows on, 0 = never, 1 = always
+void set_fft_many_tuning(int mode) { g_fft_many = mode; }
+static bool fft_many_rows(long long items) { return g_fft_many > 0 || (g_fft_many < 0 && items >= 2048); }
+
 template <int LOGB, typename R>
 static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStream_t st) {
   if constexpr (LOGB >= 6) {
@@ -1992,6 +2002,12 @@ static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStre
     const size_t lds = sizeof(cx<R>) * P::LDS_ELEMS * P::TPW;
     FwdArgs b = a;
     b.rows = rows;
+    if constexpr (LOGB == 12 && sizeof(R) == 4) {
+      if (fft_many_rows((long long)rows * channels)) {
+        RVC_LAUNCH((k_fft8_fwd<LOGB, R, true>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
+        return hipGetLastError();
+      }
+    }
     RVC_LAUNCH((k_fft8_fwd<LOGB, R>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
   } else {
     const size_t lds = sizeof(cx<R>) << LOGB;
@@ -2006,6 +2022,13 @@ static hipError_t launch_inv_t(const InvArgs &a, int rows, int channels, hipStre
     const size_t lds = sizeof(cx<R>) * P::LDS_ELEMS * P::TPW;
     InvArgs b = a;
     b.rows = rows;
+    if constexpr (LOGB == 12 && sizeof(R) == 4) {
+      if (fft_many_rows((long long)rows * channels)) {
+        if (b.add) RVC_LAUNCH((k_fft8_inv<LOGB, R, true, true>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
+        else RVC_LAUNCH((k_fft8_inv<LOGB, R, false, true>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
+        return hipGetLastError();
+      }
+    }
     if (b.add) RVC_LAUNCH((k_fft8_inv<LOGB, R, true>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
     else RVC_LAUNCH((k_fft8_inv<LOGB, R, false>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
   } else {

@@ -1218,25 +1218,29 @@ def test_two_wave_block_kernel_small_heads(head, block):
             assert rel_rms(got[c], o.process(x[c])) <= TOL, (nch, c)
 
 
-def test_many_channels_large_head_block_general_path():
+@pytest.mark.parametrize("fft_many", [0, 1])
+def test_many_channels_large_head_block_general_path(fft_many):
     """Many lock-step channels with a LARGE head block (BASELINE config 5's geometry: head 4096 / tail 8192): per-block
     calls are served by transform / delay-line / inverse launches instead of the one-workgroup-per-channel latency kernel
-    (rvc_engine.cpp block_general); tail stage time-tiled; block calls, then a ragged pair, against the oracle."""
+    (rvc_engine.cpp block_general; the head transform reads the block from the caller's buffer and appends it to the ring,
+    the tail job runs behind it); tail stage time-tiled; block calls, then a ragged pair, against the oracle. fft_many: the
+    many-rows form of the 4096-bin transforms (twiddles per pass: launches of >= 2048 rows by default) forced on / off."""
     import torch
     nch, head, tail, nblk = 256, 4096, 8192, 40
     irs = [synth.synth_ir(2 * tail + 17 * tail - 333 * (c % 5), 1, 30 + c % 13)[0] for c in range(nch)]
     x = np.stack([synth.synth_input(head * nblk, 60 + c % 7) for c in range(nch)])
     dx = torch.from_numpy(x).cuda()
-    s = reevr_amd.ConvolverSet(nch)
-    assert s.init(head, tail, irs, max_len=head), s.last_error_string
-    assert s.tile_rows(1) == 8
-    a = s.process_device_blocks(dx[:, :head * 38].contiguous(), head)
-    b = s.process_device(dx[:, head * 38:head * 38 + 1000].contiguous())
-    c = s.process_device(dx[:, head * 38 + 1000:head * 39].contiguous())
-    d = s.process_device_blocks(dx[:, head * 39:].contiguous(), head)
-    got = torch.cat([a, b, c, d], dim=1).cpu().numpy()
-    assert s.last_error == 0, s.last_error_string
-    s.close()
+    with reevr_amd.tuning(fft_many=fft_many):
+        s = reevr_amd.ConvolverSet(nch)
+        assert s.init(head, tail, irs, max_len=head), s.last_error_string
+        assert s.tile_rows(1) == 8
+        a = s.process_device_blocks(dx[:, :head * 38].contiguous(), head)
+        b = s.process_device(dx[:, head * 38:head * 38 + 1000].contiguous())
+        c = s.process_device(dx[:, head * 38 + 1000:head * 39].contiguous())
+        d = s.process_device_blocks(dx[:, head * 39:].contiguous(), head)
+        got = torch.cat([a, b, c, d], dim=1).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        s.close()
     for ch in (0, 100, 255):
         o = O.TwoStageFFTConvolver("orc")
         assert o.init(head, tail, irs[ch])

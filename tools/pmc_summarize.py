@@ -50,7 +50,7 @@ def family(name: str, head_log: int, tail_log: int):
     m = re.search(r"k_fir(?:_lds)?<(?:\d+, )?(\d)>", name)
     if m:
         return "fir_head" if m.group(1) == "0" else "fir_tail"   # <1> tail stage, <2> whole-IR line (timed as fir_tail)
-    m = re.search(r"k_fft8?_(fwd|inv)<(\d+), float(?:, (?:true|false))?>", name)
+    m = re.search(r"k_fft8?_(fwd|inv)<(\d+), float(?:, (?:true|false))*>", name)
     if m:
         lg = int(m.group(2))
         st = "head" if lg == head_log else ("tail" if lg >= tail_log else None)
