@@ -12,7 +12,8 @@ for seed in range(first, first + count):
             (T.test_fuzz_block_synchronous_time_tiling, (seed, False)), (T.test_fuzz_block_synchronous_time_tiling, (seed, True)),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "force")), (T.test_fuzz_single_stage_sets, (seed,)),
             (T.test_fuzz_geometry_and_call_pattern, (seed, "force2")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "force2")),
-            (T.test_fuzz_block_synchronous_time_tiling, (seed, "force2_k32")), (T.test_guard_bands_stay_intact_and_outputs_finite, (seed,))]
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "force2_k32")), (T.test_guard_bands_stay_intact_and_outputs_finite, (seed,)),
+            (T.test_fuzz_child_sets_call_patterns, (seed,))]
     for fn, a in jobs:
         runs += 1
         if os.environ.get("STRESS_LOG"):
