@@ -1376,12 +1376,29 @@ void drop_kids(rvc_set *s) {
   s->kids.clear();
   s->kid_c0.clear();
 }
+// the set's streams and pre-created events (a set that gets children gives its own up: the runtime maps streams onto a few
+// hardware queues, and an idle pair would still take two of them away from the children)
+void drop_streams(rvc_set *s) {
+  if (!s->streams_ok) return;
+  hipSetDevice(s->device);
+  for (int i = 0; i < s->ev_free; ++i) hipEventDestroy(s->ev_pool[i]);
+  s->ev_free = 0;
+  hipEventDestroy(s->ev_ingest);
+  hipEventDestroy(s->ev_out);
+  hipEventDestroy(s->ev_fence);
+  if (s->st_bg != s->st_main) hipStreamDestroy(s->st_bg);
+  hipStreamDestroy(s->st_main);
+  s->st_main = s->st_bg = nullptr;
+  s->ev_ingest = s->ev_out = s->ev_fence = nullptr;
+  s->streams_ok = false;
+}
 // (re)build the children for this init; false: the set stays childless
 bool make_kids(rvc_set *s, int n) {
   if (n <= 1) { drop_kids(s); return false; }
   if ((int)s->kids.size() == n) return true;
   drop_kids(s);
   if (s->streams_ok || s->live) free_device_state(s);
+  drop_streams(s);
   const int per = s->nch / n;
   for (int k = 0; k < n; ++k) {
     rvc_set *c = rvc_set_create(per, s->device, s->flags | RVC_FLAG_NO_SUBSETS);
@@ -1485,14 +1502,7 @@ void rvc_set_destroy(rvc_set *s) {
   drop_kids(s);
   free_device_state(s);
   if (s->timed_base) hipEventDestroy(s->timed_base);
-  if (s->streams_ok) {
-    for (int i = 0; i < s->ev_free; ++i) hipEventDestroy(s->ev_pool[i]);
-    hipEventDestroy(s->ev_ingest);
-    hipEventDestroy(s->ev_out);
-    hipEventDestroy(s->ev_fence);
-    if (s->st_bg != s->st_main) hipStreamDestroy(s->st_bg);
-    hipStreamDestroy(s->st_main);
-  }
+  drop_streams(s);
   delete s;
 }
 

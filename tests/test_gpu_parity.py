@@ -1052,6 +1052,19 @@ def test_child_sets_flag():
         o = O.FFTConvolver("orc")
         assert o.init(head, irs[c])
         assert rel_rms(outs[1][c], o.process(x[c])) <= TOL, c
+    # one handle through both structures: children -> single set (long calls) -> children again (the parent gives its streams up
+    # when it gets children and creates them anew when it loses them)
+    s = reevr_amd.ConvolverSet(nch)
+    assert s.init_uniform(head, irs, max_len=head) and s.subsets == 2
+    assert np.array_equal(s.process_device_blocks(dx, head).cpu().numpy(), outs[0])
+    assert s.init_uniform(head, irs, max_len=nblk * head) and s.subsets == 1
+    y = s.process_device(dx).cpu().numpy()
+    for c in (0, 2047):
+        assert rel_rms(y[c], outs[0][c]) <= 2e-6, c
+    assert s.init_uniform(head, irs, max_len=head) and s.subsets == 2
+    assert np.array_equal(s.process_device_blocks(dx, head).cpu().numpy(), outs[0])
+    assert s.last_error == 0, s.last_error_string
+    s.close()
     small = reevr_amd.ConvolverSet(64, child_sets=True)
     assert small.init_uniform(head, irs[:64], max_len=head) and small.subsets == 1
     small.close()

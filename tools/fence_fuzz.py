@@ -9,14 +9,41 @@ import numpy as np
 import reevr_amd
 from reevr_amd import synth
 sys.argv, nseeds = sys.argv[:1], int(sys.argv[1]) if len(sys.argv) > 1 else 12
-exec(open(os.path.join(os.path.dirname(__file__), "guard_diag.py")).read().split("for seed in")[0])
+
+
+def case(seed):
+    """the generator of tests/test_gpu_parity.py::test_guard_bands_stay_intact_and_outputs_finite"""
+    rng = np.random.RandomState(9100 + seed)
+    head = int(rng.choice([64, 128, 256, 512]))
+    tail = int(rng.choice([2 * head, 4 * head, 16 * head]))
+    nch = int(rng.randint(1, 4))
+    parts = 3 if seed == 226 else int(rng.choice([1, 3, 9, 20]))
+    base = 2 * tail + parts * tail - int(rng.randint(0, tail // 2))
+    irs = [synth.synth_ir(max(1, base - c * int(rng.randint(0, tail))), 1, 800 + 3 * seed + c)[0] for c in range(nch)]
+    total = int(min(max(40 * tail, 30 * 8 * head), 200000))
+    total -= total % head
+    sched, done = [], 0
+    while done < total:
+        r = rng.randint(0, 30)
+        n = (int(rng.randint(1, head)) if r == 0 else (head - done % head) if (r == 1 and done % head) else
+             int(rng.randint(2, 6)) * head if r == 2 else int(rng.randint(5, 9)) * tail if r == 3 else
+             (head if done % head == 0 else head - done % head))
+        n = max(1, min(n, total - done))
+        sched.append(n)
+        done += n
+    x = np.stack([synth.synth_input(total, 13 * seed + c) for c in range(nch)])
+    return head, tail, nch, irs, sched, x
+
+
 for seed in [226] + list(range(nseeds)):
     head, tail, nch, irs, sched, x = case(seed)
-    for tiling in (False, True, "force", "force2"):
+    for tiling in (False, True, "force", "force2", "force2_k32"):     # force2_k32: first-level tiles of 32 blocks = the LDS-fed sweeps
         reevr_amd.set_tuning("guard", 2)
-        s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1), time_tiling=tiling)
+        reevr_amd.set_tuning("k1", 32 if tiling == "force2_k32" else 0)
+        s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1), time_tiling="force2" if tiling == "force2_k32" else tiling)
         ok = s.init(head, tail, irs, max_len=max(sched))
         reevr_amd.set_tuning("guard", 0)
+        reevr_amd.set_tuning("k1", 0)
         assert ok, s.last_error_string
         pos = 0
         fin = True
@@ -30,11 +57,15 @@ import torch
 for nch, head, tail, ir_len, nblk in ((64, 512, 8192, 480000, 16 * 20), (64, 256, 8192, 700000, 32 * 40), (40, 4096, 8192, 100000, 24)):
     irs = [synth.synth_ir(ir_len - 997 * (c % 5), 1, 600 + c)[0] for c in range(nch)]
     xx = torch.from_numpy(np.stack([synth.synth_input(head * nblk, 20 + c % 7) for c in range(nch)])).cuda()
-    for tiling in (True, "force", "force2"):
+    for tiling in (True, "force", "force2", "force2_k32", "kids"):      # kids: two child sets (forced), default tiling
         reevr_amd.set_tuning("guard", 2)
-        s = reevr_amd.ConvolverSet(nch, time_tiling=tiling)
+        reevr_amd.set_tuning("k1", 32 if tiling == "force2_k32" else 0)
+        reevr_amd.set_tuning("subsets", 2 if tiling == "kids" else -1)
+        s = reevr_amd.ConvolverSet(nch, time_tiling={"force2_k32": "force2", "kids": True}.get(tiling, tiling))
         ok = s.init(head, tail, irs, max_len=head)
         reevr_amd.set_tuning("guard", 0)
+        reevr_amd.set_tuning("k1", 0)
+        reevr_amd.set_tuning("subsets", -1)
         assert ok, s.last_error_string
         y = s.process_device_blocks(xx, head)
         assert s._lib.rvc_debug_fence_probe(s._h) == 1, "the range behind an allocation is readable: no fence"
