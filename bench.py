@@ -262,7 +262,7 @@ class Lockstep:
 
     def __init__(self, torch, reevr_amd, synth, cfg: int, instances, local_rank: int, tiling: bool, bg: bool,
                  blocks_per_step: int, long_call: bool = False, distinct: int = 0, irs=None, x=None, child_sets=None,
-                 fft_f64: bool = False):
+                 fft_f64: bool = False, fft_f64_long: bool = False):
         self.torch, self.cfg = torch, cfg
         w = WORKLOADS[cfg if cfg in WORKLOADS else 2]
         self.ir_len, self.host_block, self.single = w["ir_len"], w["host_block"], w["single"]
@@ -296,7 +296,7 @@ class Lockstep:
             assert (self.renderer.head, self.renderer.tail) == (self.head, self.tail)
         else:
             self.conv = reevr_amd.ConvolverSet(self.nch, device=local_rank, bg_stream=bg, time_tiling=tiling, child_sets=child_sets,
-                                               fft_f64=fft_f64)
+                                               fft_f64=fft_f64, fft_f64_long=fft_f64_long)
             ok = (self.conv.init_uniform(self.host_block, self.irs, max_len=max_len) if self.single
                   else self.conv.init(self.host_block, self.tail, self.irs, max_len=max_len))
             if not ok:
@@ -432,8 +432,8 @@ def roofline_tables(kern: dict, exe: dict, traffic: dict):
         exe_bytes_step += tot
         roof_all[k] = {"launches_per_step": v["launches_per_step"], "avg_launch_ms": round(v["avg_ms"], 5),
                        "ms_per_step": round(busy, 5), "concurrency": round(v["avg_ms"] * v["launches_per_step"] / busy, 3),
-                       "bytes_per_launch": exe[k], "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                       "frac_per_launch": round(lit / HBM_PEAK_GBS, 4), "traffic": traffic.get(k)}
+                       "bytes_per_launch": round(exe[k]), "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+                       "frac_per_launch": round(lit / HBM_PEAK_GBS, 4), "traffic": round(traffic[k]) if k in traffic else None}
     return roof_all, exe_bytes_step
 
 
@@ -523,7 +523,10 @@ def side_config(torch, reevr_amd, synth, KERNEL_NAMES, cfg: int, channels: int, 
         cores = os.cpu_count() or 1
         n_ir = min(len(irs), max(2, cores))
         xin = [np.ascontiguousarray(x[1 + c % (len(x) - 1)]) for c in range(n_ir)]      # (channel 0 carries the probe)
-        out["cpu_baseline"] = cpu_baseline(irs[:n_ir], xin, ls.host_block, ls.tail, cpu_s, w["text"])
+        cb = cpu_baseline(irs[:n_ir], xin, ls.host_block, ls.tail, cpu_s, w["text"])
+        # (compact: the headline's cpu_baseline carries the host's description once)
+        out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": 1, "kind": cb["kind"],
+                               "all_cores": {"value": cb["all_cores"]["value"], "cores": cb["all_cores"]["cores"]}}
     return out
 
 
@@ -571,6 +574,17 @@ def small_regimes(torch, reevr_amd, synth, KERNEL_NAMES, local_rank: int, steps:
                           "note": "RVC_FLAG_FFT_F64: every transform in double (the reference's Ooura precision, AudioFFT.cpp:114-159); the "
                                   "per-block call then takes the general path (the one-launch block kernel is float only)"}
         lf.close()
+        # ... and with RVC_FLAG_FFT_F64_LONG: only the stages with partitions of 2048 .. 8192 samples (here: the tail stage) in double --
+        # the mode in which a set of more than 8 channels meets the reference's own known-answer rule on all 58 of its cases
+        ll = Lockstep(torch, reevr_amd, synth, 2, instances, local_rank, True, False, WORKLOADS[2]["blocks"], irs=irs4096, x=x4096, fft_f64_long=True)
+        ll.preroll()
+        ratel, msl = ll.timed(4, 1)
+        pl = ll.check_probe()
+        ll.conv.check()
+        out["fft_f64_long"] = {"value": round(ratel / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(msl, 4), "channels": ll.nch,
+                               "subsets": ll.conv.subsets, "probe_ok": bool(pl and pl["ok"]), "probe_rms_error": pl["rms_error"] if pl else None,
+                               "note": "RVC_FLAG_FFT_F64_LONG: the tail stage's 8192-bin transforms in double, everything else as the default"}
+        ll.close()
     return out
 
 
@@ -880,6 +894,8 @@ def main():
         summary["config5_literal_Msamples_s"] = regimes["config5_literal"]["value"]
         if "fft_f64" in regimes:
             summary["fft_f64_Msamples_s"] = regimes["fft_f64"]["value"]
+        if "fft_f64_long" in regimes:
+            summary["fft_f64_long_Msamples_s"] = regimes["fft_f64_long"]["value"]
     if "one_queue" in side:
         summary["one_queue_Msamples_s"] = side["one_queue"]["value"]
         oq = side["one_queue"]["roofline_all"].get(roof["kernel"]) if roof else None

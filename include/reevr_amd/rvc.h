@@ -62,6 +62,12 @@ enum {
                                    smaller partitions in float; larger (lock-step) sets run float32 throughout
                                    (~1e-7 relative, 100x inside the 1e-5 RMS parity bound). */
 #define RVC_FLAG_FFT_F32 256u   /* float32 transforms also for small sets (the default of large ones) */
+#define RVC_FLAG_FFT_F64_LONG 2048u /* the small sets' default rule for a set of ANY size: stages with partitions of 2048 ... 8192
+                                   samples transform in double, smaller ones in float. For lock-step sets of more than 8
+                                   channels whose outputs must meet the reference's own known-answer rule (Test.cpp:129-145)
+                                   and not only the 1e-5 RMS bar: with the plug-in's geometries (head 256 / 512, tail 8192) only
+                                   the tail stage's transforms change -- the one-launch per-block path stays --, measured at
+                                   4096 channels in bench.py's `regimes.fft_f64_long`. */
 
 #define RVC_FLAG_FIXED_PARTITIONS 8u /* always use the reference's head/tail partition sizes. Default: a long
                                    call (>= 5 tail blocks) computes the tail blocks that lie entirely

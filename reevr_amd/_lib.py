@@ -24,6 +24,7 @@ RVC_FLAG_PERSISTENT = 64
 RVC_FLAG_FORCE_TWO_LEVEL = 128
 RVC_FLAG_FFT_F32 = 256
 RVC_FLAG_NO_SUBSETS = 512
+RVC_FLAG_FFT_F64_LONG = 2048
 RVC_FLAG_CHILD_SETS = 1024
 RVC_MAX_BLOCK = 16384
 

@@ -34,15 +34,17 @@ class ConvolverSet:
 
     def __init__(self, n_channels: int, device: int = 0, bg_stream: bool = False, timing: bool = False,
                  fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True,
-                 fft_f32: bool = False, child_sets=None):
+                 fft_f32: bool = False, child_sets=None, fft_f64_long: bool = False):
         """time_tiling: True (by size) / False / "force" (every stage, one level unless long) / "force2" (two levels).
-        fft_f64 / fft_f32: every transform in double / in float (default: rvc.h, RVC_FLAG_FFT_F64).
+        fft_f64 / fft_f32: every transform in double / in float (default: rvc.h, RVC_FLAG_FFT_F64); fft_f64_long: the small
+        sets' default rule (double for partitions of 2048 .. 8192 samples) whatever the channel count (RVC_FLAG_FFT_F64_LONG).
         child_sets: None / True = the engine's default (sets of thousands of block-synchronous channels are served by child sets on
         their own streams, fenced internally), False = RVC_FLAG_NO_SUBSETS (one set on one queue: per-launch profiling),
         "unfenced" = RVC_FLAG_CHILD_SETS (no fences inside the calls: rvc_set_fork / rvc_set_join around each ordered call here)."""
         self._lib = L.lib()
         flags = ((L.RVC_FLAG_BG_STREAM if bg_stream else 0) | (L.RVC_FLAG_TIMING if timing else 0)
                  | (L.RVC_FLAG_FFT_F64 if fft_f64 else 0) | (L.RVC_FLAG_FFT_F32 if fft_f32 else 0)
+                 | (L.RVC_FLAG_FFT_F64_LONG if fft_f64_long else 0)
                  | (L.RVC_FLAG_FIXED_PARTITIONS if fixed_partitions else 0)
                  | (0 if time_tiling else L.RVC_FLAG_NO_TIME_TILING)
                  | (L.RVC_FLAG_FORCE_TIME_TILING if time_tiling == "force" else 0)

@@ -538,7 +538,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   // partitions of 2048 .. 8192 samples in double, like the reference's Ooura transform (AudioFFT.cpp:114-159): a float32
   // transform of that length leaves ~2e-7 of the LARGEST value in every output sample, which fails the reference's own
   // known-answer rule (Test.cpp:129-145) on its ramp signals. Large lock-step sets stay float32 (1e-7 relative).
-  const bool auto64 = !want64 && (s->flags & RVC_FLAG_FFT_F32) == 0 && s->nch <= 8;
+  const bool auto64 = !want64 && (s->flags & RVC_FLAG_FFT_F32) == 0 && (s->nch <= 8 || (s->flags & RVC_FLAG_FFT_F64_LONG) != 0);
   auto stage64 = [&](size_t B) { return want64 || (auto64 && B >= 2048 && B <= (size_t)RVC_MAX_BLOCK / 2); };
   const size_t max_block = want64 ? RVC_MAX_BLOCK / 2 : RVC_MAX_BLOCK;
   const size_t hb = std::min(hb_req, max_block);

@@ -58,7 +58,26 @@ def gpu32_factory(kind):
             else reevr_amd.TwoStageFFTConvolver(fft_f32=True))
 
 
-@pytest.mark.parametrize("mode", ["default", "f64", "f32"])
+class _LaneOfManyChannels:
+    """The reference's per-object surface on channel 0 of a 12-channel set created with RVC_FLAG_FFT_F64_LONG: a set of more than 8
+    channels (float transforms by default) with the small sets' precision rule -- partitions of 2048 .. 8192 samples in double."""
+    NCH = 12
+
+    def __init__(self, kind):
+        self.kind = kind
+        self._set = reevr_amd.ConvolverSet(self.NCH, fft_f64_long=True)
+
+    def init(self, *a):
+        ir = np.asarray(a[-1], np.float32)
+        irs = [ir * np.float32(1.0 - 0.05 * c) for c in range(self.NCH)]
+        return self._set.init_uniform(a[0], irs) if self.kind == "fftconv" else self._set.init(a[0], a[1], irs)
+
+    def process(self, x):
+        x = np.asarray(x, np.float32).reshape(-1)
+        return self._set.process(np.stack([x * np.float32(1.0 - 0.03 * c) for c in range(self.NCH)]))[0]
+
+
+@pytest.mark.parametrize("mode", ["default", "f64", "f32", "f64_long_12ch"])
 @pytest.mark.parametrize("kind,tup", KATS, ids=[cases.kat_name(k, t) for k, t in KATS])
 def test_kat_vs_golden_and_reference_rule(golden, kind, tup, mode):
     """The reference's 58 known-answer cases (Test.cpp:256-329) in the three precision modes.
@@ -68,8 +87,11 @@ def test_kat_vs_golden_and_reference_rule(golden, kind, tup, mode):
     transform in double. With float transforms throughout (RVC_FLAG_FFT_F32, what large lock-step sets run) the rule
     holds for partitions below 2048; with 2048-sample partitions of a 0.1*(i+1) ramp the first ~100 outputs (values
     1..1700) share a 4096-point transform with values of 1.5e7, and a float32 FFT's 2e-7 relative noise is then ~1.3
-    absolute against the rule's 1.234: margin 1.01 .. 1.10 measured on MI355X -- bounded here at 1.15."""
-    factory = {"default": gpu_factory, "f64": gpu64_factory, "f32": gpu32_factory}[mode]
+    absolute against the rule's 1.234: margin 1.01 .. 1.10 measured on MI355X -- bounded here at 1.15.
+    f64_long_12ch: a set of MORE than 8 channels created with RVC_FLAG_FFT_F64_LONG (the small sets' rule for any set size)
+    meets the rule on all 58 cases too."""
+    # f64_long_12ch: a set of MORE than 8 channels (float transforms by default) with RVC_FLAG_FFT_F64_LONG meets the rule too
+    factory = {"default": gpu_factory, "f64": gpu64_factory, "f32": gpu32_factory, "f64_long_12ch": _LaneOfManyChannels}[mode]
     out = cases.run_kat(factory, kind, tup)
     cases.compare_to_fixture(out, fixture_of(golden["kat"], cases.kat_name(kind, tup)), TOL)
     exact = O.direct_convolve(synth.ramp(tup[0]), synth.ramp(tup[1]))
