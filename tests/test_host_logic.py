@@ -45,6 +45,23 @@ def test_algorithmic_byte_model_matches_survey():
     assert round(b.alg_bytes_per_sample(4096, 8192, 240000)) == 584
 
 
+def test_bench_traffic_lookup_is_keyed_on_the_launch_size():
+    """bench.py's counter-measured bytes per launch apply only to launches of exactly the channel count they were measured with
+    (round 3's line printed half-size figures for configs 1 / 3): the committed profiles/r4_traffic.json serves the default run
+    (child sets: 2048 / 2048 / 1024 / 2048 channels per launch for configs 2 / 1 / 3 / 5) and the one-queue run (all the
+    channels per launch), and any other launch size gets nothing."""
+    b = _bench()
+    for cfg, per_launch, one_queue in ((2, 2048, 4096), (1, 2048, 8192), (3, 1024, 2048), (5, 2048, 4096)):
+        t, src = b.load_traffic(per_launch, cfg, True)
+        assert t and "r4_traffic.json" in src and str(per_launch) in src
+        t1, _ = b.load_traffic(one_queue, cfg, True)
+        assert t1 and set(t1) == set(t)
+        for k in t:                                   # twice the channels per launch: twice the bytes, within a few percent
+            assert 0.9 < t1[k] / (t[k] * one_queue / per_launch) < 1.1, (cfg, k)
+        assert b.load_traffic(per_launch + 2, cfg, True) == ({}, None)
+        assert b.load_traffic(per_launch, cfg, False) == ({}, None)       # (measured with the time tiling on)
+
+
 class _Imp:
     pass
 
