@@ -195,7 +195,9 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
     n1 = nch // max(1, conv.subsets)                       # channels per launch (child sets launch separately)
     PA, PT = conv.partitions(0), conv.partitions(1)
     p_head, p_t0, p_t = ref_partitions(head, tail, ir_len)
-    row_h, row_t = 8.0 * head * n1, 8.0 * max(tail, 1) * n1   # bytes of one spectrum row of every channel of a launch
+    # (the tail block the set RUNS: long tails of many-channel sets are served at twice the requested block with delay 1)
+    tail_x = int(conv.tail_block) if tail else 0
+    row_h, row_t = 8.0 * head * n1, 8.0 * max(tail_x, 1) * n1   # bytes of one spectrum row of every channel of a launch
     io_blk = n1 * (4.0 * 3 * head + 4.0 * 2 * head)        # per block: input + history + tail ring read, output + ring written
     if not tiled:
         exe = {
@@ -239,8 +241,8 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
             exe["fir_tail"] = ((K2 / 2.0) * 2 + 2) * row_t   # patch: t = 1..7 recent partitions (mean 4) + the sweep row, 1 row out
         else:
             exe["fir_tail"] = (2.0 * PT + 1) * row_t
-        exe["fft_fwd_tail"] = float(n1 * (4 * 2 * tail + 8 * tail))
-        exe["fft_inv_tail"] = float(n1 * (8 * tail + 4 * tail))
+        exe["fft_fwd_tail"] = float(n1 * (4 * 2 * tail_x + 8 * tail_x))
+        exe["fft_inv_tail"] = float(n1 * (8 * tail_x + 4 * tail_x))
     return exe
 
 
@@ -302,6 +304,8 @@ class Lockstep:
             if not ok:
                 raise SystemExit(f"init failed: {self.conv.last_error_string}")
         self.conv.sync()
+        # the tail block the set runs (the engine serves long tails of many-channel sets at twice the requested block, delay 1)
+        self.tail_used = int(self.conv.tail_block) if self.tail else 0
         self.init_ms = (time.perf_counter() - t0) * 1e3
         self.d_in = torch.from_numpy(self.x).to(self.dev)
         self.d_out = torch.empty_like(self.d_in)
@@ -331,7 +335,7 @@ class Lockstep:
         time 0 are never fetched, so the first P_T + 2 tail periods move fewer bytes"""
         pre = 0
         if not self.long_call:
-            span = self.tail if self.tail else self.head
+            span = self.tail_used if self.tail else self.head
             parts = self.conv.partitions(1) if self.tail else self.conv.partitions(0)
             pre = -(-(parts + 4) * span // self.frames_step)
             for _ in range(pre):
@@ -359,7 +363,7 @@ class Lockstep:
     def kernel_times(self, KERNEL_NAMES):
         """per-kernel durations, live, with HIP events on the streams the kernels run on -- over as many steps as one
         first-level sweep tile of the tail stage spans (so that every kernel family occurs), reported per step"""
-        span = self.tail if self.tail else self.head
+        span = self.tail_used if self.tail else self.head
         k1 = self.conv.tile_rows(1 if self.tail else 0) or 1
         nsteps = 1 if self.long_call else max(1, -(-k1 * span // self.frames_step))
         self.conv.set_timing(True)
@@ -390,7 +394,7 @@ class Lockstep:
         number of tiles is a fair average (config 3: 32 tail blocks = 4 steps of 8; configs 1 / 2 / 5: 1)"""
         if self.long_call:
             return 1
-        span = self.tail if self.tail else self.head
+        span = self.tail_used if self.tail else self.head
         k1 = self.conv.tile_rows(1 if self.tail else 0) or 1
         return max(1, -(-k1 * span // self.frames_step))
 
@@ -761,6 +765,7 @@ def main():
     # ---- per-kernel durations, live, with HIP events on the streams the kernels run on ----
     kern = ls.kernel_times(KERNEL_NAMES)
     PA, PT = conv.partitions(0), conv.partitions(1)
+    tail_x = ls.tail_used                 # the tail block the set runs (twice the requested one where the engine widens long tails)
     tiled = ls.tiled
     exe = {} if long_call else executed_bytes(conv, nch, head, tail, ir_len, host_block, tiled)
     traffic_all, tsrc = ({}, None) if long_call else load_traffic(nch // max(1, conv.subsets), args.config, tiled)
@@ -932,9 +937,10 @@ def main():
                    "channels_per_gpu": nch, "stereo_instances_per_gpu": nch // 2, "instances_total": total_ch // 2,
                    "frames_per_channel_per_step": frames_step, "host_block": host_block,
                    "calls_per_step": 1 if long_call else frames_step // host_block,
-                   "partitions": {"head+tail0 (block %d)" % head: PA, "tail (block %d)" % tail: PT},
+                   "partitions": {"head+tail0 (block %d)" % head: PA, "tail (block %d)" % tail_x: PT},
+                   "tail_block_requested": tail, "tail_block_run": tail_x,
                    "tile_blocks": tiles, "subsets": subsets,
-                   "resident_GB": round(nch * 8.0 * (PA * head + (PT + 2) * tail) * 2 / 1e9, 2),
+                   "resident_GB": round(nch * 8.0 * (PA * head + (PT + 2) * tail_x) * 2 / 1e9, 2),
                    "schedule": "long call" if long_call else ("causal time tiling (sweeps + patches; two levels for long delay lines)"
                                                                 if tiled else "reference order (RVC_FLAG_NO_TIME_TILING)"),
                    "call": ("one process() per step" if long_call else

@@ -302,7 +302,7 @@ def set_tuning(key: str, value: int) -> bool:
 
 
 # the engine's defaults of the process-wide knobs (rvc_debug_set_tuning): what `tuning` restores on exit
-TUNING_DEFAULTS = {"fft_many": -1, "k1": 0, "two_level_min_p": -1, "fft_loop": -1, "subsets": -1, "guard": 0, "kid_fence": 1, "sweep_split": -1,
+TUNING_DEFAULTS = {"fft_many": -1, "k1": 0, "two_level_min_p": -1, "fft_loop": -1, "subsets": -1, "guard": 0, "kid_fence": 1, "tail_slack": -1, "sweep_split": -1,
                    "sweep_lw": 0, "sweep_d": 0, "sweep_lds": -1, "patch_nt": 1, "block_occ": 0, "tile_rot": 1}
 
 

@@ -51,6 +51,10 @@ namespace {
 
 constexpr double kPi = 3.14159265358979323846264338327950288;
 constexpr int kNumKernelIds = 13;
+// delay-1 tail stage (do_init): sets of at least this many lock-step channels; widened when the tail would have at least
+// kWidenMinP partitions at the requested block (measured on MI355X, profiles/r4_tail_slack.txt)
+constexpr int kSlackMinChannels = 256;
+constexpr int kWidenMinP = 128;
 
 size_t next_pow2(size_t v) {   // Utilities.h:280-289
   size_t p = 1;
@@ -70,7 +74,8 @@ struct Stage {
   int PF = 0;         // tail stage only: rows of H = 2 + P, the WHOLE IR at block T (rows 0,1 = IR[0,2T) are
                       // used by the adaptive long-call path, rows 2.. are the delay-2 tail partitions)
   int hrows() const { return PF ? PF : P; }
-  int delay = 0;      // block delay of the delay line (0 or 2)
+  int delay = 0;      // block delay of the delay line: 0 (zero-latency stage), 2 (tail stage: the reference's slack of one
+                      // whole tail period) or 1 (tail stage WIDENED to twice the requested block, do_init)
   size_t rows = 0;    // X ring rows (power of two)
   size_t mcap = 0;    // Y rows (max output rows per call)
   float2 *H = nullptr, *X = nullptr, *Y = nullptr;
@@ -109,6 +114,8 @@ struct Tuning {
   int two_min_p = -1;     // "two_level_min_p": delay lines with MORE partitions than this get two levels (-1: kTwoLevelMinP)
   int fft_loop = -1;      // row-looping form of the 8192-bin transforms: -1 by size, 0 never, 1 always
   int subsets = -1;       // children of a many-channel set: -1 by size, else the count
+  int tail_slack = -1;    // "tail_slack": what the tail's period of slack buys (do_init): -1 by size, 0 nothing (delay 2, the reference's
+                          // structure), 1 a tail at twice the block, 2 half the zero-latency stage -- wherever supported
   int kid_fence = 1;      // "kid_fence" (measurement): 0 = no fences between a set's stream and its child sets', 2 = fences but no parent stream work
   int guard = 0;          // 1: NaN-filled guard bands around (and NaN poison inside) every device allocation of a set
 };
@@ -123,6 +130,8 @@ struct rvc_set {
   // middle of another's. A set with children holds no device state itself; every entry point forwards.
   std::vector<rvc_set *> kids;
   std::vector<int> kid_c0;
+  size_t longest_hint = 0;       // child sets: the longest (trimmed) impulse of the WHOLE set, so that all children of a set take
+                                 // the same decision about the widened tail stage (do_init); 0 for a set of its own
   int nch = 0;
   int device = 0;
   unsigned flags = 0;
@@ -161,7 +170,7 @@ struct rvc_set {
   float *h_in = nullptr, *h_out = nullptr;     // pinned
   long long n = 0;               // absolute sample clock
   long long tail_fft_done = 0;   // tail blocks [0, tail_fft_done) have spectra
-  long long tail_out_done = 2;   // tail contributions for output blocks [2, tail_out_done) are in the ring
+  long long tail_out_done = 2;   // tail contributions for output blocks [T.delay, tail_out_done) are in the ring
                                  // (or were delivered directly by the adaptive long-call path)
   long long xa_next = 0;         // head delay line: rows [xa_next-P+1, xa_next) are valid; a stage-A run that
                                  // starts beyond xa_next (the long-call path skipped blocks) rebuilds its history
@@ -400,6 +409,7 @@ void free_device_state(rvc_set *s) {
   s->n = 0;
   s->tail_fft_done = 0;
   s->tail_out_done = 2;
+  s->T.delay = 2;
   s->xa_next = 0;
   s->w_next = 0;
   s->xt_valid_lo = 0;
@@ -550,7 +560,32 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     return true;
   }
   const size_t eff_max_len = max_len ? max_len : hb_req;
-  const size_t split = two_stage ? 2 * tb : (size_t)-1;
+  size_t split = two_stage ? 2 * tb : (size_t)-1;   // the zero-latency stage covers IR[0, split): 2T of the REQUESTED tail block T
+  const bool no_resize = (s->flags & (RVC_FLAG_FIXED_PARTITIONS | RVC_FLAG_BG_STREAM)) != 0;
+  // What the tail's period of slack is spent on. The reference delivers the tail's contribution TWO tail blocks late (IR[2T, ..)
+  // at block T, delay 2): one whole tail period of slack for its background thread (TwoStageFFTConvolver.cpp:213-222). A set whose
+  // tail job runs inside the call that completes a tail block (no second stream) never uses that slack, so a tail stage with
+  // delay ONE -- the input block that ends at sample m*B meets partition 0 in the output block that starts there -- is as
+  // causal, and the period it frees buys one of two things:
+  //   WIDEN  the same IR[2T, ..) at block 2T: same zero-latency stage, HALF the tail partitions at twice the size -- half the
+  //          multiply-adds and half the IR-spectra and delay-line bytes per sample of the tail's sweeps (BASELINE config 3's
+  //          350-partition sweep is multiply-add bound: 9.1 -> 10.9-11.1 Gsamples/s), the same bytes per sample in its patches
+  //          and transforms. Float32 transforms only (a 16384-bin double transform does not fit one CU's LDS);
+  //   SHRINK the tail at block T takes IR[T, ..): the zero-latency stage covers IR[0, T), HALF its partitions (config 5's
+  //          geometry, 4 -> 2 partitions of 4096: its per-block delay line is a third of the step).
+  // For lock-step sets of many channels with time tiling on (small sets keep the reference's geometry, the reference-order
+  // measurement runs keep the reference's structure): long tails are widened, the others shrink the zero-latency stage
+  // (measured on MI355X, profiles/r4_tail_slack.txt).
+  int td = 2;
+  const size_t longest_set = std::max(longest, s->longest_hint);
+  if (two_stage && !no_resize && longest_set > split && (s->flags & RVC_FLAG_NO_TIME_TILING) == 0) {
+    const size_t pt_req = (longest_set - split + tb - 1) / tb;
+    const bool can_widen = !want64 && !stage64(tb) && 2 * tb <= max_block && tb >= 64;
+    int mode = g_tune.tail_slack;
+    if (mode < 0) mode = s->nch < kSlackMinChannels ? 0 : ((can_widen && pt_req >= (size_t)kWidenMinP) ? 1 : 2);
+    if (mode == 1 && can_widen) { td = 1; tb *= 2; }       // (split = 2T = td * tb)
+    else if (mode == 2 && hb < tb) { td = 1; split = tb; }
+  }
 
   // partition counts (ceil(float/float) as FFTConvolver.cpp:115; exact below 2^24 samples)
   std::vector<size_t> lenA(s->nch);   // samples the zero-latency stage covers; the tail and wide
@@ -565,7 +600,6 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   // only by calls that touch several such blocks (the adaptive path of step_device). It has no
   // streaming role -- P stays 0: no tail jobs, no tail ring -- its delay line is rebuilt from the
   // time ring whenever a long call needs it.
-  const bool no_resize = (s->flags & (RVC_FLAG_FIXED_PARTITIONS | RVC_FLAG_BG_STREAM)) != 0;
   const size_t lb = 8192;
   const bool uni_long = !two_stage && !no_resize && hb < lb && longest > 2 * lb && eff_max_len >= 4 * lb;
   if (uni_long) tb = lb;                         // (tb is 0 for single-stage sets otherwise)
@@ -579,7 +613,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   // ---- IR swap with unchanged geometry: keep all device state, refresh the spectra ----
   const size_t tail_pub = two_stage ? tb : 0;    // what rvc_set_tail_block reports: 0 for single-stage sets
   if (s->live && s->two_stage == two_stage && s->head == hb && s->tail == tail_pub && s->max_len == eff_max_len &&
-      s->A.P == (int)pa && s->T.P == (int)pt && s->T.PF == (int)pf && s->W.P == (int)pw) {
+      s->A.P == (int)pa && s->T.P == (int)pt && s->T.PF == (int)pf && s->W.P == (int)pw && (pf == 0 || s->T.delay == td)) {
     if (!use_device(s)) return false;
     hipStreamSynchronize(s->st_bg);
     hipStreamSynchronize(s->st_main);
@@ -587,7 +621,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     if (!upload_ir_stage(s, s->A, irs, lenA, on_device)) { free_device_state(s); return false; }
     if (pf > 0 && !upload_ir_stage(s, s->T, irs, len, on_device)) { free_device_state(s); return false; }
     if (pw > 0 && !upload_ir_stage(s, s->W, irs, len, on_device)) { free_device_state(s); return false; }
-    s->n = 0; s->tail_fft_done = 0; s->tail_out_done = 2; s->xa_next = 0; s->ypre_block = -1;
+    s->n = 0; s->tail_fft_done = 0; s->tail_out_done = td; s->xa_next = 0; s->ypre_block = -1;
     s->w_next = 0; s->xt_valid_lo = 0; s->tA.drop(); s->tT.drop();
     return true;
   }
@@ -609,7 +643,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   RVC_CK(dev_alloc(s, &A.X, sizeof(float2) * (size_t)s->nch * A.rows * A.B));
   RVC_CK(dev_alloc(s, &A.Y, sizeof(float2) * (size_t)s->nch * A.mcap * A.B));
   if (pf > 0) {
-    T.B = tb; T.logB = ilog2(tb); T.P = (int)pt; T.PF = (int)pf; T.delay = 2; T.f64 = stage64(tb);
+    T.B = tb; T.logB = ilog2(tb); T.P = (int)pt; T.PF = (int)pf; T.delay = td; T.f64 = stage64(tb);
     T.mcap = s->max_len / tb + 3;
     T.rows = next_pow2(pf + T.mcap + 2);
     if (!make_twiddles(s, T)) return false;
@@ -685,7 +719,8 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   RVC_CK(hipStreamSynchronize(s->st_bg));
   s->n = 0;
   s->tail_fft_done = 0;
-  s->tail_out_done = 2;
+  s->tail_out_done = td;
+  T.delay = td;                  // (also when the stage is absent: clear() restarts the tail clock from it)
   s->xa_next = 0;
   s->w_next = 0;
   s->xt_valid_lo = 0;
@@ -727,12 +762,15 @@ struct Timer {   // brackets one launch with events when timing is on
 
 // ---- causal time tiling: sweep launches shared by both stages -----------------------------------
 // The delay line of a stage as a sweep sees it: the zero-latency stage's whole table with delay 0 (the sweep's x_hi
-// keeps the two newest partitions out), the tail stage's partitions 2.. with delay 2.
+// keeps the two newest partitions out), the tail stage's partitions d.. with delay d (2, or 1 when widened).
+// stage_lag: how far behind the block being prepared the newest input row lies that a sweep may use -- the zero-latency
+// stage's two newest partitions belong to the per-block launch, the tail's newest row is `delay` blocks back.
+int stage_lag(const rvc_set *s, bool tail) { return tail ? s->T.delay : 2; }
 rvc::FirArgs stage_line(rvc_set *s, bool tail) {
   Stage &g = tail ? s->T : s->A;
   const long long B = (long long)g.B;
   rvc::FirArgs r{};
-  if (tail) { r.H = g.H + 2 * B; r.h_chan_stride = (long long)g.PF * B; r.delay = 2; r.tag = 1; }
+  if (tail) { r.H = g.H + (long long)g.delay * B; r.h_chan_stride = (long long)g.PF * B; r.delay = g.delay; r.tag = 1; }
   else { r.H = g.H; r.h_chan_stride = (long long)g.P * B; r.delay = 0; r.tag = 0; }
   r.X = g.X; r.x_chan_stride = (long long)g.rows * B; r.x_row_mask = g.rows - 1;
   r.P = g.P; r.B = (int)B;
@@ -746,16 +784,18 @@ rvc::FirArgs sweep1_args(rvc_set *s, bool tail, long long k0, long long x_hi) {
   r.k0 = k0; r.M = t.K1; r.x_hi = x_hi;
   return r;
 }
-// second level: blocks [g0, g0 + 8) of the tile that started at t0: first-level rows + the input rows t0 - 1 .. g0 - 2
+// second level: blocks [g0, g0 + 8) of the tile that started at t0: first-level rows + the input rows t0 - L + 1 .. g0 - L
+// (L = stage_lag)
 rvc::FirArgs sweep2_args(rvc_set *s, bool tail, long long g0) {
   const Tile &t = tail ? s->tT : s->tA;
   const long long K = rvc::kSweepRows;
   rvc::FirArgs r = stage_line(s, tail);
   r.Y = t.s2; r.y_chan_stride = K * r.B; r.y_row_mask = (unsigned)(K - 1);
   r.Ybase = t.s1; r.ybase_chan_stride = (long long)t.rows1 * r.B; r.ybase_row_mask = (unsigned)(t.rows1 - 1);
-  r.k0 = g0; r.M = (int)K; r.x_from = t.t0 - 1; r.x_hi = g0 - 2;
-  // the oldest row that counts (t0 - 1) meets block g0 + 7 in partition g0 + 7 - delay - (t0 - 1)
-  r.P = (int)std::min<long long>(r.P, g0 - t.t0 + K + 1 - r.delay);
+  const long long L = stage_lag(s, tail);
+  r.k0 = g0; r.M = (int)K; r.x_from = t.t0 - L + 1; r.x_hi = g0 - L;
+  // the oldest row that counts (t0 - L + 1) meets block g0 + 7 in partition g0 + 7 - delay - (t0 - L + 1)
+  r.P = (int)std::min<long long>(r.P, g0 - t.t0 + K - 1 + L - r.delay);
   return r;
 }
 // where the partial sums of block b live -- b inside the current first-level tile, and past its first group only once
@@ -810,19 +850,20 @@ bool ensure_tail_spectra(rvc_set *s, long long lo, hipStream_t st) {
   return true;
 }
 
-// Tail contributions (IR[2T,..), delivered two tail blocks late) for output blocks
-// [tail_out_done, m_hi) into the time-indexed tail ring. Needs spectra of blocks < m_hi - 2.
+// Tail contributions (IR[2T,..), delivered T.delay tail blocks late) for output blocks
+// [tail_out_done, m_hi) into the time-indexed tail ring. Needs spectra of blocks < m_hi - T.delay.
 bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
   Stage &T = s->T;
   const long long tb = (long long)T.B;
   const long long m_lo = s->tail_out_done;
   if (m_hi <= m_lo) return true;
-  if (!ensure_tail_spectra(s, m_lo - 2 - (long long)T.P + 1, st)) return false;
+  const long long td = T.delay;
+  if (!ensure_tail_spectra(s, m_lo - td - (long long)T.P + 1, st)) return false;
   rvc::FirArgs r{};
-  r.H = T.H + 2 * tb; r.h_chan_stride = (long long)T.PF * tb;       // partitions 2.. of the whole-IR table
+  r.H = T.H + td * tb; r.h_chan_stride = (long long)T.PF * tb;      // partitions td.. of the whole-IR table
   r.X = T.X; r.x_chan_stride = (long long)T.rows * tb; r.x_row_mask = T.rows - 1;
   r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
-  r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = 2; r.B = (int)tb; r.tag = 1;
+  r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = (int)td; r.B = (int)tb; r.tag = 1;
   const float2 *yrows = T.Y;                      // where the inverse transforms read the spectra
   if (s->tT.on && r.M == 1) {
     // block-synchronous streaming, time-tiled: output block m_lo either lies in the current tile -- then only the
@@ -838,7 +879,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
       }
       long long stride = 0;
       const float2 *row = tile_row(s, true, m_lo, &stride);
-      const long long recent = m_lo - g0;          // input rows g0-1 .. m_lo-2 came after the sweep
+      const long long recent = m_lo - g0;          // input rows g0-td+1 .. m_lo-td came after the sweep
       if (recent > 0) {
         r.P = (int)std::min<long long>(recent, T.P);
         r.Yadd = row; r.yadd_chan_stride = stride;
@@ -848,7 +889,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
         yrows = row; r.y_chan_stride = stride;
       }
     } else {
-      const rvc::FirArgs w = sweep1_args(s, true, m_lo, m_lo - 2);   // (m_lo - 2: the newest delay-line row that exists)
+      const rvc::FirArgs w = sweep1_args(s, true, m_lo, m_lo - td);  // (m_lo - td: the newest delay-line row that exists)
       {
         Timer tm(s, 10, st);
         RVC_CK(rvc::launch_fdl_sweep(w, s->nch, st));
@@ -889,8 +930,8 @@ bool run_tail_job(rvc_set *s, long long n0, long long n1, const float *src2, siz
   }
   if (!tail_spectra(s, n0, n1, src2, in_stride, st)) return false;
   const long long m_lo = s->tail_out_done;
-  if (!tail_rows(s, mb1 + 2, st)) return false;
-  if (bg && !push_job(s, m_lo, mb1 + 2, st)) return false;
+  if (!tail_rows(s, mb1 + s->T.delay, st)) return false;
+  if (bg && !push_job(s, m_lo, mb1 + s->T.delay, st)) return false;
   return true;
 }
 
@@ -971,7 +1012,7 @@ bool head_stage(rvc_set *s, long long n0, long long na, long long nb, const floa
   v.lo = na; v.hi = nb;
   v.add = has_tail ? s->tailring : nullptr;
   v.add_chan_stride = (long long)s->ring_cap; v.add_mask = s->ring_cap - 1;
-  v.add_from = has_tail ? 2 * (long long)T.B : 0;
+  v.add_from = has_tail ? (long long)T.delay * (long long)T.B : 0;
   Timer t(s, 3, s->st_main);
   RVC_CK(rvc::launch_fft_inv(A.logB, A.f64, v, M, s->nch, s->st_main));
   return true;
@@ -1107,7 +1148,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     g.out = d_out; g.out_chan_stride = (long long)out_stride;
     g.add = has_tail ? s->tailring : nullptr;
     g.add_chan_stride = (long long)s->ring_cap; g.add_mask = s->ring_cap - 1;
-    g.add_from = has_tail ? 2 * (long long)T.B : 0;
+    g.add_from = has_tail ? (long long)T.delay * (long long)T.B : 0;
     const bool block_done = n1 % hb == 0;
     // host-pointer call through the pinned buffers: the audio workgroups publish completion flags and
     // process_end polls them -- no event behind the kernel, no wait for the kernel's tail
@@ -1511,8 +1552,16 @@ int rvc_set_init(rvc_set *s, size_t head_block, size_t tail_block, const float *
   if (!s) return 0;
   if (irs && ir_lens && make_kids(s, subset_count(s, head_block, max_len))) {
     bool ok = true;
-    for (size_t k = 0; k < s->kids.size(); ++k)
+    size_t longest = 0;                  // (trimmed like do_init does: TwoStageFFTConvolver.cpp:107-110)
+    for (int c = 0; c < s->nch; ++c) {
+      size_t l = irs[c] ? ir_lens[c] : 0;
+      while (l > longest && std::fabs(irs[c][l - 1]) < 0.000001f) --l;
+      longest = std::max(longest, l);
+    }
+    for (size_t k = 0; k < s->kids.size(); ++k) {
+      s->kids[k]->longest_hint = longest;
       ok = rvc_set_init(s->kids[k], head_block, tail_block, irs + s->kid_c0[k], ir_lens + s->kid_c0[k], max_len) != 0 && ok;
+    }
     adopt_kid_geometry(s, ok);
     return ok ? 1 : 0;
   }
@@ -1541,8 +1590,15 @@ int rvc_set_init_impulse(rvc_set *s, size_t head_block, size_t tail_block, rvc_i
   if (!s) return 0;
   if (channels && make_kids(s, subset_count(s, head_block, max_len))) {
     bool ok = true;
-    for (size_t k = 0; k < s->kids.size(); ++k)
+    size_t longest = 0;
+    rvc::ImpulseView pv{};
+    if (m && rvc::impulse_view(m, &pv))
+      for (int c = 0; c < s->nch; ++c)
+        if (channels[c] >= 0 && channels[c] < pv.channels) longest = std::max(longest, (size_t)pv.trimmed[channels[c]]);
+    for (size_t k = 0; k < s->kids.size(); ++k) {
+      s->kids[k]->longest_hint = longest;
       ok = rvc_set_init_impulse(s->kids[k], head_block, tail_block, m, channels + s->kid_c0[k], max_len) != 0 && ok;
+    }
     adopt_kid_geometry(s, ok);
     return ok ? 1 : 0;
   }
@@ -1729,7 +1785,7 @@ void rvc_set_clear(rvc_set *s) {
   drop_jobs(s);
   s->n = 0;
   s->tail_fft_done = 0;
-  s->tail_out_done = 2;
+  s->tail_out_done = s->T.delay;
   s->ypre_block = -1;
   s->xa_next = 0;
   s->w_next = 0;
@@ -2049,6 +2105,7 @@ int rvc_debug_set_tuning(const char *key, int value) {
   else if (k == "subsets") g_tune.subsets = value;
   else if (k == "fft_many") rvc::set_fft_many_tuning(value);
   else if (k == "kid_fence") g_tune.kid_fence = value;
+  else if (k == "tail_slack") g_tune.tail_slack = value;
   else if (k == "patch_nt") rvc::set_patch_nt_tuning(value);
   else if (k == "block_occ") rvc::set_block_occ3_tuning(value);
   else if (k == "tile_rot") rvc::set_tile_rot_tuning(value);
