@@ -246,6 +246,19 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
     return exe
 
 
+def tail_stage_form(conv, head: int, tail: int) -> str:
+    """What the set's tail stage looks like beside the reference's (head over IR[0,T), tail0 over IR[T,2T), tail over IR[2T,..) at
+    block T, two blocks late): the engine's zero-latency stage covers head + tail0; lock-step sets of many channels run the tail
+    with delay ONE and spend the freed period on a tail at block 2T (long tails) or on half the zero-latency stage."""
+    if not tail or not conv.partitions(1):
+        return "none"
+    if int(conv.tail_block) != tail:
+        return "delay 1, block 2T over IR[2T,..) (widened)"
+    if conv.partitions(0) * head <= tail:
+        return "delay 1, block T over IR[T,..) (zero-latency stage shrunk to IR[0,T))"
+    return "delay 2, block T over IR[2T,..) (the reference's structure)"
+
+
 def probe_expected(ir: np.ndarray, frames_step: int, last_step: int, at: int) -> np.ndarray:
     """Channel 0 is fed a unit impulse at offset `at` of input batch 0, i.e. at absolute sample s * frames_step + at of
     every EVEN step s: its output in step `last_step` is the sum of the impulse responses those impulses started."""
@@ -481,6 +494,7 @@ def side_config(torch, reevr_amd, synth, KERNEL_NAMES, cfg: int, channels: int, 
         "value": round(rate / 1e6, 3), "unit": "Msamples/s", "steps": steps, "ms_per_step": round(ms, 4),
         "channels": channels, "frames_per_channel_per_step": ls.frames_step, "pre_roll_steps": pre,
         "partitions": {"zero-latency stage": ls.conv.partitions(0), "tail stage": ls.conv.partitions(1)},
+        "tail_block_run": ls.tail_used, "tail_stage": tail_stage_form(ls.conv, ls.head, ls.tail),
         "tile_blocks": {"zero-latency stage": ls.conv.tile_rows(0), "tail stage": ls.conv.tile_rows(1)},
         "subsets": ls.conv.subsets,
         "executed_bytes_per_sample": round(exe_bps, 1) if exe_bps else None,
@@ -616,6 +630,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=0, help="synthesise only this many different stereo IRs and cycle them (0: all different; config 3: 128)")
     ap.add_argument("--child-sets", type=int, default=1, help="0: RVC_FLAG_NO_SUBSETS for the measured set (one set on one queue; the "
                     "default serves thousands of block-synchronous channels by child sets on their own streams, fenced internally)")
+    ap.add_argument("--ir-len", type=int, default=0, help="measurement hook: impulse length in samples instead of the configuration's (the "
+                    "line then is NOT the BASELINE configuration: config.workload says so)")
     ap.add_argument("--tune", type=str, default="", help="rvc_debug_set_tuning knobs, e.g. k1=32,subsets=2 (measurement hook)")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a stuck run dumps every thread's stack and exits (0: off)")
@@ -630,6 +646,9 @@ def main():
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         assert reevr_amd.set_tuning(k, int(v)), k
+    if args.ir_len > 0:                      # (measurement hook: another impulse length at the configuration's geometry)
+        WORKLOADS[args.config] = dict(WORKLOADS[args.config], ir_len=args.ir_len,
+                                      text=WORKLOADS[args.config]["text"] + " -- NOT the BASELINE configuration: --ir-len %d" % args.ir_len)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -937,7 +956,8 @@ def main():
                    "channels_per_gpu": nch, "stereo_instances_per_gpu": nch // 2, "instances_total": total_ch // 2,
                    "frames_per_channel_per_step": frames_step, "host_block": host_block,
                    "calls_per_step": 1 if long_call else frames_step // host_block,
-                   "partitions": {"head+tail0 (block %d)" % head: PA, "tail (block %d)" % tail_x: PT},
+                   "partitions": {"zero-latency stage (block %d)" % head: PA, "tail stage (block %d)" % tail_x: PT},
+                   "tail_stage": tail_stage_form(conv, head, tail),
                    "tail_block_requested": tail, "tail_block_run": tail_x,
                    "tile_blocks": tiles, "subsets": subsets,
                    "resident_GB": round(nch * 8.0 * (PA * head + (PT + 2) * tail_x) * 2 / 1e9, 2),

@@ -560,15 +560,18 @@ def _random_schedule(rng, total, head, tail):
     return out
 
 
-@pytest.mark.parametrize("tiling", ["default", "force", "force2"])
+@pytest.mark.parametrize("tiling", ["default", "force", "force2", "widen", "shrink"])
 @pytest.mark.parametrize("seed", list(range(48)))
 def test_fuzz_geometry_and_call_pattern(seed, tiling):
     """Seeded fuzz: random head/tail sizes (incl. non powers of two), IR lengths around the
     stage boundaries, 1-3 channels of different lengths, flags, and call patterns; every run is
     compared with the oracle sample by sample. tiling = force: the causal time tiling of the
     block-synchronous delay lines (RVC_FLAG_FORCE_TIME_TILING) whatever the stage size; force2: with two-level
-    tiles (RVC_FLAG_FORCE_TWO_LEVEL: first-level sweeps of 16 blocks, second-level sweeps every 8)."""
+    tiles (RVC_FLAG_FORCE_TWO_LEVEL: first-level sweeps of 16 blocks, second-level sweeps every 8). widen / shrink: the
+    delay-1 tail stage of many-channel sets forced on these small ones (tail_slack = 1: the tail at twice the block,
+    2: half the zero-latency stage; float32 transforms, tail job on the set's own stream, forced tiling)."""
     rng = np.random.RandomState(1000 + seed)
+    slack = {"widen": 1, "shrink": 2}.get(tiling, -1)
     head = int(rng.choice([1, 3, 8, 24, 64, 100, 256, 512, 1024]))
     tail = int(rng.choice([max(head, 16), 2 * max(head, 8), 128, 512, 2048, 8192]))
     if head > tail:
@@ -587,8 +590,19 @@ def test_fuzz_geometry_and_call_pattern(seed, tiling):
     bg = bool(rng.randint(0, 2))
     fixed = bool(rng.randint(0, 2))
     x = np.stack([synth.synth_input(total, 5 * seed + c) for c in range(nch)])
-    s = reevr_amd.ConvolverSet(nch, bg_stream=bg, fixed_partitions=fixed, time_tiling=True if tiling == "default" else tiling)
-    assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
+    if slack > 0:
+        bg = fixed = False
+        with reevr_amd.tuning(tail_slack=slack):
+            s = reevr_amd.ConvolverSet(nch, bg_stream=False, time_tiling="force", fft_f32=True)
+            assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
+        if s.partitions(1) > 0 and hb < tb:                         # a tail stage exists
+            if slack == 2:
+                assert s.tail_block == tb and s.partitions(0) == tb // hb
+            elif 64 <= tb <= 8192:
+                assert s.tail_block == 2 * tb and s.partitions(0) == 2 * tb // hb
+    else:
+        s = reevr_amd.ConvolverSet(nch, bg_stream=bg, fixed_partitions=fixed, time_tiling=True if tiling == "default" else tiling)
+        assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
     clear_at = int(rng.randint(0, len(sched))) if rng.randint(0, 3) == 0 else -1
     got = np.empty_like(x)
     pos = 0
@@ -614,7 +628,7 @@ def test_fuzz_geometry_and_call_pattern(seed, tiling):
                                   f"bg {bg} fixed {fixed} clear {clear_at}: rel rms {err / ref:.3e}")
 
 
-@pytest.mark.parametrize("tiling", [True, False, "force", "force2", "force2_k32"])
+@pytest.mark.parametrize("tiling", [True, False, "force", "force2", "force2_k32", "widen", "shrink_force2"])
 @pytest.mark.parametrize("seed", list(range(24)) + [226])   # 226: 3 tail partitions on 4 sweep waves (a wave without work)
 def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     """The plug-in's calling pattern -- one call per host block, now and then a ragged one, several calls inside one
@@ -647,13 +661,17 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
         done += n
     bg = bool(rng.randint(0, 2))
     x = np.stack([synth.synth_input(total, 11 * seed + c) for c in range(nch)])
-    if tiling == "force2_k32":                 # two levels with first-level tiles of 32 blocks (the default is 16)
-        reevr_amd.set_tuning("k1", 32)
-    try:
-        s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling="force2" if tiling == "force2_k32" else tiling)
+    slack = {"widen": 1, "shrink_force2": 2}.get(tiling, -1)     # the delay-1 tail stage of many-channel sets, forced
+    if slack > 0:
+        bg = False
+        tiling = "force" if slack == 1 else "force2"
+    with reevr_amd.tuning(k1=32 if tiling == "force2_k32" else 0, tail_slack=slack):   # (k1 = 32: first-level tiles of 32 blocks)
+        s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling="force2" if tiling == "force2_k32" else tiling, fft_f32=slack > 0)
         assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
-    finally:
-        reevr_amd.set_tuning("k1", 0)
+    if slack == 1:
+        assert s.tail_block == 2 * tail and s.partitions(0) == 2 * tail // head
+    elif slack == 2:
+        assert s.tail_block == tail and s.partitions(0) == tail // head
     if str(tiling).startswith("force2"):
         assert s.tile_rows(1) == (32 if tiling == "force2_k32" else 16)
     clear_at = int(rng.randint(len(sched) // 4, len(sched))) if rng.randint(0, 3) == 0 else -1
@@ -1004,8 +1022,11 @@ def test_device_entry_with_misaligned_views_and_strides():
             assert rel_rms(got[c], want[c]) <= TOL
 
 
-def test_two_level_tiling_at_config3_geometry():
-    """BASELINE configs[2]'s geometry with the time tiling FORCED on both stages and many channels: head 256 / tail 8192,
+@pytest.mark.parametrize("slack", [0, 1, 2])
+def test_two_level_tiling_at_config3_geometry(slack):
+    """(slack: what the tail's period of slack buys -- 0 the reference's structure, 1 the tail at block 16384 with delay 1 = what
+    sets of >= 256 channels run at this geometry, 2 half the zero-latency stage.)
+    BASELINE configs[2]'s geometry with the time tiling FORCED on both stages and many channels: head 256 / tail 8192,
     a 30 s @ 96 kHz IR on channel 0 (P_A = 64 zero-latency partitions, P_T = 350 tail partitions -> two-level tiles on
     both stages), 64 lock-step channels with IRs of different lengths, one process() per 256-frame block through the
     device entry until every tail partition carries signal; three channels against the oracle."""
@@ -1016,9 +1037,10 @@ def test_two_level_tiling_at_config3_geometry():
     irs = [base[c % 2][:lens[c]].copy() for c in range(nch)]
     nblk = (352 + 24) * (tail // head)                       # all 350 tail partitions in use, then a few tiles more
     x = np.stack([synth.synth_input(head * nblk, 200 + c % 5) for c in range(nch)])
-    s = reevr_amd.ConvolverSet(nch, time_tiling="force")
-    assert s.init(head, tail, irs, max_len=head), s.last_error_string
-    assert s.partitions(0) == 64 and s.partitions(1) == 350
+    with reevr_amd.tuning(tail_slack=slack):
+        s = reevr_amd.ConvolverSet(nch, time_tiling="force")
+        assert s.init(head, tail, irs, max_len=head), s.last_error_string
+    assert (s.partitions(0), s.partitions(1), s.tail_block) == [(64, 350, 8192), (64, 175, 16384), (32, 351, 8192)][slack]
     assert s.tile_rows(0) > 8 and s.tile_rows(1) > 8         # two levels on both stages
     got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
     assert s.last_error == 0, s.last_error_string
@@ -1128,6 +1150,45 @@ def test_child_sets_match_single_set(kids):
         o = O.TwoStageFFTConvolver("orc")
         assert o.init(head, tail, irs[c])
         assert rel_rms(whole[c], o.process(x[c, :head * 105])) <= TOL, c
+
+
+def test_tail_slack_policy_and_children():
+    """The delay-1 tail stage (rvc_engine.cpp do_init): lock-step sets of >= 256 channels whose tail job runs on the set's own
+    stream spend the tail period of slack the reference keeps for its background thread -- long tails (>= 128 partitions) run at
+    TWICE the requested block, the others give half of the zero-latency stage to the tail; sets with the tail on a second
+    stream, fixed partitions, the reference-order schedule or fewer channels keep the reference's structure; the children of a
+    set decide TOGETHER (on the longest impulse of the whole set). Every variant against the oracle."""
+    import torch
+    head, tail, nblk = 64, 256, 700
+    long_ir, short_ir = 2 * tail + 140 * tail - 17, 2 * tail + 20 * tail - 5
+    x1 = np.stack([synth.synth_input(head * nblk, 70 + c) for c in range(4)])
+
+    def run(nch, lens, expect, subsets=-1, **kw):
+        irs = [synth.synth_ir(lens[c % len(lens)] - (c % 7), 1, 800 + c % 11)[0] for c in range(nch)]
+        x = x1[np.arange(nch) % 4]
+        with reevr_amd.tuning(subsets=subsets):
+            s = reevr_amd.ConvolverSet(nch, bg_stream=kw.pop("bg_stream", False), **kw)
+            assert s.init(head, tail, irs, max_len=head), s.last_error_string
+        assert (s.partitions(0), s.tail_block, s.partitions(1)) == expect, (kw, s.partitions(0), s.tail_block, s.partitions(1))
+        if subsets > 1:
+            assert s.subsets == subsets
+        got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        s.close()
+        for c in (0, 1, nch - 1):
+            o = O.TwoStageFFTConvolver("orc")
+            assert o.init(head, tail, irs[c])
+            assert rel_rms(got[c], o.process(x[c])) <= TOL, (kw, c)
+
+    run(256, [long_ir], (8, 512, 70))                          # long tail: widened
+    run(256, [short_ir], (4, 256, 21))                         # short tail: the zero-latency stage shrinks
+    run(255, [long_ir], (8, 256, 140))                         # below the channel threshold: the reference's structure
+    run(256, [long_ir], (8, 256, 140), bg_stream=True)         # tail on the second stream: the slack is in use
+    run(256, [long_ir], (8, 256, 140), fixed_partitions=True)
+    run(256, [long_ir], (8, 256, 140), time_tiling=False)      # reference-order schedule
+    run(256, [long_ir], (4, 256, 141), fft_f64=True)           # double transforms: no 2T-block transform, so it shrinks
+    # two children: only channel 0 carries the long impulse -- the second child alone would shrink, together they widen
+    run(512, [long_ir] + [short_ir] * 511, (8, 512, 70), subsets=2)
 
 
 def test_row_looping_transforms_match_one_row_kernels():
@@ -1330,6 +1391,13 @@ def _fdl_case(rng, nch, B, P, M, rows):
     (1, 2, 8192, 57, 16, 2, 128, "lds16"),         # 16-block tiles as 2 x 8
     (1, 3, 256, 23, 16, 0, 40, "lds16_allrows"),
     (1, 2, 512, 94, 32, 0, 128, "one_wave32"),     # the one-wave 32-block form (sweep_lds = 0)
+    # round 4: the delay-1 tail stage of many-channel sets (the newest row a sweep may use is k0 - 1), 16384-bin rows
+    (0, 2, 16384, 6, 1, 1, 40, "patch_d1"),
+    (1, 2, 8192, 20, 8, 1, 64, "split_d1"),
+    (1, 3, 512, 17, 8, 1, 64, "second_d1"),
+    (1, 2, 16384, 29, 16, 1, 64, "own_d1"),
+    (1, 2, 16384, 40, 32, 1, 100, "lds32_d1"),
+    (1, 2, 1024, 11, 16, 1, 2, "own_early_d1"),
 ])
 def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant):
     """The complex multiply-accumulate kernels ALONE (SURVEY a-12): one launch of the general delay-line launcher / a sweep
@@ -1346,10 +1414,12 @@ def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant)
     split, pack = _fdl_case(rng, nch, B, P, M, rows)
     Hre, Him = split((nch, P))
     Xre, Xim = split((nch, rows))
+    d1 = variant.endswith("_d1")
+    variant = variant[:-3] if d1 else variant
     second = variant == "second"
     has_add = variant in ("patch", "second")
     Are, Aim = split((nch, M if kind == 1 else 1)) if has_add else (None, None)
-    x_hi = k0 + M - 1 - delay if kind == 0 else (k0 + M if variant.endswith("allrows") else (k0 - 2 if variant != "second" else k0 + 3))
+    x_hi = k0 + M - 1 - delay if kind == 0 else (k0 + M if variant.endswith("allrows") else ((k0 - 1 if d1 else k0 - 2) if variant != "second" else k0 + 3))
     x_from = (k0 - 9) if second else 0
     want_re = np.zeros((nch, M, B + 1), np.float32)
     want_im = np.zeros((nch, M, B + 1), np.float32)
