@@ -44,7 +44,13 @@ enum {
 /* Largest partition (block) size used internally. The 2*block-point real FFT of one partition lives
  * in one CU's LDS (block * 8 bytes <= 128 KiB). Larger requests are accepted and served with this
  * size: partition sizes set the algorithm's latency, not its output, and here the latency is that of
- * the call. rvc_set_head_block / rvc_set_tail_block report the sizes in use. */
+ * the call. rvc_set_head_block / rvc_set_tail_block report the sizes in use.
+ * Likewise the SPLIT between the stages: the reference serves IR[0, 2T) at the head block size and IR[2T, ..) at the tail block
+ * size T, two tail blocks late -- the slack of its background thread. A lock-step set of >= 256 channels whose tail job runs on
+ * the set's own stream (no RVC_FLAG_BG_STREAM / _FIXED_PARTITIONS / _NO_TIME_TILING) runs the tail ONE block late instead and
+ * spends the freed period: tails of >= 128 partitions run at block 2T (rvc_set_tail_block reports 2T, half the partitions),
+ * every other tail takes IR[T, ..) and the zero-latency stage covers IR[0, T) only (rvc_set_partitions(s, 0) halves). Same
+ * samples (1e-5 RMS bar, measured 2-3e-7); smaller sets keep the reference's structure. */
 #define RVC_MAX_BLOCK 16384
 
 /* flags for rvc_set_create */
@@ -69,7 +75,7 @@ enum {
                                    the tail stage's transforms change -- the one-launch per-block path stays --, measured at
                                    4096 channels in bench.py's `regimes.fft_f64_long`. */
 
-#define RVC_FLAG_FIXED_PARTITIONS 8u /* always use the reference's head/tail partition sizes. Default: a long
+#define RVC_FLAG_FIXED_PARTITIONS 8u /* always use the reference's head/tail partition sizes and stage split. Default: a long
                                    call (>= 5 tail blocks) computes the tail blocks that lie entirely
                                    inside it with ONE uniform delay line at the tail block size over the
                                    whole IR -- same result (it does not depend on partition sizes), no

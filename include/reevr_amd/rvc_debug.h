@@ -42,8 +42,10 @@ int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int d
  * n children of a many-channel set; "guard" 0 / 1 guard bands around every device allocation (see rvc_debug_guard_check) / 2 every
  * allocation END-aligned against an unmapped address range (an out-of-bounds access faults: tools/fence_fuzz.py only);
  * "two_level_min_p" delay lines with more partitions than this get two tiling levels (-1: default 24); "tile_rot" 1 (default) /
- * 0 sweeps and patches on long rows take channel c's bin tiles in the order rotated by c; "sweep_lw", "sweep_d", "patch_nt",
- * "block_occ": kernel variants (rvc_internal.h). */
+ * 0 sweeps and patches on long rows take channel c's bin tiles in the order rotated by c; "tail_slack" what the tail's period of
+ * slack buys (rvc.h, RVC_MAX_BLOCK): -1 by size / 0 nothing (the reference's structure, delay 2) / 1 a tail at twice the block /
+ * 2 half the zero-latency stage, wherever supported (tests force both on small sets); "sweep_lds", "fft_many", "kid_fence",
+ * "sweep_lw", "sweep_d", "patch_nt", "block_occ": kernel / schedule variants (rvc_internal.h, rvc_engine.cpp Tuning). */
 int rvc_debug_set_tuning(const char *key, int value);
 /* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set
  * is initialised, every device allocation of the set lies between two 256 KiB guard bands filled with 0xFF and starts out
