@@ -36,14 +36,16 @@ for C in $CONFIGS; do
   D="$OUT/config$C"; mkdir -p "$D"
   case $C in
     1) GEO="--channels 8192 --subsets 4 --head-log 9 --tail-log 13 --k1-head 32 --k1-tail 0" ;;
-    2) GEO="--channels 4096 --subsets 2 --head-log 9 --tail-log 13 --k1-head 16 --k1-tail 16" ;;
-    3) GEO="--channels 2048 --subsets 2 --head-log 8 --tail-log 13 --k1-head 16 --k1-tail 32" ;;
+    # (configs 2 / 5: the tail stage one block late over IR[T,..), the zero-latency stage half as long; config 3: the tail at block 16384)
+    2) GEO="--channels 4096 --subsets 2 --head-log 9 --tail-log 13 --k1-head 8 --k1-tail 16" ;;
+    3) GEO="--channels 2048 --subsets 2 --head-log 8 --tail-log 14 --k1-head 16 --k1-tail 32" ;;
     5) GEO="--channels 4096 --subsets 2 --head-log 12 --tail-log 13 --k1-head 0 --k1-tail 16 --patch0-family fir_head" ;;
   esac
   LS=""; [ "$C" = "5" ] && LS="--lockstep 1"     # (config 5's geometry in the lock-step regime: the entry `config5` of the default line)
-  [ "$C" = "3" ] && STEPS=4 || STEPS=3          # (config 3: whole first-level tiles of the tail stage = 4 steps)
+  [ "$C" = "3" ] && STEPS=8 || STEPS=3          # (config 3: whole first-level tiles of the tail stage = 32 blocks of 16384 = 8 steps)
+  [ "$C" = "3" ] && KSTEPS=24 || KSTEPS=20
   ARGS="--config $C $LS --steps $STEPS --warmup 1 --cpu-seconds 0 --side 0 --distinct 64"
-  KT_ARGS="--config $C $LS --steps 20 --warmup 5 --cpu-seconds 0 --side 0 --distinct 64"
+  KT_ARGS="--config $C $LS --steps $KSTEPS --warmup 5 --cpu-seconds 0 --side 0 --distinct 64"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$D/kt" -o kt -- python "$ROOT/bench.py" $KT_ARGS > "$D/bench_under_rocprof.json" 2> "$D/kt.err"
   find "$D/kt" -name '*kernel_stats.csv' -exec cp {} "$D/kernel_stats.csv" \;
   find "$D/kt" -name '*kernel_trace.csv' -exec python "$ROOT/tools/trace_union.py" {} \; > "$D/kernel_union.txt" 2>&1
