@@ -223,8 +223,9 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
     if KA:
         # audio part (H0, H1, X_{k-1}, accumulator read; X_k written; samples) + on average (K2-1)/2 recent partitions patched
         exe["fused_block"] = 5 * row_h + io_blk + ((K2 - 1) / 2.0 * 2 + 2) * row_h * (K2 - 1) / K2
-        exe["sweep_head"] = (PA + (PA - 2) + KA) * row_h     # IR rows + arrived delay-line rows read once, KA partial rows written
-        exe["sweep2_head"] = sweep2_rows(KA, PA, 0) * row_h
+        # IR rows 2.. + arrived delay-line rows read once, KA partial rows written (the two newest partitions are the per-block launch's)
+        exe["sweep_head"] = ((PA - 2) + (PA - 2) + KA) * row_h
+        exe["sweep2_head"] = sweep2_rows(KA, PA - 2, 2) * row_h
     else:                                                    # zero-latency stage not tiled: every block reads all of it
         exe["fused_block"] = 5 * row_h + io_blk + (2.0 * max(PA - 2, 0) + 1) * row_h
         # (many channels with a large head block: the per-block call is transform / delay line / inverse launches)

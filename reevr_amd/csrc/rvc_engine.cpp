@@ -761,8 +761,9 @@ struct Timer {   // brackets one launch with events when timing is on
 };
 
 // ---- causal time tiling: sweep launches shared by both stages -----------------------------------
-// The delay line of a stage as a sweep sees it: the zero-latency stage's whole table with delay 0 (the sweep's x_hi
-// keeps the two newest partitions out), the tail stage's partitions d.. with delay d (2, or 1 when widened).
+// The delay line of a stage as a sweep sees it: the tail stage's partitions d.. with delay d (2, or 1 for the delay-1 forms);
+// the zero-latency stage's partitions 2.. with delay 2 -- its two newest partitions belong to the per-block launch, so a
+// sweep would only fetch their IR rows to multiply them with rows that have not arrived (2 of 38 rows of config 2's sweep).
 // stage_lag: how far behind the block being prepared the newest input row lies that a sweep may use -- the zero-latency
 // stage's two newest partitions belong to the per-block launch, the tail's newest row is `delay` blocks back.
 int stage_lag(const rvc_set *s, bool tail) { return tail ? s->T.delay : 2; }
@@ -771,9 +772,9 @@ rvc::FirArgs stage_line(rvc_set *s, bool tail) {
   const long long B = (long long)g.B;
   rvc::FirArgs r{};
   if (tail) { r.H = g.H + (long long)g.delay * B; r.h_chan_stride = (long long)g.PF * B; r.delay = g.delay; r.tag = 1; }
-  else { r.H = g.H; r.h_chan_stride = (long long)g.P * B; r.delay = 0; r.tag = 0; }
+  else { r.H = g.H + 2 * B; r.h_chan_stride = (long long)g.P * B; r.delay = 2; r.tag = 0; }
   r.X = g.X; r.x_chan_stride = (long long)g.rows * B; r.x_row_mask = g.rows - 1;
-  r.P = g.P; r.B = (int)B;
+  r.P = tail ? g.P : std::max(g.P - 2, 0); r.B = (int)B;
   return r;
 }
 // first level: blocks [k0, k0 + K1), every partition, the input rows <= x_hi

@@ -1163,7 +1163,7 @@ def test_tail_slack_policy_and_children():
     long_ir, short_ir = 2 * tail + 140 * tail - 17, 2 * tail + 20 * tail - 5
     x1 = np.stack([synth.synth_input(head * nblk, 70 + c) for c in range(4)])
 
-    def run(nch, lens, expect, subsets=-1, **kw):
+    def run(nch, lens, expect, subsets=-1, reinit=False, **kw):
         irs = [synth.synth_ir(lens[c % len(lens)] - (c % 7), 1, 800 + c % 11)[0] for c in range(nch)]
         x = x1[np.arange(nch) % 4]
         with reevr_amd.tuning(subsets=subsets):
@@ -1174,14 +1174,24 @@ def test_tail_slack_policy_and_children():
             assert s.subsets == subsets
         got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
         assert s.last_error == 0, s.last_error_string
+        got2 = None
+        if reinit:                        # IR hot-swap with unchanged geometry (the fast path keeps every buffer), mid-stream
+            irs2 = [(-0.5 * ir).astype(np.float32) for ir in irs]
+            assert s.init(head, tail, irs2, max_len=head), s.last_error_string
+            assert (s.partitions(0), s.tail_block, s.partitions(1)) == expect
+            got2 = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
+            assert s.last_error == 0, s.last_error_string
         s.close()
         for c in (0, 1, nch - 1):
             o = O.TwoStageFFTConvolver("orc")
             assert o.init(head, tail, irs[c])
             assert rel_rms(got[c], o.process(x[c])) <= TOL, (kw, c)
+            if got2 is not None:
+                assert o.init(head, tail, irs2[c])
+                assert rel_rms(got2[c], o.process(x[c])) <= TOL, (kw, c, "after re-init")
 
-    run(256, [long_ir], (8, 512, 70))                          # long tail: widened
-    run(256, [short_ir], (4, 256, 21))                         # short tail: the zero-latency stage shrinks
+    run(256, [long_ir], (8, 512, 70), reinit=True)             # long tail: widened
+    run(256, [short_ir], (4, 256, 21), reinit=True)            # short tail: the zero-latency stage shrinks
     run(255, [long_ir], (8, 256, 140))                         # below the channel threshold: the reference's structure
     run(256, [long_ir], (8, 256, 140), bg_stream=True)         # tail on the second stream: the slack is in use
     run(256, [long_ir], (8, 256, 140), fixed_partitions=True)
