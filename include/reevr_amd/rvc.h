@@ -108,8 +108,8 @@ enum {
                                    and out: the caller orders against ONE stream as ever. rvc_set_process_device_blocks fences
                                    once around its whole loop (the full gain); a caller making ONE device-pointer call per block
                                    pays the fence -- a barrier between the children -- per block and is better off on one queue
-                                   (RVC_FLAG_NO_SUBSETS: 15.5 against 13.9 Gsamples/s at 4096 channels) or WITH THIS FLAG: no
-                                   fences inside the calls (16.2 per call too): the caller brackets any run of device-pointer
+                                   (RVC_FLAG_NO_SUBSETS: 16.6 against 15.0 Gsamples/s at 4096 channels) or WITH THIS FLAG: no
+                                   fences inside the calls (17.2 per call too): the caller brackets any run of device-pointer
                                    calls between which it touches neither buffer with rvc_set_fork / rvc_set_join (or orders its
                                    own work against EVERY child's foreground stream, rvc_set_stream(s, 2 + 2 k)). */
 #define RVC_FLAG_NO_SUBSETS 512u  /* never child sets: one set, one foreground queue (per-launch profiling, A/B runs) */
