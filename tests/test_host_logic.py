@@ -62,6 +62,39 @@ def test_bench_traffic_lookup_is_keyed_on_the_launch_size():
         assert b.load_traffic(per_launch, cfg, False) == ({}, None)       # (measured with the time tiling on)
 
 
+class _SetGeometry:
+    """what bench.executed_bytes asks a ConvolverSet for"""
+
+    def __init__(self, parts, tiles, tail_block, subsets=1):
+        self._p, self._t, self.tail_block, self.subsets = parts, tiles, tail_block, subsets
+
+    def partitions(self, stage):
+        return self._p[stage]
+
+    def tile_rows(self, stage):
+        return self._t[stage]
+
+
+def test_executed_bytes_model_against_the_committed_counter_passes():
+    """bench.py's executed-bytes model of every kernel family -- with the structures the engine runs for sets of thousands of
+    channels: the tail one block late over IR[T,..) and half the zero-latency stage (configs 2 / 5: 16 + 58 and 2 + 29 partitions),
+    the tail at block 16384 (config 3: 64 + 175) -- against the PMC bytes per launch of the committed one-queue passes
+    (profiles/r4_traffic.json, rocprofv3 FETCH_SIZE / WRITE_SIZE): within 5 % for every family, none missing."""
+    b = _bench()
+    cases = {2: (4096, 512, 8192, 480000, _SetGeometry((16, 58), (8, 16), 8192)),
+             3: (2048, 256, 8192, 2880000, _SetGeometry((64, 175), (16, 32), 16384)),
+             5: (4096, 4096, 8192, 240000, _SetGeometry((2, 29), (0, 16), 8192)),
+             1: (8192, 512, 0, 48000, _SetGeometry((94, 0), (32, 0), 0))}
+    for cfg, (nch, head, tail, ir_len, conv) in cases.items():
+        exe = b.executed_bytes(conv, nch, head, tail, ir_len, head, True)
+        traffic, src = b.load_traffic(nch, cfg, True)
+        assert traffic, cfg
+        assert b.tail_stage_form(conv, head, tail).startswith({2: "delay 1, block T", 3: "delay 1, block 2T", 5: "delay 1, block T", 1: "none"}[cfg])
+        for fam, measured in traffic.items():
+            assert fam in exe, (cfg, fam)
+            assert 0.95 <= measured / exe[fam] <= 1.05, (cfg, fam, measured / exe[fam])
+
+
 class _Imp:
     pass
 
