@@ -17,6 +17,9 @@
 //            contribution to output block m needs input blocks <= m-2 only, so it is computed one
 //            whole tail period ahead (exactly the slack the reference gives its background
 //            thread) into a time-indexed ring that stage A's epilogue adds.
+//   Lock-step sets of many channels that run the tail job on their own stream do not need the second block of that slack:
+//   their stage T runs ONE block late (Stage::delay = 1) and the freed period buys a tail at block 2T (long tails) or a
+//   stage A that only covers IR[0,T) (do_init, "What the tail's period of slack is spent on").
 // Every buffer is a ring indexed by absolute sample / block number, so a process() call of ANY
 // length (one 512-sample block, a ragged 37 samples, or 40 s at once) is the same four steps:
 // ingest -> [tail: FFT new blocks, FIR, IFFT -> tail ring] -> stage A: FFT, FIR, IFFT(+tail) -> out.

@@ -54,7 +54,8 @@ struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency
   long long k0;             // absolute block index of output row 0
   int M;                    // output rows
   int P;                    // partitions
-  int delay;                // 0 for the zero-latency stage, 2 for the tail stage
+  int delay;                // block delay of the line: the tail stage's 2 (1 for the delay-1 forms of many-channel sets), the
+                            // zero-latency stage's 0 (its sweeps and patches start at partition 2 with delay 2)
   int B;
   int tag;                  // names the kernel instantiation for profilers: 0 head stage, 1 tail stage
                             // (delay 2), 2 whole-IR delay line of the adaptive long-call path
