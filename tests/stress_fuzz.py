@@ -13,7 +13,10 @@ for seed in range(first, first + count):
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "force")), (T.test_fuzz_single_stage_sets, (seed,)),
             (T.test_fuzz_geometry_and_call_pattern, (seed, "force2")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "force2")),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "force2_k32")), (T.test_guard_bands_stay_intact_and_outputs_finite, (seed,)),
-            (T.test_fuzz_child_sets_call_patterns, (seed,))]
+            (T.test_fuzz_child_sets_call_patterns, (seed,)),
+            # the delay-1 tail stage of many-channel sets, forced on these small ones: the tail at twice the block / half the zero-latency stage
+            (T.test_fuzz_geometry_and_call_pattern, (seed, "widen")), (T.test_fuzz_geometry_and_call_pattern, (seed, "shrink")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "widen")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "shrink_force2"))]
     for fn, a in jobs:
         runs += 1
         if os.environ.get("STRESS_LOG"):

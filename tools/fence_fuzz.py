@@ -37,13 +37,13 @@ def case(seed):
 
 for seed in [226] + list(range(nseeds)):
     head, tail, nch, irs, sched, x = case(seed)
-    for tiling in (False, True, "force", "force2", "force2_k32"):     # force2_k32: first-level tiles of 32 blocks = the LDS-fed sweeps
-        reevr_amd.set_tuning("guard", 2)
-        reevr_amd.set_tuning("k1", 32 if tiling == "force2_k32" else 0)
-        s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1), time_tiling="force2" if tiling == "force2_k32" else tiling)
-        ok = s.init(head, tail, irs, max_len=max(sched))
-        reevr_amd.set_tuning("guard", 0)
-        reevr_amd.set_tuning("k1", 0)
+    # force2_k32: first-level tiles of 32 blocks = the LDS-fed sweeps; widen / shrink: the delay-1 tail stage of many-channel sets
+    for tiling in (False, True, "force", "force2", "force2_k32", "widen", "shrink"):
+        slack = {"widen": 1, "shrink": 2}.get(tiling, -1)
+        with reevr_amd.tuning(guard=2, k1=32 if tiling == "force2_k32" else 0, tail_slack=slack):
+            s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1) and slack < 0, fft_f32=slack > 0,
+                                       time_tiling={"force2_k32": "force2", "widen": "force", "shrink": "force2"}.get(tiling, tiling))
+            ok = s.init(head, tail, irs, max_len=max(sched))
         assert ok, s.last_error_string
         pos = 0
         fin = True
@@ -57,19 +57,15 @@ import torch
 for nch, head, tail, ir_len, nblk in ((64, 512, 8192, 480000, 16 * 20), (64, 256, 8192, 700000, 32 * 40), (40, 4096, 8192, 100000, 24)):
     irs = [synth.synth_ir(ir_len - 997 * (c % 5), 1, 600 + c)[0] for c in range(nch)]
     xx = torch.from_numpy(np.stack([synth.synth_input(head * nblk, 20 + c % 7) for c in range(nch)])).cuda()
-    for tiling in (True, "force", "force2", "force2_k32", "kids"):      # kids: two child sets (forced), default tiling
-        reevr_amd.set_tuning("guard", 2)
-        reevr_amd.set_tuning("k1", 32 if tiling == "force2_k32" else 0)
-        reevr_amd.set_tuning("subsets", 2 if tiling == "kids" else -1)
-        s = reevr_amd.ConvolverSet(nch, time_tiling={"force2_k32": "force2", "kids": True}.get(tiling, tiling))
-        ok = s.init(head, tail, irs, max_len=head)
-        reevr_amd.set_tuning("guard", 0)
-        reevr_amd.set_tuning("k1", 0)
-        reevr_amd.set_tuning("subsets", -1)
+    for tiling in (True, "force", "force2", "force2_k32", "kids", "widen", "shrink"):      # kids: two child sets (forced), default tiling
+        with reevr_amd.tuning(guard=2, k1=32 if tiling == "force2_k32" else 0, subsets=2 if tiling == "kids" else -1,
+                              tail_slack={"widen": 1, "shrink": 2}.get(tiling, -1)):
+            s = reevr_amd.ConvolverSet(nch, time_tiling={"force2_k32": "force2", "kids": True, "widen": True, "shrink": True}.get(tiling, tiling))
+            ok = s.init(head, tail, irs, max_len=head)
         assert ok, s.last_error_string
         y = s.process_device_blocks(xx, head)
         assert s._lib.rvc_debug_fence_probe(s._h) == 1, "the range behind an allocation is readable: no fence"
-        print(f"fence ok: lock-step {nch} x head {head} tail {tail} ir {ir_len} tiling {tiling} tiles {s.tile_rows(0)}/{s.tile_rows(1)} "
+        print(f"fence ok: lock-step {nch} x head {head} tail {tail}->{s.tail_block} P {s.partitions(0)}+{s.partitions(1)} ir {ir_len} tiling {tiling} tiles {s.tile_rows(0)}/{s.tile_rows(1)} "
               f"finite {bool(torch.isfinite(y).all())}", flush=True)
         s.close()
 print("fence fuzz done")
