@@ -195,7 +195,8 @@ void rvc_set_sync(rvc_set *s);
 
 int rvc_set_channels(const rvc_set *s);
 size_t rvc_set_head_block(const rvc_set *s);   /* after rounding; 0 before init */
-size_t rvc_set_tail_block(const rvc_set *s);   /* 0 for a uniform (single-stage) set */
+size_t rvc_set_tail_block(const rvc_set *s);   /* the block the tail stage RUNS (the request rounded up to a power of two; twice that for
+                                                  the widened tail of many-channel sets, RVC_MAX_BLOCK above); 0 for a uniform set */
 size_t rvc_set_max_len(const rvc_set *s);
 /* partitions of the zero-latency stage (head + tail0 merged), of the tail stage, and of the wide
  * stage (whole IR at block 16384, used by very long calls; 0 when absent) */

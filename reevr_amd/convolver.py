@@ -232,6 +232,8 @@ class ConvolverSet:
 
     @property
     def tail_block(self) -> int:
+        """the block the tail stage runs: the requested one (rounded up to a power of two), or twice that for the widened
+        delay-1 tail of lock-step sets of many channels (rvc.h, RVC_MAX_BLOCK); 0 for single-stage sets"""
         return int(self._lib.rvc_set_tail_block(self._h))
 
     @property
