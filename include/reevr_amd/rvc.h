@@ -48,7 +48,8 @@ enum {
  * Likewise the SPLIT between the stages: the reference serves IR[0, 2T) at the head block size and IR[2T, ..) at the tail block
  * size T, two tail blocks late -- the slack of its background thread. A lock-step set of >= 256 channels whose tail job runs on
  * the set's own stream (no RVC_FLAG_BG_STREAM / _FIXED_PARTITIONS / _NO_TIME_TILING) runs the tail ONE block late instead and
- * spends the freed period: tails of >= 128 partitions run at block 2T (rvc_set_tail_block reports 2T, half the partitions),
+ * spends the freed period: tails of >= 128 partitions (>= 48 below tail blocks of 8192) run at block 2T (rvc_set_tail_block
+ * reports 2T, half the partitions),
  * every other tail takes IR[T, ..) and the zero-latency stage covers IR[0, T) only (rvc_set_partitions(s, 0) halves). Same
  * samples (1e-5 RMS bar, measured 2-3e-7); smaller sets keep the reference's structure. */
 #define RVC_MAX_BLOCK 16384

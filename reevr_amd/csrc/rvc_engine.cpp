@@ -55,9 +55,12 @@ namespace {
 constexpr double kPi = 3.14159265358979323846264338327950288;
 constexpr int kNumKernelIds = 13;
 // delay-1 tail stage (do_init): sets of at least this many lock-step channels; widened when the tail would have at least
-// kWidenMinP partitions at the requested block (measured on MI355X, profiles/r4_tail_slack.txt)
+// kWidenMinP partitions at the requested block -- kWidenMinPShort when the widened block is below 16384, whose transforms run
+// two to four workgroups per CU instead of one (measured on MI355X, profiles/r4_tail_slack.txt: head 512 / tail 8192: 117
+// partitions tie, 175 favour widening; head 256 / tail 2048, 116 partitions: widened 14.9, shrunk 13.8 Gsamples/s)
 constexpr int kSlackMinChannels = 256;
 constexpr int kWidenMinP = 128;
+constexpr int kWidenMinPShort = 48;
 
 size_t next_pow2(size_t v) {   // Utilities.h:280-289
   size_t p = 1;
@@ -585,7 +588,8 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     const size_t pt_req = (longest_set - split + tb - 1) / tb;
     const bool can_widen = !want64 && !stage64(tb) && 2 * tb <= max_block && tb >= 64;
     int mode = g_tune.tail_slack;
-    if (mode < 0) mode = s->nch < kSlackMinChannels ? 0 : ((can_widen && pt_req >= (size_t)kWidenMinP) ? 1 : 2);
+    const size_t widen_min = 2 * tb < (size_t)RVC_MAX_BLOCK ? (size_t)kWidenMinPShort : (size_t)kWidenMinP;
+    if (mode < 0) mode = s->nch < kSlackMinChannels ? 0 : ((can_widen && pt_req >= widen_min) ? 1 : 2);
     if (mode == 1 && can_widen) { td = 1; tb *= 2; }       // (split = 2T = td * tb)
     else if (mode == 2 && hb < tb) { td = 1; split = tb; }
   }
@@ -688,7 +692,9 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     Tile &tA = s->tA, &tT = s->tT;
     tA = Tile(); tT = Tile();
     tA.on = tiling && s->fold && !s->block_general && A.B >= 64 &&
-            (force ? pa >= 3 : (pa >= 16 && (size_t)s->nch * (pa - 2) * A.B * 16 >= ((size_t)4 << 20)));
+            (force ? pa >= 3 : (pa >= 8 && (size_t)s->nch * (pa - 2) * A.B * 16 >= ((size_t)4 << 20)));
+    // (pa >= 8: a shrunk zero-latency stage of 8 partitions -- head 1024 under a tail of 8192 -- measured 9.1 Gsamples/s untiled
+    //  against 14.9 tiled at 2048 channels, profiles/r4_tail_slack.txt; it was 16 while every many-channel stage had >= 16)
     tT.on = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
     // one level of 8 blocks, or -- long delay lines -- a first level of 16 / 32 blocks with second-level sweeps every 8
     auto first_level = [&](size_t P) -> int {
