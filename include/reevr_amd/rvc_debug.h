@@ -36,6 +36,14 @@ int rvc_debug_irfft(int device, size_t n, int f64, float *data, const float *re,
 int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int delay, long long k0, int ring_rows,
                   const float *H, const float *X, const float *Yadd, float *Y, long long x_hi, long long x_from);
 
+/* The stage plan rvc_set_init would choose for a two-stage set of n_channels with these creation flags, requested block sizes and
+ * longest (trimmed) impulse -- a pure function, no device needed (the CPU tests pin the policy with it): the head / tail block
+ * sizes that run, the number of impulse samples the zero-latency stage covers (2T of the reference's head + tail0; T for the
+ * shrunk form), and -- the return value -- the tail stage's delay in tail blocks: 2 (the reference's structure) or 1 (the
+ * widened / shrunk forms of lock-step sets of many channels, rvc.h RVC_MAX_BLOCK). 0: bad arguments. */
+int rvc_debug_plan(int n_channels, unsigned flags, size_t head_block, size_t tail_block, size_t longest_ir,
+                   size_t *head_run, size_t *tail_run, size_t *zero_latency_samples);
+
 /* Measurement hook (bench.py, tools/): process-wide schedule knobs, read when a set is initialised. Returns 1 if the
  * key is known. Keys: "k1" first-level tile of long delay lines (8 = one level, 16 default, 32); "sweep_split" -1 auto /
  * 0 own-tile / 1 partition-split sweeps; "fft_loop" -1 auto / 0 / 1 row-looping 8192-bin transforms; "subsets" -1 auto /

@@ -94,6 +94,7 @@ SIGNATURES = {
     "rvc_debug_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "rvc_debug_guard_check": (C.c_long, [C.c_void_p]),
     "rvc_debug_fence_probe": (C.c_int, [C.c_void_p]),
+    "rvc_debug_plan": (C.c_int, [C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t] + [C.POINTER(C.c_size_t)] * 3),
     "rvc_device_count": (C.c_int, []),
     "rvc_version": (C.c_char_p, []),
 }

@@ -303,6 +303,19 @@ def set_tuning(key: str, value: int) -> bool:
     return bool(L.lib().rvc_debug_set_tuning(key.encode(), int(value)))
 
 
+def stage_plan(n_channels: int, headBlockSize: int, tailBlockSize: int, longest_ir: int, flags: int = 0) -> dict:
+    """The stage plan rvc_set_init would choose (rvc_debug_plan: a pure function of the request, no device): block sizes that
+    run, impulse samples the zero-latency stage covers, delay of the tail stage in tail blocks (2: the reference's structure,
+    1: the widened / shrunk forms of lock-step sets of many channels)."""
+    hb, tb, zl = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    d = L.lib().rvc_debug_plan(int(n_channels), int(flags), int(headBlockSize), int(tailBlockSize), int(longest_ir),
+                               C.byref(hb), C.byref(tb), C.byref(zl))
+    if d == 0:
+        raise ValueError("bad arguments")
+    return {"head_block": hb.value, "tail_block": tb.value, "zero_latency_samples": zl.value, "tail_delay": d,
+            "partitions": (-(-min(longest_ir, zl.value) // hb.value), -(-max(longest_ir - zl.value, 0) // tb.value))}
+
+
 # the engine's defaults of the process-wide knobs (rvc_debug_set_tuning): what `tuning` restores on exit
 TUNING_DEFAULTS = {"fft_many": -1, "k1": 0, "two_level_min_p": -1, "fft_loop": -1, "subsets": -1, "guard": 0, "kid_fence": 1, "tail_slack": -1, "sweep_split": -1,
                    "sweep_lw": 0, "sweep_d": 0, "sweep_lds": -1, "patch_nt": 1, "block_occ": 0, "tile_rot": 1}

@@ -509,6 +509,59 @@ bool upload_ir_stage(rvc_set *s, Stage &g, const float *const *irs, const std::v
   return true;
 }
 
+// Block sizes, transform precision and the split between the stages of a set -- a pure function of the request (do_init
+// applies it; rvc_debug_plan exposes it to the CPU tests).
+struct StagePlan {
+  size_t hb_req, hb, tb, split, max_block;
+  int td;                       // delay of the tail stage in tail blocks: 2 (the reference's), 1 (widened / shrunk forms)
+  bool want64, auto64;
+  bool stage64(size_t B) const { return want64 || (auto64 && B >= 2048 && B <= (size_t)RVC_MAX_BLOCK / 2); }
+};
+StagePlan plan_stages(int nch, unsigned flags, int tail_slack, size_t head_block, size_t tail_block, bool two_stage,
+                      size_t longest_set) {
+  StagePlan p{};
+  // Requested partition sizes, rounded up to powers of two like the reference (:117-118); requests above what one CU's LDS can
+  // transform are served with the largest supported partition (comment in do_init).
+  p.hb_req = next_pow2(head_block);
+  p.want64 = (flags & RVC_FLAG_FFT_F64) != 0;
+  // Default precision: small sets (the plug-in's 2-4 channels; a transform costs them nothing) run stages with
+  // partitions of 2048 .. 8192 samples in double, like the reference's Ooura transform (AudioFFT.cpp:114-159): a float32
+  // transform of that length leaves ~2e-7 of the LARGEST value in every output sample, which fails the reference's own
+  // known-answer rule (Test.cpp:129-145) on its ramp signals. Large lock-step sets stay float32 (1e-7 relative).
+  p.auto64 = !p.want64 && (flags & RVC_FLAG_FFT_F32) == 0 && (nch <= 8 || (flags & RVC_FLAG_FFT_F64_LONG) != 0);
+  p.max_block = p.want64 ? RVC_MAX_BLOCK / 2 : RVC_MAX_BLOCK;
+  p.hb = std::min(p.hb_req, p.max_block);
+  p.tb = two_stage ? std::min(next_pow2(tail_block), p.max_block) : 0;
+  p.split = two_stage ? 2 * p.tb : (size_t)-1;   // the zero-latency stage covers IR[0, split): 2T of the REQUESTED tail block T
+  p.td = 2;
+  const bool no_resize = (flags & (RVC_FLAG_FIXED_PARTITIONS | RVC_FLAG_BG_STREAM)) != 0;
+  // What the tail's period of slack is spent on. The reference delivers the tail's contribution TWO tail blocks late (IR[2T, ..)
+  // at block T, delay 2): one whole tail period of slack for its background thread (TwoStageFFTConvolver.cpp:213-222). A set whose
+  // tail job runs inside the call that completes a tail block (no second stream) never uses that slack, so a tail stage with
+  // delay ONE -- the input block that ends at sample m*B meets partition 0 in the output block that starts there -- is as
+  // causal, and the period it frees buys one of two things:
+  //   WIDEN  the same IR[2T, ..) at block 2T: same zero-latency stage, HALF the tail partitions at twice the size -- half the
+  //          multiply-adds and half the IR-spectra and delay-line bytes per sample of the tail's sweeps (BASELINE config 3's
+  //          350-partition sweep is multiply-add bound: 9.1 -> 10.9-11.1 Gsamples/s), the same bytes per sample in its patches
+  //          and transforms. Float32 transforms only (a 16384-bin double transform does not fit one CU's LDS);
+  //   SHRINK the tail at block T takes IR[T, ..): the zero-latency stage covers IR[0, T), HALF its partitions (config 5's
+  //          geometry, 4 -> 2 partitions of 4096: its per-block delay line is a third of the step).
+  // For lock-step sets of many channels with time tiling on (small sets keep the reference's geometry, the reference-order
+  // measurement runs keep the reference's structure): long tails are widened, the others shrink the zero-latency stage
+  // (measured on MI355X, profiles/r4_tail_slack.txt).
+  if (two_stage && !no_resize && longest_set > p.split && (flags & RVC_FLAG_NO_TIME_TILING) == 0) {
+    const size_t tb = p.tb;
+    const size_t pt_req = (longest_set - p.split + tb - 1) / tb;
+    const bool can_widen = !p.want64 && !p.stage64(tb) && 2 * tb <= p.max_block && tb >= 64;
+    int mode = tail_slack;
+    const size_t widen_min = 2 * tb < (size_t)RVC_MAX_BLOCK ? (size_t)kWidenMinPShort : (size_t)kWidenMinP;
+    if (mode < 0) mode = nch < kSlackMinChannels ? 0 : ((can_widen && pt_req >= widen_min) ? 1 : 2);
+    if (mode == 1 && can_widen) { p.td = 1; p.tb = 2 * tb; }       // (split = 2T = td * tb)
+    else if (mode == 2 && p.hb < tb) { p.td = 1; p.split = tb; }
+  }
+  return p;
+}
+
 bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
              const float *const *irs, const size_t *ir_lens, size_t max_len, bool on_device = false) {
   // The reference's init() starts with reset() (TwoStageFFTConvolver.cpp:92, FFTConvolver.cpp:95).
@@ -548,17 +601,13 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   // is set by the call, not by the partition: requests above what one CU's LDS can transform are
   // served with the largest supported partition instead (rvc_set_head_block / _tail_block report
   // what is used). A host running 16384- or 32768-frame blocks gets the same samples.
-  const size_t hb_req = next_pow2(head_block);
-  const bool want64 = (s->flags & RVC_FLAG_FFT_F64) != 0;
-  // Default precision: small sets (the plug-in's 2-4 channels; a transform costs them nothing) run stages with
-  // partitions of 2048 .. 8192 samples in double, like the reference's Ooura transform (AudioFFT.cpp:114-159): a float32
-  // transform of that length leaves ~2e-7 of the LARGEST value in every output sample, which fails the reference's own
-  // known-answer rule (Test.cpp:129-145) on its ramp signals. Large lock-step sets stay float32 (1e-7 relative).
-  const bool auto64 = !want64 && (s->flags & RVC_FLAG_FFT_F32) == 0 && (s->nch <= 8 || (s->flags & RVC_FLAG_FFT_F64_LONG) != 0);
-  auto stage64 = [&](size_t B) { return want64 || (auto64 && B >= 2048 && B <= (size_t)RVC_MAX_BLOCK / 2); };
-  const size_t max_block = want64 ? RVC_MAX_BLOCK / 2 : RVC_MAX_BLOCK;
-  const size_t hb = std::min(hb_req, max_block);
-  size_t tb = two_stage ? std::min(next_pow2(tail_block), max_block) : 0;
+  const size_t longest_set = std::max(longest, s->longest_hint);
+  const StagePlan plan = plan_stages(s->nch, s->flags, g_tune.tail_slack, head_block, tail_block, two_stage, longest_set);
+  const size_t hb_req = plan.hb_req, hb = plan.hb, split = plan.split;
+  const bool want64 = plan.want64;
+  auto stage64 = [&](size_t B) { return plan.stage64(B); };
+  size_t tb = plan.tb;
+  const int td = plan.td;
   if (longest == 0) {   // empty IR: success, process() gives zeros (:112-115)
     drop();
     s->inited = true;
@@ -566,33 +615,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     return true;
   }
   const size_t eff_max_len = max_len ? max_len : hb_req;
-  size_t split = two_stage ? 2 * tb : (size_t)-1;   // the zero-latency stage covers IR[0, split): 2T of the REQUESTED tail block T
   const bool no_resize = (s->flags & (RVC_FLAG_FIXED_PARTITIONS | RVC_FLAG_BG_STREAM)) != 0;
-  // What the tail's period of slack is spent on. The reference delivers the tail's contribution TWO tail blocks late (IR[2T, ..)
-  // at block T, delay 2): one whole tail period of slack for its background thread (TwoStageFFTConvolver.cpp:213-222). A set whose
-  // tail job runs inside the call that completes a tail block (no second stream) never uses that slack, so a tail stage with
-  // delay ONE -- the input block that ends at sample m*B meets partition 0 in the output block that starts there -- is as
-  // causal, and the period it frees buys one of two things:
-  //   WIDEN  the same IR[2T, ..) at block 2T: same zero-latency stage, HALF the tail partitions at twice the size -- half the
-  //          multiply-adds and half the IR-spectra and delay-line bytes per sample of the tail's sweeps (BASELINE config 3's
-  //          350-partition sweep is multiply-add bound: 9.1 -> 10.9-11.1 Gsamples/s), the same bytes per sample in its patches
-  //          and transforms. Float32 transforms only (a 16384-bin double transform does not fit one CU's LDS);
-  //   SHRINK the tail at block T takes IR[T, ..): the zero-latency stage covers IR[0, T), HALF its partitions (config 5's
-  //          geometry, 4 -> 2 partitions of 4096: its per-block delay line is a third of the step).
-  // For lock-step sets of many channels with time tiling on (small sets keep the reference's geometry, the reference-order
-  // measurement runs keep the reference's structure): long tails are widened, the others shrink the zero-latency stage
-  // (measured on MI355X, profiles/r4_tail_slack.txt).
-  int td = 2;
-  const size_t longest_set = std::max(longest, s->longest_hint);
-  if (two_stage && !no_resize && longest_set > split && (s->flags & RVC_FLAG_NO_TIME_TILING) == 0) {
-    const size_t pt_req = (longest_set - split + tb - 1) / tb;
-    const bool can_widen = !want64 && !stage64(tb) && 2 * tb <= max_block && tb >= 64;
-    int mode = g_tune.tail_slack;
-    const size_t widen_min = 2 * tb < (size_t)RVC_MAX_BLOCK ? (size_t)kWidenMinPShort : (size_t)kWidenMinP;
-    if (mode < 0) mode = s->nch < kSlackMinChannels ? 0 : ((can_widen && pt_req >= widen_min) ? 1 : 2);
-    if (mode == 1 && can_widen) { td = 1; tb *= 2; }       // (split = 2T = td * tb)
-    else if (mode == 2 && hb < tb) { td = 1; split = tb; }
-  }
 
   // partition counts (ceil(float/float) as FFTConvolver.cpp:115; exact below 2^24 samples)
   std::vector<size_t> lenA(s->nch);   // samples the zero-latency stage covers; the tail and wide
@@ -2101,6 +2124,17 @@ int rvc_debug_fence_probe(rvc_set *s) {
       return (in == hipSuccess && out != hipSuccess) ? 1 : 0;
     }
   return -1;
+}
+
+int rvc_debug_plan(int n_channels, unsigned flags, size_t head_block, size_t tail_block, size_t longest_ir,
+                   size_t *head_run, size_t *tail_run, size_t *zero_latency_samples) {
+  if (n_channels < 1 || head_block == 0 || tail_block == 0) return 0;
+  if (head_block > tail_block) std::swap(head_block, tail_block);   // TwoStageFFTConvolver.cpp:100-104
+  const StagePlan p = plan_stages(n_channels, flags, g_tune.tail_slack, head_block, tail_block, true, longest_ir);
+  if (head_run) *head_run = p.hb;
+  if (tail_run) *tail_run = p.tb;
+  if (zero_latency_samples) *zero_latency_samples = p.split;
+  return p.td;
 }
 
 int rvc_debug_set_tuning(const char *key, int value) {

@@ -1170,6 +1170,9 @@ def test_tail_slack_policy_and_children():
             s = reevr_amd.ConvolverSet(nch, bg_stream=kw.pop("bg_stream", False), **kw)
             assert s.init(head, tail, irs, max_len=head), s.last_error_string
         assert (s.partitions(0), s.tail_block, s.partitions(1)) == expect, (kw, s.partitions(0), s.tail_block, s.partitions(1))
+        if not kw and subsets < 0:           # ... which is what the pure plan function (the CPU tests pin it) says for this request
+            plan = reevr_amd.stage_plan(nch, head, tail, max(len(i) for i in irs))
+            assert (plan["partitions"][0], plan["tail_block"], plan["partitions"][1]) == expect
         if subsets > 1:
             assert s.subsets == subsets
         got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()

@@ -62,6 +62,38 @@ def test_bench_traffic_lookup_is_keyed_on_the_launch_size():
         assert b.load_traffic(per_launch, cfg, False) == ({}, None)       # (measured with the time tiling on)
 
 
+def test_stage_plan_policy():
+    """rvc_debug_plan (the pure function rvc_set_init applies, rvc_engine.cpp plan_stages): the reference's structure -- zero-latency
+    stage over IR[0,2T), tail at block T two blocks late (TwoStageFFTConvolver.cpp:117-138, :213-222) -- for small sets, sets with
+    the tail on a second stream, fixed partitions or the reference-order schedule; for lock-step sets of >= 256 channels the tail one
+    block late: at block 2T for tails of >= 128 partitions (>= 48 when 2T < 16384), else over IR[T,..) with half the zero-latency
+    stage. Partition counts of the three BASELINE geometries as bench.py measures them."""
+    import reevr_amd
+    from reevr_amd import _lib as L
+    P = reevr_amd.stage_plan
+    ref2 = {"head_block": 512, "tail_block": 8192, "zero_latency_samples": 16384, "tail_delay": 2, "partitions": (32, 57)}
+    assert P(2, 512, 8192, 480000) == ref2 and P(255, 512, 8192, 480000) == ref2            # the plug-in's pair; below the threshold
+    for flag in (L.RVC_FLAG_BG_STREAM, L.RVC_FLAG_FIXED_PARTITIONS, L.RVC_FLAG_NO_TIME_TILING):
+        assert P(4096, 512, 8192, 480000, flag) == ref2
+    assert P(4096, 512, 8192, 480000) == dict(ref2, zero_latency_samples=8192, tail_delay=1, partitions=(16, 58))      # config 2: shrunk
+    assert P(2048, 256, 8192, 2880000) == {"head_block": 256, "tail_block": 16384, "zero_latency_samples": 16384, "tail_delay": 1,
+                                           "partitions": (64, 175)}                                                 # config 3: widened
+    assert P(4096, 4096, 8192, 240000)["partitions"] == (2, 29)                                                       # config 5's geometry
+    assert P(2048, 256, 8192, 2880000, L.RVC_FLAG_FFT_F64_LONG)["partitions"] == (32, 351)    # double tail transforms: no 16384-bin form
+    assert P(2048, 256, 8192, 2880000, L.RVC_FLAG_FFT_F64)["tail_block"] == 8192
+    assert P(4096, 512, 8192, 2 * 8192 + 127 * 8192)["tail_block"] == 8192 and P(4096, 512, 8192, 2 * 8192 + 128 * 8192)["tail_block"] == 16384
+    assert P(4096, 256, 2048, 2 * 2048 + 48 * 2048)["tail_block"] == 4096 and P(4096, 256, 2048, 2 * 2048 + 47 * 2048)["tail_block"] == 2048
+    assert P(4096, 512, 8192, 16384) == dict(ref2, partitions=(32, 0))        # no tail at the reference's geometry: nothing to move
+    assert P(4096, 8192, 8192, 480000)["tail_delay"] == 2                     # head = tail: there is no zero-latency stage to shrink
+    assert P(4096, 8192, 512, 480000) == P(4096, 512, 8192, 480000)           # head > tail: swapped like the reference (:100-104)
+    with reevr_amd.tuning(tail_slack=0):
+        assert P(4096, 512, 8192, 480000) == ref2
+    with reevr_amd.tuning(tail_slack=1):
+        assert P(2, 512, 8192, 480000, L.RVC_FLAG_FFT_F32)["tail_block"] == 16384 and P(2, 512, 8192, 480000)["tail_block"] == 8192
+    with pytest.raises(ValueError):
+        P(0, 512, 8192, 1000)
+
+
 class _SetGeometry:
     """what bench.executed_bytes asks a ConvolverSet for"""
 
