@@ -1166,11 +1166,12 @@ def test_tail_slack_policy_and_children():
     def run(nch, lens, expect, subsets=-1, reinit=False, **kw):
         irs = [synth.synth_ir(lens[c % len(lens)] - (c % 7), 1, 800 + c % 11)[0] for c in range(nch)]
         x = x1[np.arange(nch) % 4]
+        plain = not kw and subsets < 0      # (a set created without flags or forced children: what reevr_amd.stage_plan describes)
         with reevr_amd.tuning(subsets=subsets):
             s = reevr_amd.ConvolverSet(nch, bg_stream=kw.pop("bg_stream", False), **kw)
             assert s.init(head, tail, irs, max_len=head), s.last_error_string
         assert (s.partitions(0), s.tail_block, s.partitions(1)) == expect, (kw, s.partitions(0), s.tail_block, s.partitions(1))
-        if not kw and subsets < 0:           # ... which is what the pure plan function (the CPU tests pin it) says for this request
+        if plain:                            # ... which is what the pure plan function (the CPU tests pin it) says for this request
             plan = reevr_amd.stage_plan(nch, head, tail, max(len(i) for i in irs))
             assert (plan["partitions"][0], plan["tail_block"], plan["partitions"][1]) == expect
         if subsets > 1:
