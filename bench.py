@@ -607,6 +607,160 @@ def small_regimes(torch, reevr_amd, synth, KERNEL_NAMES, local_rank: int, steps:
     return out
 
 
+def self_launch(n: int, n_devices: int):
+    """`python bench.py --gpus N` typed bare (no WORLD_SIZE in the environment): start the N ranks ourselves -- this process
+    becomes `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` on a free port, one rank
+    per GPU over RCCL; rank 0 prints the line. On a box with fewer than N devices the ranks share device 0 over gloo
+    (REEVR_BENCH_SAME_DEVICE=1; the line says `shared_device`): the control flow, not a scaling measurement."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    if n_devices < n:
+        env["REEVR_BENCH_SAME_DEVICE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def write_full(full: dict, where: str = ""):
+    """The full record (tens of KB) goes to a file, never to the line the driver parses."""
+    outs = [where] if where else [os.path.join(ROOT, "bench_full.json")]
+    if not where and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        outs.append(os.path.join(ROOT, "gpurun_out", "bench_full.json"))
+    done = []
+    for o in outs:
+        try:
+            with open(o, "w") as f:
+                json.dump(full, f, indent=1)
+            done.append(os.path.relpath(o, ROOT) if o.startswith(ROOT) else o)
+        except OSError:
+            pass
+    return done
+
+
+# kernel family -> a substring of the rocprofv3 kernel name (the committed kernel-trace summaries list C++ names)
+FAMILY_KERNEL = {"fused_block": "k_fused_block", "fir_tail": "k_fdl_patch<1", "fir_head": "k_fdl_patch<0", "fft_fwd_tail": "k_fft8_fwd",
+                 "fft_inv_tail": "k_fft8_inv"}
+
+
+def rocprof_cross_check(roof: dict, cfg: int, one_queue: bool) -> dict:
+    """The committed `rocprofv3 --kernel-trace --stats` summary of this command (profiles/r5_config<C>/kernel_stats*.csv, older
+    rounds as a fallback): the dominant kernel's average duration there, and the fraction of the HBM peak it gives with this
+    run's bytes per launch -- the figure DESIGN.md quotes; `frac` beside it is this run's own HIP-event measurement."""
+    import csv
+    pat = FAMILY_KERNEL.get(roof.get("kernel", ""))
+    if not pat or not roof.get("bytes_per_launch"):
+        return {}
+    for rnd in ("r5", "r4"):
+        f = os.path.join(ROOT, "profiles", "%s_config%d" % (rnd, cfg), "kernel_stats_one_queue.csv" if one_queue else "kernel_stats.csv")
+        if not os.path.exists(f):
+            continue
+        rows = [r for r in csv.DictReader(open(f)) if pat in r["Name"]]
+        if not rows:
+            continue
+        r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        avg_ms = float(r["AverageNs"]) * 1e-6
+        return {"rocprof_avg_launch_ms": round(avg_ms, 5), "frac_rocprof": round(roof["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "rocprof_summary": os.path.relpath(f, ROOT)}
+    return {}
+
+
+COMPACT_LIMIT = 4096
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_line(full: dict, full_path=None) -> dict:
+    """The ONE line the driver parses, from the full record: the contract's keys, `roofline` of the dominant kernel,
+    `cpu_baseline`, the probe, and a handful of scalars per other configuration / regime. Always < COMPACT_LIMIT bytes:
+    optional groups are dropped (never the contract's keys) should a run produce more."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                        "vs_baseline", "dtype", "data"))
+    cfg = full.get("config") or {}
+    line["config"] = _pick(cfg, ("workload", "baseline_config", "channels_per_gpu", "instances_total", "frames_per_channel_per_step",
+                                 "host_block", "calls_per_step", "partitions", "tail_stage", "tail_block_run", "tile_blocks", "subsets",
+                                 "resident_GB", "schedule", "gather", "gathered_channels_per_gpu", "gather_matches_output", "devices",
+                                 "shared_device", "tune"))
+    if len(str(line["config"].get("workload", ""))) > 200:
+        line["config"]["workload"] = line["config"]["workload"][:197] + "..."
+    roof = full.get("roofline")
+    if roof:
+        r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms",
+                         "traffic_over_model", "alg_frac_reference_schedule", "alg_equiv", "frac_whole_step_executed_bytes",
+                         "default_run_frac", "rocprof_avg_launch_ms", "frac_rocprof", "rocprof_summary"))
+        for k in ("traffic_source", "measured_in"):
+            if roof.get(k):
+                r[k] = str(roof[k])[:120]
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    pr = full.get("probe")
+    line["probe"] = {"ok": pr["ok"], "rms_error": float("%.3g" % pr["rms_error"])} if pr else None
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "cpu_model"))
+        c["sample"] = str(cb.get("sample", ""))[:160]
+        if cb.get("all_cores"):
+            c["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    optional = []
+    others = {}
+    for key in ("config1", "config3", "config5"):
+        ent = full.get(key)
+        if ent:
+            others[key[-1]] = {"Msamples_s": ent["value"], "exec_frac": ent.get("frac_of_hbm_peak_executed_bytes"),
+                               "ref_schedule_alg_frac": ent.get("alg_frac_reference_schedule"),
+                               "one_queue_Msamples_s": (ent.get("one_queue") or {}).get("value"),
+                               "cpu_1thread_Msamples_s": (ent.get("cpu_baseline") or {}).get("value"),
+                               "probe_ok": bool(ent.get("probe") and ent["probe"]["ok"])}
+    if others:
+        line["other_configs"] = others
+        optional.append("other_configs")
+    side = {}
+    if full.get("reference_schedule"):
+        side["reference_schedule_Msamples_s"] = full["reference_schedule"]["value"]
+    if full.get("one_queue"):
+        side["one_queue_Msamples_s"] = full["one_queue"]["value"]
+    sb = full.get("stereo_block_sync")
+    if sb:
+        side["stereo_pair_us_per_block"] = sb["us_per_block"]
+        side["stereo_pair_host_call_us_median"] = sb["host_call_us_median"]
+    reg = full.get("regimes")
+    if reg:
+        sw = reg.get("channel_sweep", {})
+        for ch in ("2", "16", "64", "256", "1024"):
+            if isinstance(sw.get(ch), dict):
+                side["ch%s_Msamples_s" % ch] = sw[ch]["value"]
+                side["ch%s_us_per_block" % ch] = sw[ch]["us_per_block"]
+        for k in ("config5_literal", "fft_f64", "fft_f64_long"):
+            if k in reg:
+                side[k + "_Msamples_s"] = reg[k]["value"]
+    if side:
+        line["side"] = side
+        optional.insert(0, "side")
+    if full_path:
+        line["full_record"] = full_path
+    for k in optional + ["full_record"]:                 # never reached by a normal run: shed optional groups, largest last
+        if len(json.dumps(line)) < COMPACT_LIMIT:
+            break
+        line.pop(k, None)
+    if len(json.dumps(line)) >= COMPACT_LIMIT:           # a pathological workload string or partitions table
+        line["config"] = _pick(line["config"], ("workload", "baseline_config", "channels_per_gpu", "host_block"))
+        line["config"]["workload"] = str(line["config"].get("workload", ""))[:80]
+    assert len(json.dumps(line)) < COMPACT_LIMIT
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -634,6 +788,8 @@ def main():
     ap.add_argument("--ir-len", type=int, default=0, help="measurement hook: impulse length in samples instead of the configuration's (the "
                     "line then is NOT the BASELINE configuration: config.workload says so)")
     ap.add_argument("--tune", type=str, default="", help="rvc_debug_set_tuning knobs, e.g. k1=32,subsets=2 (measurement hook)")
+    ap.add_argument("--full-out", type=str, default="", help="where the full record goes (default: bench_full.json beside bench.py, "
+                    "and gpurun_out/bench_full.json where that directory exists)")
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a stuck run dumps every thread's stack and exits (0: off)")
     args = ap.parse_args()
@@ -654,11 +810,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, torch.cuda.device_count())        # does not return: the ranks print the line
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with "
-                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
-    # development switch: all ranks on GPU 0 over gloo, to exercise the N > 1 control flow on a 1-GPU box
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: a launcher started {world} ranks for a {args.gpus}-GPU run "
+                         f"(bare `python bench.py --gpus {args.gpus} ...` starts its own ranks)")
+    # all ranks on GPU 0 over gloo: the N > 1 control flow on a box with fewer devices than ranks (self_launch sets it there)
     same_device = os.environ.get("REEVR_BENCH_SAME_DEVICE") == "1"
+    devices = [0] * world if same_device else list(range(world))
     if same_device:
         local_rank = 0
     dist = None
@@ -942,6 +1101,7 @@ def main():
                          "traffic_source": otsrc, "measured_in": "one_queue leg of this run (RVC_FLAG_NO_SUBSETS, same channels / inputs / "
                                                                  "call pattern); value / ms_per_step: the default run (child sets)"})
     if roof is not None:
+        roof.update(rocprof_cross_check(roof, args.config, one_queue="default_run_frac" in roof))
         roof["probe_ok"] = bool(probe and probe["ok"])
         roof["frac_whole_step_executed_bytes"] = path["frac_of_hbm_peak"]
         if roof.get("traffic") and roof.get("bytes_per_launch"):
@@ -949,7 +1109,7 @@ def main():
         if roof.get("default_run_traffic") and roof.get("default_run_bytes_per_launch"):
             roof["default_run_traffic_over_model"] = round(roof["default_run_traffic"] / roof["default_run_bytes_per_launch"], 4)
 
-    line = {
+    full = {
         "metric": "Msamples/s convolved (stereo, 10s IR, block=512); % HBM roofline",
         "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
@@ -969,7 +1129,7 @@ def main():
                             "one process_device() per %d-frame host block for all channels (rvc_set_process_device_blocks), "
                             "device-resident I/O, %d input/output batches rotated" % (host_block, nbuf)),
                    "tile_period_steps": ls_period, "pre_roll_steps": pre, "gather": do_gather, "gathered_channels_per_gpu": gch if do_gather else 0,
-                   "gather_matches_output": gather_ok, "tune": args.tune, **summary,
+                   "gather_matches_output": gather_ok, "tune": args.tune,
                    "sharding": "instances dealt to ranks, equal shards, no data-path collective"
                                + (f"; one RCCL all_gather of the output blocks of {gch} channels per GPU per step, overlapped with the next step" if do_gather else "")},
         "roofline": roof,
@@ -979,11 +1139,18 @@ def main():
         "kernels_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()},
         **side,
         "regimes": regimes,
+        "summary": summary,
         "cpu_baseline": cpu,
         **others,
         "init_ms": round(init_ms, 2), "synth_s": round(synth_s, 2),
     }
-    print(json.dumps(line), flush=True)
+    full["config"]["devices"] = devices
+    full["config"]["shared_device"] = same_device
+    # The whole record goes to a side file (its path on an EARLIER stdout line); the LAST stdout line is the compact
+    # (< 4 KB) line the driver parses: contract keys, roofline, cpu_baseline, probe and a dozen scalars of the other configs.
+    paths = write_full(full, args.full_out)
+    print("bench.py: full record (per-family rooflines, regimes, the other configurations) -> " + ", ".join(paths), flush=True)
+    print(json.dumps(compact_line(full, paths[0] if paths else None)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

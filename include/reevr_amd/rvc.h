@@ -224,6 +224,39 @@ int rvc_set_subsets(const rvc_set *s);
 int rvc_last_error(const rvc_set *s);
 const char *rvc_last_error_string(const rvc_set *s);
 
+/* What the set actually runs -- everything an integrator would otherwise infer from rvc_set_tail_block() == 2T and the
+ * thresholds in the RVC_MAX_BLOCK comment above: stage blocks, partitions, the tail's delay, transform precision, time tiles,
+ * child sets. Filled from the state of the last init (all zero before it; `live` = 0 after an init with empty impulses).
+ * The reference's structure (TwoStageFFTConvolver.cpp:117-138) is head_block / tail_block as requested (rounded to powers of
+ * two), zero_latency_samples = 2 * tail_block, tail_delay = 2, no tiles, one set: `reference_structure` says whether the stage
+ * SPLIT is that one (tiling and child sets never change it). */
+typedef struct rvc_plan {
+  int channels;                 /* of the whole set */
+  int subsets;                  /* child sets serving it (1 = none), rvc_set_subsets */
+  int initialised;              /* an init has succeeded */
+  int live;                     /* device state exists (non-empty impulses) */
+  int two_stage;                /* 1 TwoStageFFTConvolver form, 0 one uniform FFTConvolver */
+  int tail_on_second_stream;    /* RVC_FLAG_BG_STREAM */
+  size_t head_block;            /* block of the zero-latency stage (after rounding / clamping) */
+  size_t tail_block;            /* block the tail stage RUNS (2T for the widened form); 0 for a uniform set */
+  size_t max_len;
+  size_t zero_latency_samples;  /* impulse samples [0, this) are served by the zero-latency stage (head + tail0 of the reference
+                                   merged): 2T, or T for the shrunk form; 0 for a uniform set (all of it) */
+  int head_partitions;          /* partitions of the zero-latency stage, the tail stage, the wide stage (largest over channels) */
+  int tail_partitions;
+  int wide_partitions;
+  int tail_delay;               /* tail blocks between an input block and its first contribution: 2 (the reference's), 1, 0 = no tail */
+  int head_f64, tail_f64;       /* that stage's transforms run in double */
+  int head_tile_blocks;         /* blocks per first-level time tile of the stage's delay line: 0 not tiled, 8 one level, 16 / 32 two */
+  int tail_tile_blocks;
+  int block_path;               /* per-block calls: 0 one fused launch per block, 1 transform / delay line / inverse launches */
+  int reference_structure;      /* 1: stage split and tail delay are the reference's for these block sizes */
+  size_t long_call_block;       /* block of the whole-IR delay line long calls use (adaptive partitioning), 0 = none */
+  size_t wide_block;            /* block of the wide stage very long calls use, 0 = none */
+} rvc_plan;
+/* plan_size = sizeof(rvc_plan) as the caller compiled it (the struct may grow at its end). 1 = filled. */
+int rvc_set_plan(const rvc_set *s, rvc_plan *plan, size_t plan_size);
+
 /* With RVC_FLAG_TIMING: accumulated HIP-event time of one kernel family since the last
  * rvc_set_kernel_time_reset. kernel: 0 ingest, 1 fft_fwd(head) 2 fir(head) 3 fft_inv(head),
  * 4 fft_fwd(tail) 5 fir(tail; time-tiled streaming: the patch launches) 6 fft_inv(tail), 7 fused single-block step,
@@ -360,6 +393,12 @@ int rvc_send_pre_device(int device, void *stream, const rvc_send_params *p);
 /* Number of visible HIP devices (0 when there is none or the runtime cannot start). */
 int rvc_device_count(void);
 const char *rvc_version(void);
+/* Bumped whenever the meaning of an existing entry changes. 2 (round 4/5): rvc_set_stream(s, which) of a set WITH child sets --
+ * which = 0 is the set's one ordering stream (child 0's foreground stream), 1 is NULL, child k's streams are 2 + 2 k / 3 + 2 k
+ * (version 1: 2 k / 2 k + 1); RVC_FLAG_CHILD_SETS means "child sets unfenced" (version 1: "enable child sets"; they are now the
+ * default for >= 2048 block-synchronous channels); rvc_set_plan added. Check it when linking against a prebuilt library. */
+#define RVC_ABI_VERSION 2
+int rvc_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -44,8 +44,18 @@ int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int d
 int rvc_debug_plan(int n_channels, unsigned flags, size_t head_block, size_t tail_block, size_t longest_ir,
                    size_t *head_run, size_t *tail_run, size_t *zero_latency_samples);
 
-/* Measurement hook (bench.py, tools/): process-wide schedule knobs, read when a set is initialised. Returns 1 if the
- * key is known. Keys: "k1" first-level tile of long delay lines (8 = one level, 16 default, 32); "sweep_split" -1 auto /
+/* rvc_set_create with measurement knobs of the set's own: `knobs` = "key=value,key=value" (the keys of rvc_debug_set_tuning)
+ * on top of the current defaults. A set's knobs are fixed when it is created and are its alone -- sets created or used on other
+ * threads are not affected (the reference's contract: init on one handle concurrently with process on another,
+ * src/PluginProcessor.cpp:1680-1691). NULL for an unknown key / malformed item. */
+rvc_set *rvc_set_create_tuned(int n_channels, int device, unsigned flags, const char *knobs);
+/* The value the engine SHIPS with for a knob (whatever rvc_debug_set_tuning has set since); 1 if the key is known.
+ * rvc_debug_tuning_keys: every key, comma-separated. */
+int rvc_debug_tuning_default(const char *key, int *value);
+const char *rvc_debug_tuning_keys(void);
+
+/* Measurement hook (bench.py, tools/): the DEFAULTS sets created afterwards start with (a set copies them once, in
+ * rvc_set_create; existing sets keep theirs). Returns 1 if the key is known. Keys: "k1" first-level tile of long delay lines (8 = one level, 16 default, 32); "sweep_split" -1 auto /
  * 0 own-tile / 1 partition-split sweeps; "fft_loop" -1 auto / 0 / 1 row-looping 8192-bin transforms; "subsets" -1 auto /
  * n children of a many-channel set; "guard" 0 / 1 guard bands around every device allocation (see rvc_debug_guard_check) / 2 every
  * allocation END-aligned against an unmapped address range (an out-of-bounds access faults: tools/fence_fuzz.py only);
@@ -53,7 +63,8 @@ int rvc_debug_plan(int n_channels, unsigned flags, size_t head_block, size_t tai
  * 0 sweeps and patches on long rows take channel c's bin tiles in the order rotated by c; "tail_slack" what the tail's period of
  * slack buys (rvc.h, RVC_MAX_BLOCK): -1 by size / 0 nothing (the reference's structure, delay 2) / 1 a tail at twice the block /
  * 2 half the zero-latency stage, wherever supported (tests force both on small sets); "sweep_lds", "fft_many", "kid_fence",
- * "sweep_lw", "sweep_d", "patch_nt", "block_occ": kernel / schedule variants (rvc_internal.h, rvc_engine.cpp Tuning). */
+ * "sweep_lw", "sweep_d", "patch_nt", "block_occ", "mac3": kernel / schedule variants (rvc_internal.h LaunchTune, rvc_engine.cpp
+ * Tuning). */
 int rvc_debug_set_tuning(const char *key, int value);
 /* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set
  * is initialised, every device allocation of the set lies between two 256 KiB guard bands filled with 0xFF and starts out

@@ -95,12 +95,27 @@ SIGNATURES = {
     "rvc_debug_guard_check": (C.c_long, [C.c_void_p]),
     "rvc_debug_fence_probe": (C.c_int, [C.c_void_p]),
     "rvc_debug_plan": (C.c_int, [C.c_int, C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t] + [C.POINTER(C.c_size_t)] * 3),
+    "rvc_set_create_tuned": (C.c_void_p, [C.c_int, C.c_int, C.c_uint, C.c_char_p]),
+    "rvc_debug_tuning_default": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "rvc_debug_tuning_keys": (C.c_char_p, []),
+    "rvc_set_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rvc_device_count": (C.c_int, []),
     "rvc_version": (C.c_char_p, []),
+    "rvc_abi_version": (C.c_int, []),
 }
+RVC_ABI_VERSION = 2
 
 RVC_IMPULSE_FFT_SIZE = 4096
 RVC_IMPULSE_LUT_SIZE = RVC_IMPULSE_FFT_SIZE // 2 + 1
+
+
+class Plan(C.Structure):                # struct rvc_plan
+    _fields_ = [("channels", C.c_int), ("subsets", C.c_int), ("initialised", C.c_int), ("live", C.c_int), ("two_stage", C.c_int),
+                ("tail_on_second_stream", C.c_int), ("head_block", C.c_size_t), ("tail_block", C.c_size_t), ("max_len", C.c_size_t),
+                ("zero_latency_samples", C.c_size_t), ("head_partitions", C.c_int), ("tail_partitions", C.c_int),
+                ("wide_partitions", C.c_int), ("tail_delay", C.c_int), ("head_f64", C.c_int), ("tail_f64", C.c_int),
+                ("head_tile_blocks", C.c_int), ("tail_tile_blocks", C.c_int), ("block_path", C.c_int),
+                ("reference_structure", C.c_int), ("long_call_block", C.c_size_t), ("wide_block", C.c_size_t)]
 
 
 class ImpulseParams(C.Structure):       # struct rvc_impulse_params

@@ -34,13 +34,14 @@ class ConvolverSet:
 
     def __init__(self, n_channels: int, device: int = 0, bg_stream: bool = False, timing: bool = False,
                  fft_f64: bool = False, fixed_partitions: bool = False, time_tiling=True,
-                 fft_f32: bool = False, child_sets=None, fft_f64_long: bool = False):
+                 fft_f32: bool = False, child_sets=None, fft_f64_long: bool = False, tune=None):
         """time_tiling: True (by size) / False / "force" (every stage, one level unless long) / "force2" (two levels).
         fft_f64 / fft_f32: every transform in double / in float (default: rvc.h, RVC_FLAG_FFT_F64); fft_f64_long: the small
         sets' default rule (double for partitions of 2048 .. 8192 samples) whatever the channel count (RVC_FLAG_FFT_F64_LONG).
         child_sets: None / True = the engine's default (sets of thousands of block-synchronous channels are served by child sets on
         their own streams, fenced internally), False = RVC_FLAG_NO_SUBSETS (one set on one queue: per-launch profiling),
-        "unfenced" = RVC_FLAG_CHILD_SETS (no fences inside the calls: rvc_set_fork / rvc_set_join around each ordered call here)."""
+        "unfenced" = RVC_FLAG_CHILD_SETS (no fences inside the calls: rvc_set_fork / rvc_set_join around each ordered call here).
+        tune: dict of measurement knobs for THIS set only (rvc_set_create_tuned; keys: reevr_amd.TUNING_DEFAULTS)."""
         self._lib = L.lib()
         flags = ((L.RVC_FLAG_BG_STREAM if bg_stream else 0) | (L.RVC_FLAG_TIMING if timing else 0)
                  | (L.RVC_FLAG_FFT_F64 if fft_f64 else 0) | (L.RVC_FLAG_FFT_F32 if fft_f32 else 0)
@@ -53,7 +54,13 @@ class ConvolverSet:
         self.unfenced = child_sets == "unfenced"
         self.n_channels = int(n_channels)
         self.device = int(device)
-        self._h = self._lib.rvc_set_create(self.n_channels, self.device, flags)
+        if tune:
+            knobs = ",".join("%s=%d" % (k, int(v)) for k, v in tune.items())
+            self._h = self._lib.rvc_set_create_tuned(self.n_channels, self.device, flags, knobs.encode())
+            if not self._h:
+                raise KeyError(f"rvc_set_create_tuned refused {knobs!r}")
+        else:
+            self._h = self._lib.rvc_set_create(self.n_channels, self.device, flags)
         if not self._h:
             raise RvcError("rvc_set_create failed")
 
@@ -251,6 +258,13 @@ class ConvolverSet:
     def subsets(self) -> int:
         return int(self._lib.rvc_set_subsets(self._h))
 
+    def plan(self) -> dict:
+        """What the set runs (rvc_set_plan): stage blocks, partitions, tail delay, precision, tiles, child sets."""
+        p = L.Plan()
+        if not self._lib.rvc_set_plan(self._h, C.byref(p), C.sizeof(p)):
+            raise RvcError("rvc_set_plan failed")
+        return {name: getattr(p, name) for name, _ in L.Plan._fields_}
+
     def stream(self, which: int = 0) -> int:
         return int(self._lib.rvc_set_stream(self._h, which) or 0)
 
@@ -299,7 +313,7 @@ KERNEL_NAMES = ["ingest", "fft_fwd_head", "fir_head", "fft_inv_head", "fft_fwd_t
 
 
 def set_tuning(key: str, value: int) -> bool:
-    """Process-wide schedule knob, read when a set is initialised (rvc_debug_set_tuning; measurement hook)."""
+    """Default of a schedule knob for the sets created afterwards (rvc_debug_set_tuning; measurement hook)."""
     return bool(L.lib().rvc_debug_set_tuning(key.encode(), int(value)))
 
 
@@ -316,15 +330,57 @@ def stage_plan(n_channels: int, headBlockSize: int, tailBlockSize: int, longest_
             "partitions": (-(-min(longest_ir, zl.value) // hb.value), -(-max(longest_ir - zl.value, 0) // tb.value))}
 
 
-# the engine's defaults of the process-wide knobs (rvc_debug_set_tuning): what `tuning` restores on exit
-TUNING_DEFAULTS = {"fft_many": -1, "k1": 0, "two_level_min_p": -1, "fft_loop": -1, "subsets": -1, "guard": 0, "kid_fence": 1, "tail_slack": -1, "sweep_split": -1,
-                   "sweep_lw": 0, "sweep_d": 0, "sweep_lds": -1, "patch_nt": 1, "block_occ": 0, "tile_rot": 1}
+def _tuning_defaults() -> dict:
+    """The knobs and the values the engine ships with, from the library itself (rvc_debug_tuning_keys / _default)."""
+    lib = L.lib()
+    out = {}
+    for key in lib.rvc_debug_tuning_keys().decode().split(","):
+        v = C.c_int(0)
+        assert lib.rvc_debug_tuning_default(key.encode(), C.byref(v))
+        out[key] = v.value
+    return out
+
+
+class _LazyDefaults(dict):
+    """TUNING_DEFAULTS: filled from the library on first use (importing the package must not need the built library)."""
+
+    def _fill(self):
+        if not dict.__len__(self):
+            dict.update(self, _tuning_defaults())
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def __contains__(self, k):
+        self._fill()
+        return dict.__contains__(self, k)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+
+# the knobs rvc_debug_set_tuning / ConvolverSet(tune=...) know, with the values the engine ships with (what `tuning` restores)
+TUNING_DEFAULTS = _LazyDefaults()
 
 
 class tuning:
-    """`with reevr_amd.tuning(sweep_lds=0, k1=32): ...` -- set process-wide schedule knobs for the sets initialised inside the
-    block and put the engine's defaults back on the way out, also when the block raises (a test that fails between a
-    set_tuning and its reset would otherwise leak the knob into every later set of the process)."""
+    """`with reevr_amd.tuning(sweep_lds=0, k1=32): ...` -- change the knob DEFAULTS for the sets CREATED inside the block (a
+    set copies them when it is created and keeps them) and put the engine's defaults back on the way out, also when the block
+    raises. Process-wide while the block runs: concurrent code uses ConvolverSet(tune={...}) instead (the set's own knobs)."""
 
     def __init__(self, **knobs):
         unknown = [k for k in knobs if k not in TUNING_DEFAULTS]

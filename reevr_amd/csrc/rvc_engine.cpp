@@ -114,18 +114,65 @@ struct Tile {
   long long group(long long b) const { return t0 + (b - t0) / rvc::kSweepRows * rvc::kSweepRows; }
 };
 
-// process-wide measurement knobs (rvc_debug_set_tuning); the defaults are what the engine ships with
+// Measurement knobs. Every set owns a copy, fixed when the set is created (rvc_set_create: the defaults below as
+// rvc_debug_set_tuning has changed them so far; rvc_set_create_tuned: those plus the knobs named in the call; child sets: their
+// parent's), so a knob set by one thread never changes the plan of a handle another thread is initialising (the reference's
+// contract: init on one handle concurrently with process on another, src/PluginProcessor.cpp:1680-1691).
 struct Tuning {
   int k1 = 0;             // first-level tile of delay lines with more than kTwoLevelMinP partitions: 0 by length, else 8 / 16 / 32
   int two_min_p = -1;     // "two_level_min_p": delay lines with MORE partitions than this get two levels (-1: kTwoLevelMinP)
-  int fft_loop = -1;      // row-looping form of the 8192-bin transforms: -1 by size, 0 never, 1 always
   int subsets = -1;       // children of a many-channel set: -1 by size, else the count
   int tail_slack = -1;    // "tail_slack": what the tail's period of slack buys (do_init): -1 by size, 0 nothing (delay 2, the reference's
                           // structure), 1 a tail at twice the block, 2 half the zero-latency stage -- wherever supported
   int kid_fence = 1;      // "kid_fence" (measurement): 0 = no fences between a set's stream and its child sets', 2 = fences but no parent stream work
   int guard = 0;          // 1: NaN-filled guard bands around (and NaN poison inside) every device allocation of a set
+  rvc::LaunchTune launch; // kernel variants the launchers choose between (rvc_internal.h)
 };
-Tuning g_tune;
+// key -> member: the one table behind rvc_debug_set_tuning / rvc_set_create_tuned / rvc_debug_tuning_default
+struct TuneKey { const char *key; int Tuning::*m; int rvc::LaunchTune::*lm; };
+const TuneKey kTuneKeys[] = {
+    {"k1", &Tuning::k1, nullptr}, {"two_level_min_p", &Tuning::two_min_p, nullptr}, {"subsets", &Tuning::subsets, nullptr},
+    {"tail_slack", &Tuning::tail_slack, nullptr}, {"kid_fence", &Tuning::kid_fence, nullptr}, {"guard", &Tuning::guard, nullptr},
+    {"fft_loop", nullptr, &rvc::LaunchTune::fft_loop}, {"fft_many", nullptr, &rvc::LaunchTune::fft_many},
+    {"tile_rot", nullptr, &rvc::LaunchTune::tile_rot}, {"block_occ", nullptr, &rvc::LaunchTune::block_occ},
+    {"patch_nt", nullptr, &rvc::LaunchTune::patch_nt}, {"sweep_split", nullptr, &rvc::LaunchTune::sweep_split},
+    {"sweep_lw", nullptr, &rvc::LaunchTune::sweep_lw}, {"sweep_d", nullptr, &rvc::LaunchTune::sweep_d},
+    {"sweep_lds", nullptr, &rvc::LaunchTune::sweep_lds}, {"mac3", nullptr, &rvc::LaunchTune::mac3},
+};
+int *tune_slot(Tuning &t, const std::string &key) {
+  for (const TuneKey &k : kTuneKeys)
+    if (key == k.key) return k.m ? &(t.*(k.m)) : &(t.launch.*(k.lm));
+  return nullptr;
+}
+// what sets created from now on start with: rvc_debug_set_tuning writes here (under the mutex; a set copies it once, at create)
+Tuning g_tune_defaults;
+std::mutex g_tune_mutex;
+Tuning tune_defaults_now() {
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  return g_tune_defaults;
+}
+// "k1=32,subsets=2" on top of t; false on an unknown key / malformed item
+bool apply_knobs(Tuning &t, const char *knobs) {
+  if (!knobs) return true;
+  const std::string all(knobs);
+  size_t pos = 0;
+  while (pos < all.size()) {
+    size_t end = all.find(',', pos);
+    if (end == std::string::npos) end = all.size();
+    const std::string item = all.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.empty()) continue;
+    const size_t eq = item.find('=');
+    if (eq == std::string::npos || eq == 0 || eq + 1 >= item.size()) return false;
+    int *slot = tune_slot(t, item.substr(0, eq));
+    if (!slot) return false;
+    char *rest = nullptr;
+    const long v = std::strtol(item.c_str() + eq + 1, &rest, 10);
+    if (!rest || *rest != '\0') return false;
+    *slot = (int)v;
+  }
+  return true;
+}
 
 }  // namespace
 
@@ -138,15 +185,21 @@ struct rvc_set {
   std::vector<int> kid_c0;
   size_t longest_hint = 0;       // child sets: the longest (trimmed) impulse of the WHOLE set, so that all children of a set take
                                  // the same decision about the widened tail stage (do_init); 0 for a set of its own
+  bool is_kid = false;           // a child of another set: it keeps its streams also with empty impulses (the parent's fences and
+                                 // rvc_set_stream(s, 0) are anchored on child 0's stream)
   int nch = 0;
+  int plan_nch = 0;              // child sets: the channel count of the WHOLE set -- the stage plan (delay-1 tail, transform
+                                 // precision) is the parent's, whatever share of the channels a child serves; 0 for a set of its own
   int device = 0;
   unsigned flags = 0;
+  Tuning tune;                   // this set's measurement knobs (fixed at create)
   int err = RVC_OK;
   std::string errstr;
 
   bool inited = false;   // init succeeded (possibly with an empty IR)
   bool live = false;     // device state exists (non-empty IR)
   size_t head = 0, tail = 0, max_len = 0;
+  size_t split = 0;              // impulse samples the zero-latency stage covers (two-stage sets: 2T, or T for the shrunk form)
   bool two_stage = false;
   Stage A, T;
   Stage W;                       // optional "wide" stage: the whole IR at block 16384, used by calls that span
@@ -248,6 +301,16 @@ bool use_device(rvc_set *s) {
   return true;
 }
 
+// Announces the set's kernel variants to the launchers of this thread for the duration of an entry point.
+struct TuneScope {
+  const rvc::LaunchTune *prev;
+  explicit TuneScope(const rvc_set *s) : prev(&rvc::launch_tune()) { rvc::set_launch_tune(&s->tune.launch); }
+  explicit TuneScope(const rvc::LaunchTune *t) : prev(&rvc::launch_tune()) { rvc::set_launch_tune(t); }
+  ~TuneScope() { rvc::set_launch_tune(prev); }
+  TuneScope(const TuneScope &) = delete;
+  TuneScope &operator=(const TuneScope &) = delete;
+};
+
 // Device allocations of a set. Guard mode: [256 KiB of 0xFF | payload, 0xFF-filled | 256 KiB of 0xFF] -- an out-of-bounds
 // WRITE lands in a band and is counted by rvc_debug_guard_check; an out-of-bounds or never-written value that is USED
 // is a NaN in the output (0xFFFFFFFF is a quiet NaN), where the unguarded build would read a neighbour's plausible data.
@@ -288,8 +351,8 @@ hipError_t fence_alloc(rvc_set *s, void **p, size_t bytes) {
 }
 
 hipError_t dev_alloc_raw(rvc_set *s, void **p, size_t bytes) {
-  if (!g_tune.guard) return hipMalloc(p, bytes);
-  if (g_tune.guard == 2 && s->streams_ok) return fence_alloc(s, p, bytes);
+  if (!s->tune.guard) return hipMalloc(p, bytes);
+  if (s->tune.guard == 2 && s->streams_ok) return fence_alloc(s, p, bytes);
   char *base = nullptr;
   hipError_t e = hipMalloc(&base, bytes + 2 * kGuardBytes);
   if (e != hipSuccess) return e;
@@ -569,6 +632,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   // block sizes / partition counts (the plug-in's hot-swap, src/PluginProcessor.cpp:1680-1691)
   // keeps every buffer and only re-uploads and re-transforms the IR.
   auto drop = [&]() { if (s->streams_ok || s->live) free_device_state(s); };
+  const TuneScope tune_scope(s);
   s->err = RVC_OK;
   s->errstr.clear();
   if ((s->flags & RVC_FLAG_PERSISTENT) != 0) {   // the resident-kernel mode of rounds 2-3: removed, not silently ignored
@@ -602,7 +666,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   // served with the largest supported partition instead (rvc_set_head_block / _tail_block report
   // what is used). A host running 16384- or 32768-frame blocks gets the same samples.
   const size_t longest_set = std::max(longest, s->longest_hint);
-  const StagePlan plan = plan_stages(s->nch, s->flags, g_tune.tail_slack, head_block, tail_block, two_stage, longest_set);
+  const StagePlan plan = plan_stages(s->plan_nch ? s->plan_nch : s->nch, s->flags, s->tune.tail_slack, head_block, tail_block, two_stage, longest_set);
   const size_t hb_req = plan.hb_req, hb = plan.hb, split = plan.split;
   const bool want64 = plan.want64;
   auto stage64 = [&](size_t B) { return plan.stage64(B); };
@@ -610,6 +674,9 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   const int td = plan.td;
   if (longest == 0) {   // empty IR: success, process() gives zeros (:112-115)
     drop();
+    // (a child set whose channels all carry empty impulses still needs its stream: the parent fences the other children against
+    //  child 0's stream and hands it out as the set's ordering stream; its zeros are an asynchronous fill on that stream)
+    if (s->is_kid && !ensure_streams(s)) return false;
     s->inited = true;
     s->head = hb; s->tail = tb; s->max_len = max_len ? max_len : hb_req;
     return true;
@@ -663,6 +730,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
   s->head = hb;
   s->tail = tail_pub;
   s->two_stage = two_stage;
+  s->split = two_stage ? split : 0;
   s->max_len = eff_max_len;
   Stage &A = s->A, &T = s->T;
   A.B = hb; A.logB = ilog2(hb); A.P = (int)pa; A.delay = 0; A.f64 = stage64(hb);
@@ -721,10 +789,11 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     tT.on = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
     // one level of 8 blocks, or -- long delay lines -- a first level of 16 / 32 blocks with second-level sweeps every 8
     auto first_level = [&](size_t P) -> int {
-      // g_tune.k1: 0 = by length (16 above kTwoLevelMinP partitions, 32 from kLongLineMinP on: measured, profiles/r3_tuning.txt)
-      int k1 = (g_tune.k1 == 32 || g_tune.k1 == 16 || g_tune.k1 == 8) ? g_tune.k1 : ((int)P >= rvc::kLongLineMinP ? 32 : 16);
+      // knob k1: 0 = by length (16 above kTwoLevelMinP partitions, 32 from kLongLineMinP on: measured, profiles/r3_tuning.txt)
+      const int tk1 = s->tune.k1;
+      int k1 = (tk1 == 32 || tk1 == 16 || tk1 == 8) ? tk1 : ((int)P >= rvc::kLongLineMinP ? 32 : 16);
       if (force2 && k1 == 8) k1 = 16;
-      const int minp = g_tune.two_min_p >= 0 ? g_tune.two_min_p : rvc::kTwoLevelMinP;
+      const int minp = s->tune.two_min_p >= 0 ? s->tune.two_min_p : rvc::kTwoLevelMinP;
       return (force2 || (int)P > minp) ? k1 : (int)K;
     };
     tA.K1 = first_level(pa);
@@ -1415,8 +1484,11 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
   if (block_call && head_ingests) {
     // (the per-block call of many channels: the head transform appends the block to the ring, so the tail job runs BEHIND it
     //  and reads whole rows from the ring alone -- which keeps the row-looping form of its 8192-bin transforms, 0.57 instead
-    //  of 0.34 of the HBM peak at 2048 rows; nothing of this call's output depends on the job: it serves blocks two tail
-    //  periods ahead)
+    //  of 0.34 of the HBM peak at 2048 rows. Nothing of THIS call's output depends on the job: with delay d >= 1 the job that
+    //  tail block m completes serves output blocks >= m + d, the earliest of which starts with the NEXT call. That holds only
+    //  because both run on st_main in this order (block_call implies !bg): a tail job on another stream would have to be
+    //  waited for by the next call's head stage, as the bg path does.)
+    if (bg || (has_tail && T.delay < 1)) return fail(s, RVC_ERR_HIP, hipSuccess, "block_call: tail job must follow the head stage on st_main with delay >= 1");
     if (!head_stage(s, n0, n0, n1, src2, in_stride, d_out, out_stride, bg, n0)) return false;
     if (has_tail && !run_tail_job(s, n0, n1, nullptr, in_stride, bg)) return false;
     mark_long_stage_stale(s, n1);
@@ -1434,7 +1506,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
 // hook's "subsets" forces a count). Measured on MI355X (profiles/r3_tuning.txt).
 int subset_count(const rvc_set *s, size_t head_block, size_t max_len) {
   if ((s->flags & RVC_FLAG_NO_SUBSETS) != 0) return 1;
-  int n = g_tune.subsets;
+  int n = s->tune.subsets;
   // Default since round 4 (the calls fence the children against the set's own stream, fence_children_in / _out, so the caller
   // still orders against ONE stream): two children for sets of thousands of lock-step channels served block by block, four
   // from 8192 on (measured on MI355X, BASELINE config 2: 4096 channels 13.2 -> 14.3 Gsamples/s with two, 13.1 with four; 8192
@@ -1478,6 +1550,9 @@ bool make_kids(rvc_set *s, int n) {
     rvc_set *c = rvc_set_create(per, s->device, s->flags | RVC_FLAG_NO_SUBSETS);
     if (!c) { drop_kids(s); return false; }
     c->timing = s->timing;
+    c->is_kid = true;
+    c->tune = s->tune;
+    c->plan_nch = s->nch;
     s->kids.push_back(c);
     s->kid_c0.push_back(k * per);
   }
@@ -1497,7 +1572,7 @@ bool make_kids(rvc_set *s, int n) {
 // stream, rvc_set_stream(s, 2 + 2 k)).
 bool fence_children_in(rvc_set *s, bool explicit_call = false) {
   rvc_set *f = s->kids[0];
-  if (g_tune.kid_fence == 0 || (!explicit_call && (s->flags & RVC_FLAG_CHILD_SETS) != 0) || !f->streams_ok) return true;
+  if (s->tune.kid_fence == 0 || (!explicit_call && (s->flags & RVC_FLAG_CHILD_SETS) != 0) || !f->streams_ok) return true;
   if (!use_device(s)) return false;
   RVC_CK(hipEventRecord(f->ev_fence, f->st_main));
   for (size_t k = 1; k < s->kids.size(); ++k)
@@ -1506,7 +1581,7 @@ bool fence_children_in(rvc_set *s, bool explicit_call = false) {
 }
 bool fence_children_out(rvc_set *s, bool explicit_call = false) {
   rvc_set *f = s->kids[0];
-  if (g_tune.kid_fence == 0 || (!explicit_call && (s->flags & RVC_FLAG_CHILD_SETS) != 0) || !f->streams_ok) return true;
+  if (s->tune.kid_fence == 0 || (!explicit_call && (s->flags & RVC_FLAG_CHILD_SETS) != 0) || !f->streams_ok) return true;
   for (size_t k = 1; k < s->kids.size(); ++k) {
     rvc_set *c = s->kids[k];
     if (!c->streams_ok) continue;
@@ -1543,6 +1618,7 @@ void release_after_failed_init(rvc_set *s) {
 bool zero_device_out(rvc_set *s, float *d_out, size_t out_stride, size_t len) {
   if (len == 0 || !d_out) return true;
   if (s->streams_ok) {
+    if (hipSetDevice(s->device) != hipSuccess) return true;
     RVC_CK(hipMemset2DAsync(d_out, out_stride * sizeof(float), 0, len * sizeof(float), (size_t)s->nch, s->st_main));
   } else if (hipSetDevice(s->device) == hipSuccess) {   // never initialised with a non-empty IR: no stream yet
     (void)hipMemset2D(d_out, out_stride * sizeof(float), 0, len * sizeof(float), (size_t)s->nch);
@@ -1564,10 +1640,19 @@ rvc_set *rvc_set_create(int n_channels, int device, unsigned flags) {
   s->nch = n_channels;
   s->device = device;
   s->flags = flags;
+  s->tune = tune_defaults_now();
   s->timing = (flags & RVC_FLAG_TIMING) != 0;
   if ((flags & RVC_FLAG_PERSISTENT) != 0) { s->err = RVC_ERR_UNSUPPORTED; s->errstr = "RVC_FLAG_PERSISTENT was removed (round 4)"; }
   s->in_ptrs.assign((size_t)n_channels, nullptr);
   s->out_ptrs.assign((size_t)n_channels, nullptr);
+  return s;
+}
+
+rvc_set *rvc_set_create_tuned(int n_channels, int device, unsigned flags, const char *knobs) {
+  Tuning t = tune_defaults_now();
+  if (!apply_knobs(t, knobs)) return nullptr;
+  rvc_set *s = rvc_set_create(n_channels, device, flags);
+  if (s) s->tune = t;
   return s;
 }
 
@@ -1672,6 +1757,7 @@ void rvc_set_process_device(rvc_set *s, const float *d_in, size_t in_stride, flo
     return;
   }
   if (!use_device(s)) return;
+  const TuneScope tune_scope(s);
   size_t done = 0;
   while (done < len) {   // calls longer than max_len are split; results are call-pattern independent
     const size_t chunk = std::min(len - done, s->max_len);
@@ -1728,6 +1814,7 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   if (len > s->max_len) return;   // refused: process_end writes zeros for this call; the handle stays usable
                                   // (rvc_set_process splits long calls itself)
   if (!use_device(s)) return;
+  const TuneScope tune_scope(s);
   for (int c = 0; c < s->nch; ++c) std::memcpy(s->h_in + (size_t)c * len, in[c], len * sizeof(float));
   // Per-block calls (the latency path: one fused launch) skip both DMA copies: the pinned staging
   // buffers are device-visible, the kernel reads its 2 KB per channel over PCIe and writes the
@@ -1986,6 +2073,7 @@ static int debug_fft(int device, size_t n, int f64, bool inverse, const float *i
   if (logB > (f64 ? 13 : 14)) return 0;
   rvc_set *s = rvc_set_create(1, device, f64 ? RVC_FLAG_FFT_F64 : 0u);
   if (!s) return 0;
+  const TuneScope tune_scope(s);
   bool ok = ensure_streams(s) && use_device(s);
   Stage g;
   g.B = B; g.logB = logB; g.f64 = f64 != 0;
@@ -2054,6 +2142,8 @@ int rvc_debug_fdl(int device, int kind, int channels, int B, int P, int M, int d
     return 0;
   if (kind == 1 && M != 8 && M != 16 && M != 32) return 0;
   if (hipSetDevice(device) != hipSuccess) return 0;
+  const Tuning tune_now = tune_defaults_now();         // (no set: the variants rvc_debug_set_tuning has selected)
+  const TuneScope tune_scope(&tune_now.launch);
   const size_t nh = (size_t)channels * P * B, nx = (size_t)channels * ring_rows * B, ny = (size_t)channels * M * B;
   const size_t nadd = Yadd ? (kind == 1 ? ny : (size_t)channels * B) : 0;
   float2 *dH = nullptr, *dX = nullptr, *dY = nullptr, *dA = nullptr;
@@ -2094,7 +2184,7 @@ long rvc_debug_guard_check(rvc_set *s) {
     }
     return bad;
   }
-  if (s->guards.empty()) return g_tune.guard ? 0 : -1;
+  if (s->guards.empty()) return s->tune.guard ? 0 : -1;
   hipSetDevice(s->device);
   rvc_set_sync(s);
   std::vector<unsigned char> band(kGuardBytes);
@@ -2130,7 +2220,9 @@ int rvc_debug_plan(int n_channels, unsigned flags, size_t head_block, size_t tai
                    size_t *head_run, size_t *tail_run, size_t *zero_latency_samples) {
   if (n_channels < 1 || head_block == 0 || tail_block == 0) return 0;
   if (head_block > tail_block) std::swap(head_block, tail_block);   // TwoStageFFTConvolver.cpp:100-104
-  const StagePlan p = plan_stages(n_channels, flags, g_tune.tail_slack, head_block, tail_block, true, longest_ir);
+  // (child sets plan with the whole set's channel count, rvc_set::plan_nch: this is the plan of a set of n_channels however
+  //  many children serve it)
+  const StagePlan p = plan_stages(n_channels, flags, tune_defaults_now().tail_slack, head_block, tail_block, true, longest_ir);
   if (head_run) *head_run = p.hb;
   if (tail_run) *tail_run = p.tb;
   if (zero_latency_samples) *zero_latency_samples = p.split;
@@ -2139,23 +2231,65 @@ int rvc_debug_plan(int n_channels, unsigned flags, size_t head_block, size_t tai
 
 int rvc_debug_set_tuning(const char *key, int value) {
   if (!key) return 0;
-  const std::string k(key);
-  if (k == "k1") g_tune.k1 = value;
-  else if (k == "sweep_split") rvc::set_sweep_tuning(value);
-  else if (k == "sweep_lw") rvc::set_sweep_lane_width(value);
-  else if (k == "sweep_d") rvc::set_sweep_depth(value);
-  else if (k == "sweep_lds") rvc::set_sweep_lds_tuning(value);
-  else if (k == "fft_loop") { g_tune.fft_loop = value; rvc::set_fft_loop_tuning(value); }
-  else if (k == "subsets") g_tune.subsets = value;
-  else if (k == "fft_many") rvc::set_fft_many_tuning(value);
-  else if (k == "kid_fence") g_tune.kid_fence = value;
-  else if (k == "tail_slack") g_tune.tail_slack = value;
-  else if (k == "patch_nt") rvc::set_patch_nt_tuning(value);
-  else if (k == "block_occ") rvc::set_block_occ3_tuning(value);
-  else if (k == "tile_rot") rvc::set_tile_rot_tuning(value);
-  else if (k == "two_level_min_p") g_tune.two_min_p = value;
-  else if (k == "guard") g_tune.guard = value;
-  else return 0;
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
+  int *slot = tune_slot(g_tune_defaults, key);
+  if (!slot) return 0;
+  *slot = value;
+  return 1;
+}
+
+int rvc_debug_tuning_default(const char *key, int *value) {
+  if (!key) return 0;
+  Tuning shipped;                        // (default-constructed: what the engine ships with, whatever has been set since)
+  const int *slot = tune_slot(shipped, key);
+  if (!slot) return 0;
+  if (value) *value = *slot;
+  return 1;
+}
+
+const char *rvc_debug_tuning_keys(void) {
+  static const std::string keys = [] {
+    std::string k;
+    for (const TuneKey &t : kTuneKeys) { if (!k.empty()) k += ','; k += t.key; }
+    return k;
+  }();
+  return keys.c_str();
+}
+
+int rvc_set_plan(const rvc_set *s, rvc_plan *out, size_t out_size) {
+  if (!s || !out || out_size < sizeof(rvc_plan)) return 0;
+  std::memset(out, 0, out_size);
+  const rvc_set *k = s->kids.empty() ? s : s->kids[0];      // (children share one plan: rvc_set::plan_nch, longest_hint)
+  rvc_plan p{};
+  p.channels = s->nch;
+  p.subsets = s->kids.empty() ? 1 : (int)s->kids.size();
+  p.initialised = s->inited ? 1 : 0;
+  p.two_stage = k->two_stage ? 1 : 0;
+  p.tail_on_second_stream = (s->flags & RVC_FLAG_BG_STREAM) != 0;
+  p.head_block = k->head;
+  p.tail_block = k->tail;
+  p.max_len = k->max_len;
+  for (const rvc_set *c : (s->kids.empty() ? std::vector<rvc_set *>{const_cast<rvc_set *>(s)} : s->kids)) {
+    p.head_partitions = std::max(p.head_partitions, c->A.P);
+    p.tail_partitions = std::max(p.tail_partitions, c->T.P);
+    p.wide_partitions = std::max(p.wide_partitions, c->W.P);
+    if (c->live) k = c;                                     // (a child with empty impulses holds no stages: describe a live one)
+  }
+  if (k->live) {
+    p.live = 1;
+    p.zero_latency_samples = k->split;
+    p.tail_delay = k->T.P > 0 ? k->T.delay : 0;
+    p.head_f64 = k->A.f64 ? 1 : 0;
+    p.tail_f64 = (k->T.P > 0 && k->T.f64) ? 1 : 0;
+    p.head_tile_blocks = k->tA.on ? k->tA.K1 : 0;
+    p.tail_tile_blocks = k->tT.on ? k->tT.K1 : 0;
+    p.block_path = k->block_general ? 1 : 0;
+    p.long_call_block = k->T.PF > 0 ? k->T.B : 0;
+    p.wide_block = k->W.P > 0 ? k->W.B : 0;
+    // the reference's structure at these sizes: head + tail0 cover IR[0, 2T) at the head block, the tail runs 2 blocks late
+    p.reference_structure = (k->T.P == 0 || (k->T.delay == 2)) ? 1 : 0;
+  }
+  *out = p;
   return 1;
 }
 
@@ -2164,6 +2298,7 @@ int rvc_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
-const char *rvc_version(void) { return "reevr_amd 0.1 (gfx950)"; }
+const char *rvc_version(void) { return "reevr_amd 0.2 (gfx950)"; }
+int rvc_abi_version(void) { return RVC_ABI_VERSION; }
 
 }  // extern "C"

@@ -159,13 +159,23 @@ void set_launch_events(hipEvent_t a, hipEvent_t b);
 void get_launch_events(hipEvent_t *a, hipEvent_t *b);   // (for launchers in other translation units)
 // one-off: raise the dynamic-LDS limit of the large FFT kernels
 hipError_t prepare_kernels();
-// measurement hook (rvc_debug_set_tuning "fft_loop"): -1 row-looping 8192-bin transforms by size, 0 never, 1 whenever legal
-void set_fft_loop_tuning(int mode);
-void set_fft_many_tuning(int mode);   // "fft_many": -1 auto / 0 never / 1 always the many-rows form of the 4096-bin transforms (twiddles per pass, 4 workgroups per CU)
-void set_tile_rot_tuning(int on);    // "tile_rot": sweeps / patches on long rows take channel c's bin tiles in the order rotated by c (XCD spread)
-int tile_rot_tuning();
-void set_block_occ3_tuning(int on);  // "block_occ": 4 = the lean 4-waves-per-SIMD per-block kernel for many-channel launches (measurement)
-void set_patch_nt_tuning(int on);    // "patch_nt": 0 = ordinary loads in the stand-alone patch kernel (default: non-temporal for many channels)
+// Kernel / schedule variants the launchers choose between. Every set carries its own copy (rvc_set::tune, fixed when the set
+// is created); the engine announces it to the launchers of THIS thread for the duration of an entry point (TuneScope in
+// rvc_engine.cpp), so two handles used from two threads never see each other's knobs. Defaults = what ships.
+struct LaunchTune {
+  int fft_loop = -1;     // row-looping form of the 8192-bin transforms: -1 by size, 0 never, 1 whenever legal
+  int fft_many = -1;     // many-rows form of the 4096-bin transforms (twiddles per pass, 4 workgroups per CU): -1 from 2048 rows on / 0 / 1
+  int tile_rot = 1;      // sweeps / patches on long rows take channel c's bin tiles in the order rotated by c (XCD spread)
+  int block_occ = 0;     // 4 = the lean 4-waves-per-SIMD per-block kernel for many-channel launches (measurement)
+  int patch_nt = 1;      // 0 = ordinary loads in the stand-alone patch kernel (default: non-temporal for many channels)
+  int sweep_split = -1;  // -1 auto / 0 own-tile form / 1 partition-split form of the 8-block sweeps
+  int sweep_lw = 0;      // 4 = 16-byte lanes for the 16-block first-level sweeps (default by row length)
+  int sweep_d = 0;       // 8 = eight row pairs requested ahead in the long-tile sweeps (default 4)
+  int sweep_lds = -1;    // LDS-fed first-level sweeps, accumulators split over waves (rvc_sweep.hip): -1 default / 0 off / 1 / 2 / 3
+  int mac3 = -1;         // three-product complex multiply-accumulate in the LDS-fed 32-block sweeps: -1 default / 0 off / 1 on
+};
+void set_launch_tune(const LaunchTune *t);   // thread-local; nullptr = the defaults above
+const LaunchTune &launch_tune();
 
 // radix-8 kernels (logB >= 9): number of entries of their per-pass twiddle table, laid out as
 //   for j = 1 .. N8-1 (N8 = logB / 3):  p = 8^j entries [k < p][r < 8] = e^{-2 pi i r k / (8 p)}
@@ -195,12 +205,6 @@ constexpr int kLongLineMinP = 80; // from this many partitions on the first leve
 constexpr int kSweepLagMax = 3;   // a sweep may run up to this many blocks before its first row is due (x_hi that much older)
 // M = 8, 16 or 32 output rows
 hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st);
-// measurement hook (rvc_debug_set_tuning): "sweep_split" -1 auto / 0 own-tile form / 1 partition-split form
-void set_sweep_tuning(int split);
-void set_sweep_lds_tuning(int v);  // "sweep_lds": LDS-fed first-level sweeps, accumulators split over waves (rvc_sweep.hip): -1 default / 0 off / 1 / 2 / 3
-void set_sweep_depth(int d);         // "sweep_d": 8 = eight row pairs requested ahead in the long-tile sweeps (default 4)
-void set_sweep_lane_width(int lw);   // "sweep_lw": 4 = 16-byte lanes for the 16-block first-level sweeps (default 8-byte)
-
 // A prepared impulse as rvc_set_init_impulse sees it (rvc_impulse.hip): device pointers of the
 // prepared channels and their lengths with trailing |x| < 1e-6 dropped (TwoStageFFTConvolver.cpp:107-110).
 struct ImpulseView {

@@ -47,6 +47,11 @@ namespace rvc {
 static thread_local hipEvent_t t_ev_a = nullptr, t_ev_b = nullptr;
 void set_launch_events(hipEvent_t a, hipEvent_t b) { t_ev_a = a; t_ev_b = b; }
 void get_launch_events(hipEvent_t *a, hipEvent_t *b) { *a = t_ev_a; *b = t_ev_b; }
+// the variants the launchers of this thread choose (rvc_internal.h, LaunchTune): the calling set's, announced by the engine
+static thread_local const LaunchTune *t_tune = nullptr;
+static const LaunchTune k_default_tune{};
+void set_launch_tune(const LaunchTune *t) { t_tune = t; }
+const LaunchTune &launch_tune() { return t_tune ? *t_tune : k_default_tune; }
 #define RVC_LAUNCH(kernel, grid, block, lds, st, ...)                                              \
   do {                                                                                             \
     if (t_ev_a) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, t_ev_a, t_ev_b, 0, __VA_ARGS__); \
@@ -1781,9 +1786,6 @@ __device__ __forceinline__ bool fdl_is_patch(const FirArgs &a) { return a.Yadd !
 // no request is issued twice), kPatchMax with clamped addresses otherwise (the patch workgroups of k_fused_block2).
 // streaming (non-temporal) 16-byte load: the rows a patch reads are far larger than any cache by the time they are read again
 typedef float patch_vf4 __attribute__((ext_vector_type(4)));
-static int g_patch_nt = 1, g_block_occ = 0;      // g_block_occ = 4: the lean 4-waves-per-SIMD per-block kernel for many-channel launches
-void set_patch_nt_tuning(int on) { g_patch_nt = on; }
-void set_block_occ3_tuning(int on) { g_block_occ = on; }
 template <bool NT> __device__ __forceinline__ float4 patch_ld(const float2 *p) {
   if constexpr (NT) {
     const patch_vf4 v = __builtin_nontemporal_load(reinterpret_cast<const patch_vf4 *>(p));
@@ -1991,9 +1993,8 @@ __global__ void __launch_bounds__(256) k_ingest(const IngestArgs a) {
 // ----------------------------------------------------------------------------------------
 // launchers
 // ----------------------------------------------------------------------------------------
-static int g_fft_many = -1;                      // "fft_many": -1 = the MANY form of the 4096-bin transforms from 2048 rows on, 0 = never, 1 = always
-void set_fft_many_tuning(int mode) { g_fft_many = mode; }
-static bool fft_many_rows(long long items) { return g_fft_many > 0 || (g_fft_many < 0 && items >= 2048); }
+// "fft_many": -1 = the MANY form of the 4096-bin transforms from 2048 rows on, 0 = never, 1 = always
+static bool fft_many_rows(long long items) { const int m = launch_tune().fft_many; return m > 0 || (m < 0 && items >= 2048); }
 
 template <int LOGB, typename R>
 static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStream_t st) {
@@ -2071,8 +2072,7 @@ int fft8_table_entries(int logB) {   // entries of the tw8 table the radix-8 ker
     case 13: return FN<13, R>(__VA_ARGS__);
 
 // ---- row-looping big transforms: when, and on how many workgroups --------------------------------------------
-static int g_fft_loop = -1;                      // -1: by size, 0: never, 1: whenever the rows qualify
-void set_fft_loop_tuning(int mode) { g_fft_loop = mode; }
+// LaunchTune::fft_loop: -1 by size, 0 never, 1 whenever the rows qualify
 
 constexpr int kLoopLogB = 13;
 static size_t fft_loop_lds_bytes(bool inverse) {   // exchange buffer (+ the inverse kernel's twiddle table)
@@ -2112,12 +2112,12 @@ static bool inv_rows_loopable(const InvArgs &a, int rows) {
 
 hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int channels, hipStream_t st) {
   if (rows <= 0 || channels <= 0) return hipSuccess;
-  if (logB == kLoopLogB && !f64 && g_fft_loop != 0 && fwd_rows_loopable(a, rows)) {
+  if (logB == kLoopLogB && !f64 && launch_tune().fft_loop != 0 && fwd_rows_loopable(a, rows)) {
     const int nwg = fft_loop_workgroups(false);
     const long long items = (long long)rows * channels;
     // (many rows per workgroup, else the loop is all prologue -- and a looping workgroup needs a CU's whole register file:
     //  beside another child set's stream of small launches a 4-rows-per-workgroup launch waited for CUs longer than it ran)
-    if (nwg > 0 && items < (1ll << 30) && (g_fft_loop > 0 || items >= 8ll * nwg)) {
+    if (nwg > 0 && items < (1ll << 30) && (launch_tune().fft_loop > 0 || items >= 8ll * nwg)) {
       typedef Plan8<kLoopLogB> P;
       FwdArgs b = a;
       b.rows = rows;
@@ -2139,10 +2139,10 @@ hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int ch
   if (rows <= 0 || channels <= 0) return hipSuccess;
   // (the inverse gains nothing from looping -- measured 113 vs 107 us per 4096 rows on MI355X: its one-row kernel already
   //  runs two workgroups per CU at 54 registers -- so it loops only on request; the forward transform: 163 -> 117 us)
-  if (logB == kLoopLogB && !f64 && g_fft_loop > 0 && inv_rows_loopable(a, rows)) {
+  if (logB == kLoopLogB && !f64 && launch_tune().fft_loop > 0 && inv_rows_loopable(a, rows)) {
     const int nwg = fft_loop_workgroups(true);
     const long long items = (long long)rows * channels;
-    if (nwg > 0 && items < (1ll << 30) && (g_fft_loop > 0 || items >= 8ll * nwg)) {
+    if (nwg > 0 && items < (1ll << 30) && (launch_tune().fft_loop > 0 || items >= 8ll * nwg)) {
       typedef Plan8<kLoopLogB> P;
       InvArgs b = a;
       b.rows = rows;
@@ -2187,8 +2187,8 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
   const bool patch = f.Yadd != nullptr && f.P <= kPatchMax && f.P >= 1;
   if constexpr (LOGB >= 7 && LOGB <= 9) {     // the audio workgroup is ONE wave: audio wave + patch wave per workgroup
     if (patch || f.P <= 0) {
-      if (g_patch_nt == 2 && (long long)channels * P::B >= (1ll << 19)) RVC_LAUNCH((k_fused_block2w<LOGB, true, false>), dim3(n_audio), dim3(128), lds, st, b, f);
-      else if (g_block_occ == 4 && n_audio >= 1024) RVC_LAUNCH((k_fused_block2w<LOGB, false, true>), dim3(n_audio), dim3(128), lds, st, b, f);
+      if (launch_tune().patch_nt == 2 && (long long)channels * P::B >= (1ll << 19)) RVC_LAUNCH((k_fused_block2w<LOGB, true, false>), dim3(n_audio), dim3(128), lds, st, b, f);
+      else if (launch_tune().block_occ == 4 && n_audio >= 1024) RVC_LAUNCH((k_fused_block2w<LOGB, false, true>), dim3(n_audio), dim3(128), lds, st, b, f);
       else RVC_LAUNCH((k_fused_block2w<LOGB, false, false>), dim3(n_audio), dim3(128), lds, st, b, f);
       return hipGetLastError();
     }
@@ -2253,8 +2253,8 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   // 16 bytes per lane, all requests of a thread in flight at once; the row kernel below is built for the latency of a few)
   if (a.M == 1 && a.P <= kPatchMax && (a.B % 2) == 0 && (a.Yadd != nullptr || (long long)channels * a.B >= (1ll << 18))) {
     const dim3 grid((a.B + 511) / 512, channels), block(256);
-    const bool nt = g_patch_nt != 0 && (long long)channels * a.B >= (1ll << 20);    // (a few channels: rows stay in the L2 / MALL)
-    const int rot = (grid.x >= 8 && tile_rot_tuning()) ? 1 : 0;
+    const bool nt = launch_tune().patch_nt != 0 && (long long)channels * a.B >= (1ll << 20);    // (a few channels: rows stay in the L2 / MALL)
+    const int rot = (grid.x >= 8 && launch_tune().tile_rot) ? 1 : 0;
     if (a.tag == 0) { if (nt) RVC_LAUNCH((k_fdl_patch<0, true>), grid, block, 0, st, a, rot); else RVC_LAUNCH((k_fdl_patch<0, false>), grid, block, 0, st, a, rot); }
     else { if (nt) RVC_LAUNCH((k_fdl_patch<1, true>), grid, block, 0, st, a, rot); else RVC_LAUNCH((k_fdl_patch<1, false>), grid, block, 0, st, a, rot); }
     return hipGetLastError();

@@ -508,9 +508,6 @@ __global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a, const in
   }
 }
 
-static int g_tile_rot = 1;
-void set_tile_rot_tuning(int on) { g_tile_rot = on; }
-int tile_rot_tuning() { return g_tile_rot; }
 
 template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
 static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
@@ -519,7 +516,7 @@ static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
   // Workgroups go to the 8 XCDs round robin by linear index. With a power-of-two count of workgroups per channel, XCD j
   // would only ever see the bin tiles j, j + 8, .. of every row: a fixed eighth of each row's addresses. Rotating the order
   // by the channel index gives every XCD every part of the rows.
-  const int rot = (grid.x >= 8 && g_tile_rot) ? 1 : 0;
+  const int rot = (grid.x >= 8 && launch_tune().tile_rot) ? 1 : 0;
   hipEvent_t ea, eb;
   get_launch_events(&ea, &eb);
   if (ea) hipExtLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, ea, eb, 0, a, rot);
@@ -529,22 +526,16 @@ static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
 template <int KW, int NKW, int A, int STAGE, bool NT, int LB>
 static void launch_lds_variant(const FirArgs &a, int channels, hipStream_t st) {
   const dim3 grid(a.B / 128, channels), block(128 * NKW);
-  const int rot = (grid.x >= 8 && g_tile_rot) ? 1 : 0;
+  const int rot = (grid.x >= 8 && launch_tune().tile_rot) ? 1 : 0;
   hipEvent_t ea, eb;
   get_launch_events(&ea, &eb);
   if (ea) hipExtLaunchKernelGGL((k_fdl_sweep_lds<KW, NKW, A, STAGE, NT, LB>), grid, block, 0, st, ea, eb, 0, a, rot);
   else hipLaunchKernelGGL((k_fdl_sweep_lds<KW, NKW, A, STAGE, NT, LB>), grid, block, 0, st, a, rot);
 }
 
-static int g_sweep_split = -1, g_sweep_lw = 0, g_sweep_depth = 0;
 // "sweep_lds": the LDS-fed form (accumulators split over waves) for first-level sweeps: -1 = where it is the default (32-block
 // tiles as 2 x 16, rings one chunk ahead), 0 = never (the one-wave forms), 1 = 2 x 16 with rings three chunks ahead, 2 = 32-block
 // tiles as 4 x 8, 3 = also 16-block tiles (2 x 8)
-static int g_sweep_lds = -1;
-void set_sweep_lds_tuning(int v) { g_sweep_lds = v; }
-void set_sweep_tuning(int split) { g_sweep_split = split; }
-void set_sweep_lane_width(int lw) { g_sweep_lw = lw; }
-void set_sweep_depth(int d) { g_sweep_depth = d; }
 
 template <int STAGE>
 static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
@@ -554,22 +545,22 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
   const long long waves1 = (long long)((a.B + 127) / 128) * channels;
   bool split = a.M == kSweepRows && a.Ybase == nullptr && (waves1 < 2048 || a.B >= 2048);
   if (a.M > kSweepRows) split = false;      // (long tiles: every wave of the split form reads K window rows besides its share)
-  else if (g_sweep_split >= 0) split = g_sweep_split != 0;
+  else if (launch_tune().sweep_split >= 0) split = launch_tune().sweep_split != 0;
   // K = 8: 16 B per lane, 4 row pairs ahead, <= 168 VGPRs (3 waves per SIMD), non-temporal loads on the own-tile form;
   // measured against 8 B per lane, deeper queues, 2 / 4 waves per SIMD on MI355X (profiles/r2_sweep_variants.txt).
   // K = 16 / 32 (first level of long delay lines): 8 B per lane -- 2 K registers of accumulators, 2 K of window.
-  const bool deep = g_sweep_depth == 8;           // (measurement: 8 row pairs requested ahead instead of 4)
-  const bool lds_ok = a.B >= 128 && a.Ybase == nullptr && g_sweep_lds != 0;
+  const bool deep = launch_tune().sweep_d == 8;           // (measurement: 8 row pairs requested ahead instead of 4)
+  const bool lds_ok = a.B >= 128 && a.Ybase == nullptr && launch_tune().sweep_lds != 0;
   if (a.M == 32 && lds_ok) {
     // Measured on MI355X (profiles/r4_sweep_lds.txt): rings ONE chunk ahead (32 KiB: five workgroups = 20 waves per CU) beat
     // three chunks ahead (48 KiB, three workgroups) on 512-bin rows -- config 1's 94-partition line 1.50 (one-wave form) / 1.47 /
     // 1.35 ms per 8192-channel launch -- and tie on 8192-bin rows (config 3's 350 partitions: 23.6 / 23.3 / 23.2 ms), where every
     // form executes 63-64 TFLOP/s of FMAs at a core clock the power limit holds at 1.70 GHz: that launch is bound by VALU work
     // and power, not by HBM or occupancy.
-    if (g_sweep_lds == 2) launch_lds_variant<8, 4, 3, STAGE, true, 4>(a, channels, st);
-    else if (g_sweep_lds == 1) launch_lds_variant<16, 2, 3, STAGE, true, 3>(a, channels, st);
+    if (launch_tune().sweep_lds == 2) launch_lds_variant<8, 4, 3, STAGE, true, 4>(a, channels, st);
+    else if (launch_tune().sweep_lds == 1) launch_lds_variant<16, 2, 3, STAGE, true, 3>(a, channels, st);
     else launch_lds_variant<16, 2, 1, STAGE, true, 4>(a, channels, st);
-  } else if (a.M == 16 && lds_ok && g_sweep_lds == 3) {
+  } else if (a.M == 16 && lds_ok && launch_tune().sweep_lds == 3) {
     // (measurement only: 16-block tiles through the LDS-fed form lose to the one-wave 16-byte-lane form on config 2's 57 x
     //  8192-bin tail -- 6.38 ms per launch against 6.64 (2 x 8, one chunk ahead), 6.98 (2 x 8, three chunks), 6.87 / 7.17 (one
     //  wave of 16 fed through the rings, one / three chunks ahead): at 8 flop per byte that sweep is not VALU-bound, and the
@@ -581,7 +572,7 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
   } else if (a.M == 16) {
     // 16 B per lane (2 waves per SIMD) on the long rows of a tail stage, 8 B per lane (4 waves) on short ones: measured on
     // MI355X, config 2's 57 x 8192-bin tail: 0.63 vs 0.60 of the HBM peak (profiles/r3_tuning.txt)
-    if (g_sweep_lw == 4 || (g_sweep_lw == 0 && a.B >= 1024)) {
+    if (launch_tune().sweep_lw == 4 || (launch_tune().sweep_lw == 0 && a.B >= 1024)) {
       if (deep) launch_variant<16, 1, STAGE, 4, 8, 2, true>(a, channels, st);
       else launch_variant<16, 1, STAGE, 4, 4, 2, true>(a, channels, st);
     } else if (deep) launch_variant<16, 1, STAGE, 2, 8, 3, true>(a, channels, st);

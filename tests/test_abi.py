@@ -37,8 +37,9 @@ def test_header_symbols_all_exported(lib):
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
     # rvc.h is the reference's surface plus the set API: no measurement / development entry in it
-    assert not [n for n in declared_symbols(HEADER) if n.startswith("rvc_debug_") or n.endswith("_timed")]
-    assert all(n.startswith("rvc_debug_") or n.endswith("_timed") for n in declared_symbols(DEBUG_HEADER))
+    dbg = lambda n: n.startswith("rvc_debug_") or n.endswith("_timed") or n.endswith("_tuned")
+    assert not [n for n in declared_symbols(HEADER) if dbg(n)]
+    assert all(dbg(n) for n in declared_symbols(DEBUG_HEADER))
 
 
 def test_no_cpu_fallback_without_gpu(lib):
@@ -101,6 +102,48 @@ def test_tuning_knobs_and_context_manager(lib):
             raise RuntimeError("boom")
 
 
+def test_plan_and_per_set_knobs_without_gpu(lib):
+    """rvc_set_plan before any init (all zero but the channel count), after an init with empty impulses (initialised, not live);
+    rvc_set_create_tuned takes knobs of the set's own and refuses unknown keys / malformed items; the knob defaults come from
+    the library; the ABI number is the header's."""
+    import reevr_amd
+    from reevr_amd import _lib
+    assert lib.rvc_abi_version() == _lib.RVC_ABI_VERSION == 2
+    hdr = open(HEADER).read()
+    assert "#define RVC_ABI_VERSION 2" in hdr
+    s = reevr_amd.ConvolverSet(6)
+    p = s.plan()
+    assert p["channels"] == 6 and p["subsets"] == 1 and not p["initialised"] and not p["live"] and p["head_block"] == 0
+    assert s.init(64, 256, [np.zeros(5, np.float32)] * 6)
+    p = s.plan()
+    assert p["initialised"] == 1 and p["live"] == 0 and (p["head_block"], p["tail_block"]) == (64, 256)
+    s.close()
+    # the struct the header declares and the ctypes mirror have the same fields in the same order
+    body = re.sub(r"/\*.*?\*/", "", hdr[hdr.index("typedef struct rvc_plan {"):hdr.index("} rvc_plan;")], flags=re.S)
+    fields = [n for decl in re.findall(r"(?:int|size_t)\s+([a-z_0-9, ]+);", body) for n in re.split(r",\s*", decl.strip())]
+    assert fields == [n for n, _ in _lib.Plan._fields_], fields
+    assert lib.rvc_set_plan(None, None, 0) == 0
+    # knobs
+    keys = lib.rvc_debug_tuning_keys().decode().split(",")
+    assert "k1" in keys and "sweep_lds" in keys and "mac3" in keys and sorted(keys) == sorted(reevr_amd.TUNING_DEFAULTS.keys())
+    assert reevr_amd.TUNING_DEFAULTS["subsets"] == -1 and reevr_amd.TUNING_DEFAULTS["kid_fence"] == 1
+    t = reevr_amd.ConvolverSet(4, tune={"k1": 32, "subsets": 2})
+    t.close()
+    for bad in (b"no_such=1", b"k1", b"k1=", b"=3", b"k1=3x"):
+        assert not lib.rvc_set_create_tuned(2, 0, 0, bad), bad
+    h = lib.rvc_set_create_tuned(2, 0, 0, None)
+    assert h
+    lib.rvc_set_destroy(h)
+    # rvc_debug_set_tuning changes the DEFAULT of later sets only, and the shipped value stays readable
+    assert reevr_amd.set_tuning("k1", 8)
+    try:
+        v = ctypes.c_int(-5)
+        assert lib.rvc_debug_tuning_default(b"k1", ctypes.byref(v)) == 1 and v.value == 0
+        assert lib.rvc_debug_tuning_default(b"nope", ctypes.byref(v)) == 0
+    finally:
+        reevr_amd.set_tuning("k1", 0)
+
+
 def test_cpp_shim_headers_compile():
     """The C++ drop-in classes (include/reevr_amd/Convolver.h, StereoConvolver.h) compile and
     link against the C ABI with plain g++ (no HIP headers needed on the host side)."""
@@ -121,36 +164,7 @@ def test_cpp_shim_headers_compile():
         assert r.returncode == 0, r.stdout + r.stderr
 
 
-REF_SC = "/root/reference/src/dsp/StereoConvolver.cpp"
-
-
-GLUE_EXE = os.path.join(ROOT, "oracle", "_ref", "ref_glue")     # (git-ignored, travels to the GPU box like oracle/_ref's other files)
-
-
-def build_reference_glue(tmp, exe=None):
-    """INTEGRATION.md: "the reference's StereoConvolver.cpp then compiles unchanged against include/reevr_amd/Convolver.h".
-    The reference's StereoConvolver.{h,cpp} are compiled WHERE THEY LIE -- reached through symlinks in a temp dir, because a
-    quoted #include looks in the including file's own directory first and would find the JUCE-bound src/dsp/Convolver.h --
-    next to three temp-dir headers: Convolver.h = the drop-in, JuceHeader.h = the std headers the file relies on, Impulse.h =
-    the four buffers + isQuad loadImpulse reads and the SVF::EQBand the header names. Nothing of the reference is copied."""
-    import subprocess
-    from reevr_amd import _lib, build
-    build.build_lib()
-    os.symlink(REF_SC, os.path.join(tmp, "StereoConvolver.cpp"))
-    os.symlink(REF_SC[:-3] + "h", os.path.join(tmp, "StereoConvolver.h"))
-    open(os.path.join(tmp, "JuceHeader.h"), "w").write("#pragma once\n#include <algorithm>\n#include <memory>\n#include <vector>\n")
-    open(os.path.join(tmp, "Convolver.h"), "w").write('#pragma once\n#include "reevr_amd/Convolver.h"\n')
-    open(os.path.join(tmp, "Impulse.h"), "w").write(
-        "#pragma once\n#include <vector>\n"
-        "struct SVF { enum Mode { LP, BP, HP, LS, HS, PK, BS, HP6, LP6, Off }; struct EQBand { Mode mode; float freq, q, gain; }; };\n"
-        "struct Impulse { std::vector<float> bufferLL, bufferRR, bufferLR, bufferRL; bool isQuad = false; };\n")
-    exe = exe or os.path.join(tmp, "ref_glue")
-    os.makedirs(os.path.dirname(exe), exist_ok=True)
-    libdir = os.path.dirname(_lib.LIB_PATH)
-    subprocess.run(["g++", "-std=c++17", "-O1", "-I", tmp, "-I", os.path.join(ROOT, "include"),
-                    os.path.join(tmp, "StereoConvolver.cpp"), os.path.join(ROOT, "tests", "ref_glue_main.cpp"), "-o", exe,
-                    "-L", libdir, "-lreevr_amd", f"-Wl,-rpath,{libdir}"], check=True)
-    return exe
+from oracle.ref_glue import GLUE_EXE, REF_SC, build_reference_glue  # noqa: E402  (the recipe lives with the checker, not with the tests)
 
 
 def glue_operands(path, block, nblocks, ir_len, quad):

@@ -444,6 +444,56 @@ def test_handles_are_independent_across_threads():
         assert rel_rms(got[c], want[c]) <= TOL
 
 
+def test_knobs_are_per_handle_across_threads():
+    """rvc_set_create_tuned: a set's measurement knobs are its own. Two threads create, initialise and run sets with DIFFERENT
+    knobs at the same time (one forces two levels of 32-block tiles and two child sets, the other one level and none) while
+    the main thread flips the process-wide defaults: every set must report the plan of its own knobs and match the oracle."""
+    import threading
+    import torch
+    head, tail, nch, nblk = 64, 256, 8, 16 * 12
+    irs = [synth.synth_ir(2 * tail + 40 * tail - 37 * c, 1, 500 + c)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 90 + c) for c in range(nch)])
+    want = []
+    for c in range(nch):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        want.append(o.process(x[c]))
+    errors, stop = [], threading.Event()
+
+    def worker(tune, tiling, expect_tile, expect_subsets):
+        try:
+            dx = torch.from_numpy(x).cuda()
+            for _ in range(6):
+                s = reevr_amd.ConvolverSet(nch, time_tiling=tiling, tune=tune)
+                assert s.init(head, tail, irs, max_len=head), s.last_error_string
+                p = s.plan()
+                assert (p["tail_tile_blocks"], p["subsets"]) == (expect_tile, expect_subsets), (tune, p)
+                got = s.process_device_blocks(dx, head).cpu().numpy()
+                assert s.last_error == 0, s.last_error_string
+                s.close()
+                for c in (0, nch - 1):
+                    assert rel_rms(got[c], want[c]) <= TOL, (tune, c)
+        except Exception as e:
+            errors.append((tune, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=({"k1": 32, "subsets": 2}, "force2", 32, 2)),
+          threading.Thread(target=worker, args=({"k1": 8, "two_level_min_p": 1000, "subsets": 1}, "force", 8, 1))]
+    for t in ts:
+        t.start()
+    try:
+        while any(t.is_alive() for t in ts):          # the old failure mode: a debug knob set by one thread changes another's plan
+            for v in (16, 0):
+                reevr_amd.set_tuning("k1", v)
+            for v in (4, -1):
+                reevr_amd.set_tuning("subsets", v)
+    finally:
+        reevr_amd.set_tuning("k1", 0)
+        reevr_amd.set_tuning("subsets", -1)
+        for t in ts:
+            t.join()
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("ir_len", [60000, 150000])
 @pytest.mark.parametrize("fixed", [False, True])
 def test_mixed_long_and_short_calls_hand_state_over(fixed, ir_len):
@@ -1203,6 +1253,44 @@ def test_tail_slack_policy_and_children():
     run(256, [long_ir], (4, 256, 141), fft_f64=True)           # double transforms: no 2T-block transform, so it shrinks
     # two children: only channel 0 carries the long impulse -- the second child alone would shrink, together they widen
     run(512, [long_ir] + [short_ir] * 511, (8, 512, 70), subsets=2)
+    # children plan with the WHOLE set's channel count (rvc_debug_plan's n_channels): 300 channels over two children of 150 run the
+    # delay-1 plan of a 300-channel set, not the reference's structure a 150-channel set of its own would get
+    run(300, [long_ir], (8, 512, 70), subsets=2)
+    assert reevr_amd.stage_plan(300, head, tail, long_ir)["tail_delay"] == 1 and reevr_amd.stage_plan(150, head, tail, long_ir)["tail_delay"] == 2
+
+
+def test_child_sets_with_empty_impulses_in_the_first_child():
+    """A 4096-channel lock-step set is served by two children; when every impulse of the FIRST child's channels is empty that
+    child holds no stages -- but the set's ordering stream (rvc_set_stream(s, 0)) and the fences of the other child are anchored
+    on its stream, so it must still have one: the live half against the oracle, the empty half zeros (asynchronously, on that
+    stream), with torch's producer / consumer ordered through stream 0 only."""
+    import torch
+    nch, head, tail, nblk = 4096, 512, 8192, 40
+    live = synth.synth_ir(3 * tail + 999, 2, 7)
+    irs = [np.zeros(0, np.float32)] * (nch // 2) + [live[c % 2][:3 * tail + 999 - 13 * (c % 5)].copy() for c in range(nch // 2)]
+    x4 = np.stack([synth.synth_input(head * nblk, 400 + c) for c in range(4)])
+    s = reevr_amd.ConvolverSet(nch)
+    assert s.init(head, tail, irs, max_len=head), s.last_error_string
+    assert s.subsets == 2 and s.stream(0), "the set's ordering stream must exist although child 0 has no stages"
+    p = s.plan()
+    assert p["live"] == 1 and p["tail_partitions"] >= 1 and p["subsets"] == 2
+    dx = torch.from_numpy(x4).cuda()[torch.arange(nch, device="cuda") % 4].contiguous()
+    out = torch.full_like(dx, float("nan"))
+    for rep in range(3):                                  # producer and consumer on torch's stream, ordered through stream 0
+        dx2 = dx * 1.0
+        got = s.process_device_blocks(dx2, head, out, sync=False, order=True)
+        total = got.abs().sum(dim=1)                      # consumer kernel on torch's stream, right behind the call
+        s.clear()
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    assert s.last_error == 0, s.last_error_string
+    s.close()
+    assert np.all(got[:nch // 2] == 0) and np.all(total[:nch // 2].cpu().numpy() == 0)
+    assert np.isfinite(got).all()
+    for c in (nch // 2, nch // 2 + 1, nch - 1):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(got[c], o.process(x4[c % 4])) <= TOL, c
 
 
 def test_row_looping_transforms_match_one_row_kernels():

@@ -203,3 +203,63 @@ def test_pmc_summary_kernel_families():
     assert fam("void rvc::k_fft8_fwd_loop<13>(rvc::FwdArgs, int)") == "fft_fwd_tail"
     assert fam("void rvc::k_fft8_fwd<13, double>(rvc::FwdArgs)") is None
 
+
+
+def test_compact_bench_line_fits_and_carries_the_contract():
+    """bench.py prints ONE compact line last (the driver parses it; round 4's 24 KB line could not be parsed) and writes the
+    full record to a side file: the line builder on a canned full record (round 4's, the largest so far) and on an inflated
+    one must stay under 4 KB and keep every key of the contract."""
+    import copy
+    import json
+    b = _bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r4_bench.json")))
+    full["config"].update(devices=[0], shared_device=False)
+    fat = copy.deepcopy(full)
+    fat["config"]["workload"] = "x" * 5000
+    fat["cpu_baseline"]["sample"] = "y" * 5000
+    fat["roofline"]["traffic_source"] = "z" * 5000
+    fat["config"]["partitions"] = {"stage %d" % i: i for i in range(400)}
+    for rec in (full, fat):
+        line = b.compact_line(rec, "bench_full.json")
+        text = json.dumps(line)
+        assert len(text) < 4096, len(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "probe"):
+            assert k in line, k
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in line["roofline"], k
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in line["cpu_baseline"], k
+        assert line["config"]["workload"] and line["config"]["baseline_config"] == 2
+        assert line["value"] == rec["value"] and line["roofline"]["frac"] == rec["roofline"]["frac"]
+    # the normal record keeps the optional groups too
+    line = b.compact_line(full, "bench_full.json")
+    assert set(line["other_configs"]) == {"1", "3", "5"} and "ch2_us_per_block" in line["side"]
+    # a multi-rank record without roofline / cpu legs still serialises
+    bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data", "config")}
+    line = b.compact_line(dict(bare, roofline=None, probe=None, cpu_baseline=None))
+    assert line["roofline"] is None and line["cpu_baseline"] is None
+
+
+def test_bare_gpus_n_builds_a_launcher_command(monkeypatch):
+    """`python bench.py --gpus N` typed bare re-executes itself under torch.distributed.run with N ranks on 127.0.0.1 and a free
+    port; with fewer devices than ranks the ranks share device 0 over gloo."""
+    b = _bench()
+    seen = {}
+
+    def fake_execve(exe, cmd, env):
+        seen.update(exe=exe, cmd=cmd, env=env)
+        raise SystemExit(0)
+    monkeypatch.setattr(b.os, "execve", fake_execve)
+    monkeypatch.setattr(b.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    with pytest.raises(SystemExit):
+        b.self_launch(4, 1)
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["REEVR_BENCH_SAME_DEVICE"] == "1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    with pytest.raises(SystemExit):
+        b.self_launch(4, 8)
+    assert "REEVR_BENCH_SAME_DEVICE" not in seen["env"] or os.environ.get("REEVR_BENCH_SAME_DEVICE") == "1"

@@ -105,9 +105,31 @@ def test_bench_eight_ranks_control_flow(extra):
         assert rec["config"]["gathered_channels_per_gpu"] == 8
 
 
-def test_bench_refuses_gpus_without_launcher():
-    """`python bench.py --gpus 8` outside torch.distributed.run must fail, not report a 1-GPU number."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+@pytest.mark.parametrize("extra", [["--config", "4", "--blocks-per-step", "32"],
+                                   ["--config", "2", "--channels", "8", "--blocks-per-step", "32"]], ids=["cfg4", "cfg2"])
+def test_bench_bare_gpus_two_launches_itself(extra):
+    """`python bench.py --gpus 2 ...` as the driver types it -- no launcher, no WORLD_SIZE: bench.py starts its own two ranks
+    under torch.distributed.run (one device each over RCCL where two are visible; on a 1-GPU box both on device 0 over
+    gloo, and the line says so) and rank 0 prints the one compact line LAST with n_gpus == 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                            "TORCHELASTIC_RUN_ID", "REEVR_BENCH_SAME_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--cpu-seconds", "0", "--side", "0", "--watchdog", "120"] + extra, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert out_lines[-1].startswith("{") and len(out_lines[-1]) < 4096        # the compact line is the LAST stdout line
+    assert len([ln for ln in out_lines if ln.startswith("{")]) == 1
+    rec = json.loads(out_lines[-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["gather"] is True
+    assert rec["config"]["devices"] == ([0, 1] if _ndev() >= 2 else [0, 0])
+    assert rec["config"]["shared_device"] == (_ndev() < 2)
+    assert rec["config"]["gather_matches_output"] is True and rec["probe"]["ok"] is True
+
+
+def test_bench_refuses_a_mismatched_world_size():
+    """Under a launcher that started a different number of ranks than --gpus says, bench.py must fail, not report a number."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
