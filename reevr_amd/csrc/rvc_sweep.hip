@@ -348,7 +348,17 @@ struct SweepLdsCfg {
   static_assert((A - 1) * LPW <= 63, "vmcnt immediate");
 };
 
-template <int KW, int NKW, int A, int STAGE, bool NT, int LB>
+//
+// M3 (round 5): the THREE-product complex multiply-accumulate. The K = 32 walk does 16 flop per HBM byte and is bound by VALU
+// issue, not by bandwidth (profiles/r4_sweep_lds.txt), so the four FMAs per (IR bin, delay-line bin, output block) of
+// Utilities.cpp:62-111 are replaced by three: with h = (hr, hi), x = (xr, xi)
+//   S1 += xr (hr + hi),  S2 += hr (xi - xr),  S3 += hi (xr + xi);   re = S1 - S3,  im = S1 + S2   (at the end of the walk).
+// (hr + hi) is formed once per fetched IR row, (xi - xr) and (xr + xi) once per delay-line row when it enters the window -- both
+// amortised over the KW accumulators --, so a step costs 3 KW FMAs + ~8 other VALU instead of 4 KW + 4: same HBM bytes, a
+// quarter fewer multiply-adds, three accumulators and three window values per bin instead of two. The packed first bin (DC,
+// Nyquist: two REAL products) rides along by per-lane operands: hs = h.x, hr = h.y, hi = 0, window d = x.y -> S1 = DC sum, S2 =
+// Nyquist sum, S3 = 0, and im = S2 for that lane.
+template <int KW, int NKW, int A, int STAGE, bool NT, int LB, bool M3>
 __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a, const int rot) {
   typedef SweepLdsCfg<KW, NKW, A> G;
   constexpr int C = G::C, NH = G::NH, PRE = G::PRE, XR = G::XR, LPW = G::LPW, PIECE = G::PIECE;
@@ -399,9 +409,20 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
     }
   };
 
+  // M3: acc[t] = (S1, S2), acc3[t] = S3; w[j] = (xr, xi - xr), w3[j] = xr + xi. Else acc[t] = (re, im), w[j] = (xr, xi).
   V acc[KW], w[KW];
+  float acc3[M3 ? KW : 1], w3[M3 ? KW : 1];
 #pragma unroll
   for (int t = 0; t < KW; ++t) acc[t] = make_float2(0.f, 0.f);
+  if constexpr (M3) {
+#pragma unroll
+    for (int t = 0; t < KW; ++t) acc3[t] = 0.f;
+  }
+  const float pm = packed ? 0.f : 1.f;             // (per-lane factor instead of selects: one FMA forms hr + hi / xi - xr)
+  auto to3 = [&](const V x, V &wv, float &ws) {   // a delay-line bin as the three-product form keeps it
+    wv = make_float2(x.x, fmaf(-pm, x.x, x.y));
+    ws = x.x + x.y;
+  };
   // the window at step 0: rows cb .. cb + KW - 1, straight from global (ordinary loads; rows that do not count -- for a
   // first-level sweep nearly all of them: they have not arrived yet -- are not requested: wave-uniform branches)
   {
@@ -426,6 +447,10 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
   //  means "everything requested so far", not behind the next chunk's requests)
 #pragma unroll
   for (int t = 0; t < KW; ++t) asm volatile("" : "+v"(w[t].x), "+v"(w[t].y));
+  if constexpr (M3) {
+#pragma unroll
+    for (int t = 0; t < KW; ++t) to3(w[t], w[t], w3[t]);
+  }
 
   const V *ldsH = reinterpret_cast<const V *>(ring) + bt * 64 + lane;
   const V *ldsX = reinterpret_cast<const V *>(ring + NH * PIECE) + bt * 64 + lane;
@@ -454,11 +479,25 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
       const V h = hq[q * RV];
       const V xl = xq[q * RV];
       const V xin = valid_step(s - kw * KW) ? xl : make_float2(0.f, 0.f);
-      const float hz = packed ? 0.f : h.y;          // first bin: ordinary (re, re, im) / packed (DC gain, Nyquist gain, 0)
-      const float h3 = packed ? h.y : h.x;
+      if constexpr (M3) {
+        const float hs = fmaf(pm, h.y, h.x);
+        const float hr = packed ? h.y : h.x;
+        const float hi = pm * h.y;
 #pragma unroll
-      for (int t = 0; t < KW; ++t) sweep_mac(acc[t], h, w[(t - u) & (KW - 1)], hz, h3);
-      w[(KW - 1 - u) & (KW - 1)] = xin;             // (the slot of the row that just left the window)
+        for (int t = 0; t < KW; ++t) {
+          const int j = (t - u) & (KW - 1);
+          acc[t].x = fmaf(w[j].x, hs, acc[t].x);
+          acc[t].y = fmaf(hr, w[j].y, acc[t].y);
+          acc3[t] = fmaf(hi, w3[j], acc3[t]);
+        }
+        to3(xin, w[(KW - 1 - u) & (KW - 1)], w3[(KW - 1 - u) & (KW - 1)]);
+      } else {
+        const float hz = packed ? 0.f : h.y;          // first bin: ordinary (re, re, im) / packed (DC gain, Nyquist gain, 0)
+        const float h3 = packed ? h.y : h.x;
+#pragma unroll
+        for (int t = 0; t < KW; ++t) sweep_mac(acc[t], h, w[(t - u) & (KW - 1)], hz, h3);
+        w[(KW - 1 - u) & (KW - 1)] = xin;             // (the slot of the row that just left the window)
+      }
     }
     hrow = hrow + C == NH ? 0 : hrow + C;
     xrow = xrow + C == XR ? 0 : xrow + C;
@@ -475,6 +514,10 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
   for (; s0 + KW <= P; s0 += KW) body(s0, std::false_type());
   if (s0 < P) body(s0, std::true_type());
   sweep_wait_vm<0>();                               // (no DMA piece may land after this workgroup's LDS has been handed on)
+  if constexpr (M3) {                               // (S1, S2), S3 -> (re, im)
+#pragma unroll
+    for (int t = 0; t < KW; ++t) acc[t] = make_float2(acc[t].x - acc3[t], packed ? acc[t].y : acc[t].x + acc[t].y);
+  }
   float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
   const long long k1 = a.k0 + (long long)kw * KW;
   if (a.Ybase) {                                    // (+ rows of a level below: all requests first, then the stores)
@@ -523,14 +566,14 @@ static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
   else hipLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a, rot);
 }
 
-template <int KW, int NKW, int A, int STAGE, bool NT, int LB>
+template <int KW, int NKW, int A, int STAGE, bool NT, int LB, bool M3 = false>
 static void launch_lds_variant(const FirArgs &a, int channels, hipStream_t st) {
   const dim3 grid(a.B / 128, channels), block(128 * NKW);
   const int rot = (grid.x >= 8 && launch_tune().tile_rot) ? 1 : 0;
   hipEvent_t ea, eb;
   get_launch_events(&ea, &eb);
-  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep_lds<KW, NKW, A, STAGE, NT, LB>), grid, block, 0, st, ea, eb, 0, a, rot);
-  else hipLaunchKernelGGL((k_fdl_sweep_lds<KW, NKW, A, STAGE, NT, LB>), grid, block, 0, st, a, rot);
+  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep_lds<KW, NKW, A, STAGE, NT, LB, M3>), grid, block, 0, st, ea, eb, 0, a, rot);
+  else hipLaunchKernelGGL((k_fdl_sweep_lds<KW, NKW, A, STAGE, NT, LB, M3>), grid, block, 0, st, a, rot);
 }
 
 // "sweep_lds": the LDS-fed form (accumulators split over waves) for first-level sweeps: -1 = where it is the default (32-block
@@ -557,8 +600,13 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
     // 1.35 ms per 8192-channel launch -- and tie on 8192-bin rows (config 3's 350 partitions: 23.6 / 23.3 / 23.2 ms), where every
     // form executes 63-64 TFLOP/s of FMAs at a core clock the power limit holds at 1.70 GHz: that launch is bound by VALU work
     // and power, not by HBM or occupancy.
-    if (launch_tune().sweep_lds == 2) launch_lds_variant<8, 4, 3, STAGE, true, 4>(a, channels, st);
-    else if (launch_tune().sweep_lds == 1) launch_lds_variant<16, 2, 3, STAGE, true, 3>(a, channels, st);
+    const int m3 = launch_tune().mac3;              // three-product multiply-accumulate (k_fdl_sweep_lds, M3): -1 = the default
+    if (launch_tune().sweep_lds == 2) {
+      if (m3 > 0) launch_lds_variant<8, 4, 3, STAGE, true, 4, true>(a, channels, st);
+      else launch_lds_variant<8, 4, 3, STAGE, true, 4>(a, channels, st);
+    } else if (launch_tune().sweep_lds == 1) launch_lds_variant<16, 2, 3, STAGE, true, 3>(a, channels, st);
+    else if (m3 == 2) launch_lds_variant<16, 2, 1, STAGE, true, 3, true>(a, channels, st);
+    else if (m3 != 0) launch_lds_variant<16, 2, 1, STAGE, true, 4, true>(a, channels, st);
     else launch_lds_variant<16, 2, 1, STAGE, true, 4>(a, channels, st);
   } else if (a.M == 16 && lds_ok && launch_tune().sweep_lds == 3) {
     // (measurement only: 16-block tiles through the LDS-fed form lose to the one-wave 16-byte-lane form on config 2's 57 x

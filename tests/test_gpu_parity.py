@@ -1500,6 +1500,19 @@ def _fdl_case(rng, nch, B, P, M, rows):
     (1, 2, 16384, 29, 16, 1, 64, "own_d1"),
     (1, 2, 16384, 40, 32, 1, 100, "lds32_d1"),
     (1, 2, 1024, 11, 16, 1, 2, "own_early_d1"),
+    # round 5: the three-product complex multiply-accumulate of the LDS-fed 32-block sweeps (S1 / S2 / S3 accumulators, combined at
+    # the end of the walk; the packed DC / Nyquist bin through per-lane operands) -- forced on (_m3) and off (_m4) whatever ships
+    (1, 2, 512, 94, 32, 0, 128, "lds32_m3"),
+    (1, 3, 8192, 37, 32, 2, 200, "lds32_m3"),
+    (1, 2, 128, 5, 32, 0, 64, "lds32_m3"),
+    (1, 2, 256, 1, 32, 2, 64, "lds32_m3"),
+    (1, 2, 512, 40, 32, 2, 7, "lds32_early_m3"),
+    (1, 2, 512, 50, 32, 0, 96, "lds32_allrows_m3"),
+    (1, 2, 1024, 45, 32, 2, 96, "lds32_4x8_m3"),
+    (1, 2, 16384, 40, 32, 1, 100, "lds32_m3_d1"),
+    (1, 2, 512, 94, 32, 0, 128, "lds32_m4"),
+    (1, 3, 8192, 37, 32, 2, 200, "lds32_m4"),
+    (1, 2, 16384, 40, 32, 1, 100, "lds32_m4_d1"),
 ])
 def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant):
     """The complex multiply-accumulate kernels ALONE (SURVEY a-12): one launch of the general delay-line launcher / a sweep
@@ -1518,6 +1531,8 @@ def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant)
     Xre, Xim = split((nch, rows))
     d1 = variant.endswith("_d1")
     variant = variant[:-3] if d1 else variant
+    mac3 = {"_m3": 1, "_m4": 0}.get(variant[-3:], -1)
+    variant = variant[:-3] if mac3 >= 0 else variant
     second = variant == "second"
     has_add = variant in ("patch", "second")
     Are, Aim = split((nch, M if kind == 1 else 1)) if has_add else (None, None)
@@ -1542,7 +1557,7 @@ def test_delay_line_kernels_in_isolation(kind, nch, B, P, M, delay, k0, variant)
     fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
     tune = {"split": 1, "own": 0, "own_early": 0, "second": 0}.get(variant)
     lds = 2 if variant.startswith("lds32_4x8") else (3 if variant.startswith("lds16") else (0 if variant == "one_wave32" else (1 if variant.endswith("deep") else -1)))
-    with reevr_amd.tuning(sweep_lds=lds, **({"sweep_split": tune} if tune is not None else {})):
+    with reevr_amd.tuning(sweep_lds=lds, mac3=mac3, **({"sweep_split": tune} if tune is not None else {})):
         ok = L.lib().rvc_debug_fdl(0, kind, nch, B, P, M, delay, k0, rows, fp(H), fp(X), fp(A), fp(got), x_hi, x_from)
     assert ok == 1
     if kind == 1:                                   # output row j sits in slot (k0 + j) & (M - 1)
