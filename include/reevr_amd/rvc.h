@@ -62,19 +62,21 @@ enum {
 #define RVC_FLAG_FFT_F64 4u     /* run EVERY transform in double, spectra still stored as float -- the reference's
                                    precision (Ooura in double, AudioFFT.cpp:114-159). Largest partition
                                    RVC_MAX_BLOCK/2. IR spectra are computed in double at init in any mode.
-                                   Default (neither this nor RVC_FLAG_FFT_F32): sets of up to 8 channels -- the
-                                   plug-in's case, where a transform costs nothing -- run the stages with
-                                   partitions of 2048 ... 8192 samples in double (so that the reference's own
-                                   known-answer rule, test/Test.cpp:129-145, holds for every one of its cases) and
-                                   smaller partitions in float; larger (lock-step) sets run float32 throughout
-                                   (~1e-7 relative, 100x inside the 1e-5 RMS parity bound). */
-#define RVC_FLAG_FFT_F32 256u   /* float32 transforms also for small sets (the default of large ones) */
+                                   Default (none of the three precision flags): stages with partitions below 2048 samples (and
+                                   the 16384-sample ones, which do not fit one CU's LDS in double) transform in float; stages
+                                   with partitions of 2048 ... 8192 samples run
+                                     - both transforms in double in sets of up to 8 channels (the plug-in's case, where a
+                                       transform costs nothing),
+                                     - the INVERSE transform in double in larger (lock-step) sets (round 5): the float noise that
+                                       breaks the reference's own known-answer rule (test/Test.cpp:129-145) on its ramp signals is
+                                       the inverse transform's -- small outputs sharing a 4096-point transform with outputs of
+                                       1.5e7 --; with it in double all 58 of the reference's cases pass that rule (margin <= 0.16)
+                                       at -2.4 % on BASELINE config 2 at 4096 channels (both in double: -5.3 %).
+                                   rvc_set_plan reports what runs (head_f64 / tail_f64: bit 0 forward, bit 1 inverse). */
+#define RVC_FLAG_FFT_F32 256u   /* float32 transforms throughout, whatever the set size (~1e-7 relative, 100x inside the 1e-5 RMS
+                                   parity bound; the reference's own rule then fails by up to 10 % on 4 of its 58 cases) */
 #define RVC_FLAG_FFT_F64_LONG 2048u /* the small sets' default rule for a set of ANY size: stages with partitions of 2048 ... 8192
-                                   samples transform in double, smaller ones in float. For lock-step sets of more than 8
-                                   channels whose outputs must meet the reference's own known-answer rule (Test.cpp:129-145)
-                                   and not only the 1e-5 RMS bar: with the plug-in's geometries (head 256 / 512, tail 8192) only
-                                   the tail stage's transforms change -- the one-launch per-block path stays --, measured at
-                                   4096 channels in bench.py's `regimes.fft_f64_long`. */
+                                   samples run BOTH transforms in double, smaller ones in float. */
 
 #define RVC_FLAG_FIXED_PARTITIONS 8u /* always use the reference's head/tail partition sizes and stage split. Default: a long
                                    call (>= 5 tail blocks) computes the tail blocks that lie entirely
@@ -246,7 +248,7 @@ typedef struct rvc_plan {
   int tail_partitions;
   int wide_partitions;
   int tail_delay;               /* tail blocks between an input block and its first contribution: 2 (the reference's), 1, 0 = no tail */
-  int head_f64, tail_f64;       /* that stage's transforms run in double */
+  int head_f64, tail_f64;       /* that stage's transforms in double: bit 0 the forward, bit 1 the inverse one (3 = both) */
   int head_tile_blocks;         /* blocks per first-level time tile of the stage's delay line: 0 not tiled, 8 one level, 16 / 32 two */
   int tail_tile_blocks;
   int block_path;               /* per-block calls: 0 one fused launch per block, 1 transform / delay line / inverse launches */

@@ -11,7 +11,7 @@
  * double (AudioFFT.cpp:114-159); here it is a textbook radix-2 complex FFT of half
  * size plus a real split, also in double, rounded to float at the same two places.
  * Both are exact DFTs to ~1e-16, so the float results agree to the last bit except
- * for rare 1-ulp ties; tests/test_oracle_vs_ref.py bounds the difference.
+ * for rare 1-ulp ties; tests/test_oracle.py::test_oracle_vs_live_reference bounds the difference.
  */
 #include "rvc_oracle.h"
 

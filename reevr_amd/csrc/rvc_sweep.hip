@@ -600,7 +600,10 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
     // 1.35 ms per 8192-channel launch -- and tie on 8192-bin rows (config 3's 350 partitions: 23.6 / 23.3 / 23.2 ms), where every
     // form executes 63-64 TFLOP/s of FMAs at a core clock the power limit holds at 1.70 GHz: that launch is bound by VALU work
     // and power, not by HBM or occupancy.
-    const int m3 = launch_tune().mac3;              // three-product multiply-accumulate (k_fdl_sweep_lds, M3): -1 = the default
+    // three-product multiply-accumulate (k_fdl_sweep_lds, M3): default on -- measured on MI355X (profiles/r5_mac3.txt), one queue:
+    // config 3's 175 x 16384-bin tail 23.6 -> 20.9 ms per 2048-channel launch (0.54 -> 0.61 of the HBM peak), config 1's 94 x
+    // 512-bin line 1.38 -> 1.27 ms (0.66 -> 0.71); 2 = the same at three workgroups per CU (no different); the 4 x 8 form loses
+    const int m3 = launch_tune().mac3;
     if (launch_tune().sweep_lds == 2) {
       if (m3 > 0) launch_lds_variant<8, 4, 3, STAGE, true, 4, true>(a, channels, st);
       else launch_lds_variant<8, 4, 3, STAGE, true, 4>(a, channels, st);
@@ -613,7 +616,8 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
     //  8192-bin tail -- 6.38 ms per launch against 6.64 (2 x 8, one chunk ahead), 6.98 (2 x 8, three chunks), 6.87 / 7.17 (one
     //  wave of 16 fed through the rings, one / three chunks ahead): at 8 flop per byte that sweep is not VALU-bound, and the
     //  one-wave form's 16-byte lanes move twice the bytes per request; profiles/r4_sweep_lds.txt)
-    launch_lds_variant<8, 2, 1, STAGE, true, 4>(a, channels, st);
+    if (launch_tune().mac3 > 0) launch_lds_variant<8, 2, 1, STAGE, true, 4, true>(a, channels, st);
+    else launch_lds_variant<8, 2, 1, STAGE, true, 4>(a, channels, st);
   } else if (a.M == 32) {
     if (deep) launch_variant<32, 1, STAGE, 2, 8, 2, true>(a, channels, st);
     else launch_variant<32, 1, STAGE, 2, 4, 2, true>(a, channels, st);
