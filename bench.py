@@ -947,6 +947,7 @@ def main():
     # ---- per-kernel durations, live, with HIP events on the streams the kernels run on ----
     kern = ls.kernel_times(KERNEL_NAMES)
     PA, PT = conv.partitions(0), conv.partitions(1)
+    transforms = transforms_form(conv)
     tail_x = ls.tail_used                 # the tail block the set runs (twice the requested one where the engine widens long tails)
     tail_form = tail_stage_form(conv, head, tail)
     tiled = ls.tiled
@@ -1121,7 +1122,7 @@ def main():
                    "frames_per_channel_per_step": frames_step, "host_block": host_block,
                    "calls_per_step": 1 if long_call else frames_step // host_block,
                    "partitions": {"zero-latency stage (block %d)" % head: PA, "tail stage (block %d)" % tail_x: PT},
-                   "tail_stage": tail_form, "transforms": transforms_form(conv),
+                   "tail_stage": tail_form, "transforms": transforms,
                    "tail_block_requested": tail, "tail_block_run": tail_x,
                    "tile_blocks": tiles, "subsets": subsets,
                    "resident_GB": round(nch * 8.0 * (PA * head + (PT + 2) * tail_x) * 2 / 1e9, 2),

@@ -127,6 +127,30 @@ def test_bench_bare_gpus_two_launches_itself(extra):
     assert rec["config"]["gather_matches_output"] is True and rec["probe"]["ok"] is True
 
 
+def test_bench_single_gpu_line_with_side_legs():
+    """The N = 1 run as the driver types it, in small: the side legs (reference-order schedule, stereo pair, CPU baseline) run
+    after the measured set has been closed -- everything the record needs from that set must have been read before -- and
+    the LAST stdout line is the compact (< 4 KB) line with roofline and cpu_baseline; the full record is on disk."""
+    import tempfile
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    with tempfile.TemporaryDirectory() as d:
+        full = os.path.join(d, "full.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--channels", "64",
+                            "--blocks-per-step", "32", "--configs", "", "--regimes", "0", "--cpu-seconds", "2", "--full-out", full,
+                            "--watchdog", "200"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        out_lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert out_lines[-1].startswith("{") and len(out_lines[-1]) < 4096
+        rec = json.loads(out_lines[-1])
+        rec_full = json.load(open(full))
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["value"] > 0 and rec["probe"]["ok"] is True
+    assert rec["roofline"]["bound"] == "hbm" and 0 < rec["roofline"]["frac"] <= 1.0 and rec["roofline"]["kernel"]
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["cores"] == 1 and rec["cpu_baseline"]["kind"] in ("reference", "port")
+    assert "transforms" in rec["config"] and rec["config"]["channels_per_gpu"] == 64
+    assert rec["side"]["reference_schedule_Msamples_s"] > 0 and rec["side"]["stereo_pair_us_per_block"] > 0
+    assert rec_full["value"] == rec["value"] and "roofline_all" in rec_full and "kernels_ms" in rec_full
+
+
 def test_bench_refuses_a_mismatched_world_size():
     """Under a launcher that started a different number of ranks than --gpus says, bench.py must fail, not report a number."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
