@@ -149,7 +149,6 @@ const TuneKey kTuneKeys[] = {
     {"patch_nt", nullptr, &rvc::LaunchTune::patch_nt}, {"sweep_split", nullptr, &rvc::LaunchTune::sweep_split},
     {"sweep_lw", nullptr, &rvc::LaunchTune::sweep_lw}, {"sweep_d", nullptr, &rvc::LaunchTune::sweep_d},
     {"sweep_lds", nullptr, &rvc::LaunchTune::sweep_lds}, {"mac3", nullptr, &rvc::LaunchTune::mac3},
-    {"fft_pf", nullptr, &rvc::LaunchTune::fft_pf},
 };
 int *tune_slot(Tuning &t, const std::string &key) {
   for (const TuneKey &k : kTuneKeys)
@@ -1536,7 +1535,7 @@ int subset_count(const rvc_set *s, size_t head_block, size_t max_len) {
   // profiles/r3_tuning.txt); long calls gain nothing from it
   if (n < 0) n = (s->nch >= 2048 && max_len <= 2 * next_pow2(head_block ? head_block : 1)) ? (s->nch >= 8192 ? 4 : 2) : 1;
   if (n > 8) n = 8;
-  while (n > 1 && (s->nch % n != 0 || s->nch / n < 2)) --n;
+  while (n > 1 && s->nch / n < 2) --n;          // (children need not be equal: make_kids deals the remainder out one by one)
   return n < 1 ? 1 : n;
 }
 void drop_kids(rvc_set *s) {
@@ -1567,16 +1566,19 @@ bool make_kids(rvc_set *s, int n) {
   drop_kids(s);
   if (s->streams_ok || s->live) free_device_state(s);
   drop_streams(s);
-  const int per = s->nch / n;
+  const int per = s->nch / n, rem = s->nch % n;   // the first `rem` children serve one channel more
+  int c0 = 0;
   for (int k = 0; k < n; ++k) {
-    rvc_set *c = rvc_set_create(per, s->device, s->flags | RVC_FLAG_NO_SUBSETS);
+    const int mine = per + (k < rem ? 1 : 0);
+    rvc_set *c = rvc_set_create(mine, s->device, s->flags | RVC_FLAG_NO_SUBSETS);
     if (!c) { drop_kids(s); return false; }
     c->timing = s->timing;
     c->is_kid = true;
     c->tune = s->tune;
     c->plan_nch = s->nch;
     s->kids.push_back(c);
-    s->kid_c0.push_back(k * per);
+    s->kid_c0.push_back(c0);
+    c0 += mine;
   }
   return true;
 }

@@ -41,8 +41,6 @@ struct FwdArgs {            // real time-domain segment(s) -> spectrum row(s)
   long long row0;           // absolute row index of row 0
   unsigned long long row_mask;   // row slot = (row0 + r) & row_mask
   int rows;                 // set by the launcher (several small transforms share a workgroup)
-  int pf_stride;            // set by the launcher: > 0 = workgroups the device holds of a one-workgroup-per-CU transform; every
-                            // workgroup then touches the input row of workgroup (own + pf_stride), its successor on the CU
 };
 
 struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency-domain delay line)
@@ -92,7 +90,6 @@ struct InvArgs {            // spectrum row(s) -> last B samples of the inverse 
   unsigned long long add_mask;
   long long add_from;       // add applies for n >= add_from
   int rows;                 // set by the launcher
-  int pf_stride;            // set by the launcher (see FwdArgs)
 };
 
 // One head block per call (the plugin's per-block process()): ingest + forward transform +
@@ -175,7 +172,6 @@ struct LaunchTune {
   int sweep_lw = 0;      // 4 = 16-byte lanes for the 16-block first-level sweeps (default by row length)
   int sweep_d = 0;       // 8 = eight row pairs requested ahead in the long-tile sweeps (default 4)
   int sweep_lds = -1;    // LDS-fed first-level sweeps, accumulators split over waves (rvc_sweep.hip): -1 default / 0 off / 1 / 2 / 3
-  int fft_pf = 0;        // 16384-bin transforms (one workgroup per CU): touch the successor workgroup's input row (L2 / MALL prefetch)
   int mac3 = -1;         // three-product complex multiply-accumulate in the LDS-fed 32-block sweeps: -1 default / 0 off / 1 on
 };
 void set_launch_tune(const LaunchTune *t);   // thread-local; nullptr = the defaults above

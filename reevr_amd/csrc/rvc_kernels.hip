@@ -595,17 +595,6 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const TW &T, con
 // geometry): the twiddles are fetched per pass, one pass ahead, instead of being held in registers from the top of the kernel
 // -- the latency form's choice, right for a handful of rows --: <= 64 instead of 83 / 92 registers, FOUR workgroups per CU
 // instead of two, and a launch of thousands of rows is a matter of how many rows a CU overlaps.
-// One-workgroup-per-CU transforms (16384 bins: 136 KiB of LDS): nobody runs under a row's load phase. Poor man's overlap: every
-// workgroup touches ONE 128-byte line per thread of the input row of its successor on the CU (the workgroup pf_stride later in
-// dispatch order), so that row is on its way into the L2 / the memory-side cache while this one's passes run. The destination
-// register stays reserved until `pf_done` (loads return in order: by then the touch has long landed).
-__device__ __forceinline__ float pf_touch(const void *line) {
-  float d;
-  asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(line) : "memory");
-  return d;
-}
-__device__ __forceinline__ void pf_done(float d) { asm volatile("" ::"v"(d)); }
-
 template <int LOGB, typename R, bool MANY = false>
 __global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_fwd(const FwdArgs a) {
   typedef Plan8<LOGB> P;
@@ -636,20 +625,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_fwd(cons
   const C *tw = reinterpret_cast<const C *>(a.tw);
   const C *tw8 = reinterpret_cast<const C *>(a.tw8);
   const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
-  float pf = 0.f;
-  if constexpr (LOGB == 14 && sizeof(R) == 4) {
-    if (a.pf_stride > 0) {                       // (successor in dispatch order: same XCD, pf_stride / 8 items on)
-      const unsigned G = gridDim.x, total = G * gridDim.y;
-      const unsigned lin = blockIdx.x + G * blockIdx.y + (unsigned)a.pf_stride;
-      if (lin < total) {
-        const unsigned xcd = lin & 7u, slot = lin >> 3;
-        const unsigned item = xcd * (total >> 3) + (xcd < (total & 7u) ? xcd : (total & 7u)) + slot;
-        const long long sn = a.seg0 + (long long)(item % G) * B + (long long)threadIdx.x * 32;   // 32 floats = one 128-byte line
-        if (sn >= a.lo && sn + 32 <= a.hi && (!a.src2 || sn + 32 <= a.src2_from))
-          pf = pf_touch(a.src + (long long)(item / G) * a.src_chan_stride + ((unsigned long long)sn & a.src_mask));
-      }
-    }
-  }
 
   TW T;
   T.load(tw8, tw, tid);
@@ -754,7 +729,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_fwd(cons
   };
   load_ws();   // requested before the transform: the latency hides behind it
   fft8_core<LOGB, false, R, false, TW>(v, lds, T, tid);
-  pf_done(pf);
 
   constexpr bool kLin = P::kLin;
   const int lt = lpad(tid), ln = lpad_neg(tid);
@@ -839,14 +813,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_inv(cons
   const C *tw = reinterpret_cast<const C *>(a.tw);
   const C *tw8 = reinterpret_cast<const C *>(a.tw8);
   const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
-  float pf = 0.f;
-  if constexpr (LOGB == 14 && sizeof(R) == 4) {
-    if (a.pf_stride > 0) {                       // (pf_touch: the successor workgroup's spectrum row, one line per thread)
-      const unsigned G = gridDim.x, lin = blockIdx.x + G * blockIdx.y + (unsigned)a.pf_stride;
-      if (lin < G * gridDim.y && (int)(lin % G) < a.rows)
-        pf = pf_touch(a.Y + (long long)(lin / G) * a.y_chan_stride + (long long)(lin % G) * B + (long long)threadIdx.x * 16);
-    }
-  }
 
   // Inverse split in PAIRS (mirror of the forward kernel): the first pass wants Z[in_idx(e)]; half of a
   // thread's indices are "low" (k < B/2). For each low k it loads Y[k], Y[B-k] and one twiddle and
@@ -931,7 +897,6 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_inv(cons
       if (!P::out_is_low(e)) addv[q++] = ab[(unsigned)P::out_idx(tid, e)];
   }
   fft8_core<LOGB, true, R, false, TW>(v, lds, T, tid);
-  pf_done(pf);
 
   if (!live) return;                                        // (after the last barrier)
   if (flat) {
@@ -2031,17 +1996,6 @@ __global__ void __launch_bounds__(256) k_ingest(const IngestArgs a) {
 // "fft_many": -1 = the MANY form of the 4096-bin transforms from 2048 rows on, 0 = never, 1 = always
 static bool fft_many_rows(long long items) { const int m = launch_tune().fft_many; return m > 0 || (m < 0 && items >= 2048); }
 
-static int device_cus() {     // CUs of the current device (cached per device; 0: unknown)
-  static int cache[16] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
-  if (cache[dev] == 0) {
-    int cus = 0;
-    cache[dev] = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ? cus : -1;
-  }
-  return cache[dev] > 0 ? cache[dev] : 0;
-}
-
 template <int LOGB, typename R>
 static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStream_t st) {
   if constexpr (LOGB >= 6) {
@@ -2049,7 +2003,6 @@ static hipError_t launch_fwd_t(const FwdArgs &a, int rows, int channels, hipStre
     const size_t lds = sizeof(cx<R>) * P::LDS_ELEMS * P::TPW;
     FwdArgs b = a;
     b.rows = rows;
-    b.pf_stride = (LOGB == 14 && launch_tune().fft_pf > 0) ? device_cus() : 0;
     if constexpr (LOGB == 12 && sizeof(R) == 4) {
       if (fft_many_rows((long long)rows * channels)) {
         RVC_LAUNCH((k_fft8_fwd<LOGB, R, true>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
@@ -2070,7 +2023,6 @@ static hipError_t launch_inv_t(const InvArgs &a, int rows, int channels, hipStre
     const size_t lds = sizeof(cx<R>) * P::LDS_ELEMS * P::TPW;
     InvArgs b = a;
     b.rows = rows;
-    b.pf_stride = (LOGB == 14 && launch_tune().fft_pf > 0) ? device_cus() : 0;
     if constexpr (LOGB == 12 && sizeof(R) == 4) {
       if (fft_many_rows((long long)rows * channels)) {
         if (b.add) RVC_LAUNCH((k_fft8_inv<LOGB, R, true, true>), dim3((rows + P::TPW - 1) / P::TPW, channels), dim3(P::WG), lds, st, b);
