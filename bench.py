@@ -221,8 +221,13 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
         return float(np.mean([min(P, K2 * g + K2 + 1 - delay) + K2 * g + 2 * K2 for g in gs])) if K1 > K2 else 0.0
     exe = {}
     if KA:
-        # audio part (H0, H1, X_{k-1}, accumulator read; X_k written; samples) + on average (K2-1)/2 recent partitions patched
-        exe["fused_block"] = 5 * row_h + io_blk + ((K2 - 1) / 2.0 * 2 + 2) * row_h * (K2 - 1) / K2
+        if conv.plan()["head_patch_in_launch"]:
+            # round 5: the launch patches its OWN block and hands the row over through LDS -- audio part (H0, H1, X_{k-1} read; X_k
+            # written; samples) + the block's sweep row + on average (K2-1)/2 recent partitions (an IR row and a delay-line row each)
+            exe["fused_block"] = 4 * row_h + io_blk + ((K2 - 1) / 2.0 * 2 + 1) * row_h
+        else:
+            # audio part (H0, H1, X_{k-1}, accumulator read; X_k written; samples) + on average (K2-1)/2 recent partitions patched
+            exe["fused_block"] = 5 * row_h + io_blk + ((K2 - 1) / 2.0 * 2 + 2) * row_h * (K2 - 1) / K2
         # IR rows 2.. + arrived delay-line rows read once, KA partial rows written (the two newest partitions are the per-block launch's)
         exe["sweep_head"] = ((PA - 2) + (PA - 2) + KA) * row_h
         exe["sweep2_head"] = sweep2_rows(KA, PA - 2, 2) * row_h

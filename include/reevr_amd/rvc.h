@@ -255,6 +255,9 @@ typedef struct rvc_plan {
   int reference_structure;      /* 1: stage split and tail delay are the reference's for these block sizes */
   size_t long_call_block;       /* block of the whole-IR delay line long calls use (adaptive partitioning), 0 = none */
   size_t wide_block;            /* block of the wide stage very long calls use, 0 = none */
+  int head_patch_in_launch;     /* 1: time-tiled zero-latency stage whose per-block launch patches its OWN block's accumulator and hands
+                                   it to the audio wave through LDS (head 128 / 256 / 512); 0: the launch prepares the next block's
+                                   accumulator through memory, or the stage is not tiled */
 } rvc_plan;
 /* plan_size = sizeof(rvc_plan) as the caller compiled it (the struct may grow at its end). 1 = filled. */
 int rvc_set_plan(const rvc_set *s, rvc_plan *plan, size_t plan_size);

@@ -115,7 +115,8 @@ class Plan(C.Structure):                # struct rvc_plan
                 ("zero_latency_samples", C.c_size_t), ("head_partitions", C.c_int), ("tail_partitions", C.c_int),
                 ("wide_partitions", C.c_int), ("tail_delay", C.c_int), ("head_f64", C.c_int), ("tail_f64", C.c_int),
                 ("head_tile_blocks", C.c_int), ("tail_tile_blocks", C.c_int), ("block_path", C.c_int),
-                ("reference_structure", C.c_int), ("long_call_block", C.c_size_t), ("wide_block", C.c_size_t)]
+                ("reference_structure", C.c_int), ("long_call_block", C.c_size_t), ("wide_block", C.c_size_t),
+                ("head_patch_in_launch", C.c_int)]
 
 
 class ImpulseParams(C.Structure):       # struct rvc_impulse_params

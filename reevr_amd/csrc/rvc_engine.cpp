@@ -135,6 +135,8 @@ struct Tuning {
                           // structure), 1 a tail at twice the block, 2 half the zero-latency stage -- wherever supported
   int kid_fence = 1;      // "kid_fence" (measurement): 0 = no fences between a set's stream and its child sets', 2 = fences but no parent stream work
   int guard = 0;          // 1: NaN-filled guard bands around (and NaN poison inside) every device allocation of a set
+  int same_block = 1;     // "same_block": 0 = the patch wave of the per-block launch prepares the NEXT block's accumulator through memory
+                          // (rounds 2-4) instead of handing THIS block's over through LDS
   int mix64 = -1;         // "mix64": sets of more than 8 channels, stages with partitions of 2048 .. 8192 samples: -1 default (kMix64Default),
                           // 0 float transforms, 1 forward in double, 2 inverse in double, 3 both (= RVC_FLAG_FFT_F64_LONG)
   rvc::LaunchTune launch; // kernel variants the launchers choose between (rvc_internal.h)
@@ -144,6 +146,7 @@ struct TuneKey { const char *key; int Tuning::*m; int rvc::LaunchTune::*lm; };
 const TuneKey kTuneKeys[] = {
     {"k1", &Tuning::k1, nullptr}, {"two_level_min_p", &Tuning::two_min_p, nullptr}, {"subsets", &Tuning::subsets, nullptr},
     {"tail_slack", &Tuning::tail_slack, nullptr}, {"kid_fence", &Tuning::kid_fence, nullptr}, {"guard", &Tuning::guard, nullptr}, {"mix64", &Tuning::mix64, nullptr},
+    {"same_block", &Tuning::same_block, nullptr},
     {"fft_loop", nullptr, &rvc::LaunchTune::fft_loop}, {"fft_many", nullptr, &rvc::LaunchTune::fft_many},
     {"tile_rot", nullptr, &rvc::LaunchTune::tile_rot}, {"block_occ", nullptr, &rvc::LaunchTune::block_occ},
     {"patch_nt", nullptr, &rvc::LaunchTune::patch_nt}, {"sweep_split", nullptr, &rvc::LaunchTune::sweep_split},
@@ -226,6 +229,9 @@ struct rvc_set {
   unsigned *h_flags = nullptr;   // pinned, device-visible: completion flags of the audio workgroups (host-pointer calls)
   unsigned flag_seq = 0;         // value the next flagged launch publishes
   int flag_count = 0;            // flags the pending call waits for (0: wait for ev_out instead)
+  bool same_block = false;       // time-tiled zero-latency stage whose folded launch is audio wave + patch wave in ONE workgroup
+                                 // (head 128 / 256 / 512): the patch wave works on the SAME block and hands its row to the audio
+                                 // wave through LDS -- the accumulator of a block never travels through memory (round 5)
   bool fold = false;             // one launch per block: H_1 X_{k-1} folded into the fused kernel, ypre = sum_{i>=2}
   bool block_general = false;    // per-block calls take the general path (transform / delay line / inverse launches): many
                                  // channels with a LARGE head block, where the one-workgroup-per-channel latency kernel
@@ -830,6 +836,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
       if (tT.K1 > (int)K) RVC_CK(dev_alloc(s, &tT.s2, sizeof(float2) * (size_t)s->nch * K * T.B));
     }
   }
+  s->same_block = s->tA.on && rvc::fused_same_block(A.logB) && s->tune.same_block != 0;
   RVC_CK(dev_alloc(s, &s->d_in, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(dev_alloc(s, &s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipHostMalloc(&s->h_in, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));
@@ -1258,7 +1265,18 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       s->ypre_block = -1;
       s->tA.drop();
     }
-    if (s->ypre_block != k0 && !run_premultiply(s, k0)) return false;
+    // same_block: what block k0 needs from the tile -- its sweep row -- exists? (it does in block order: the sweep that starts a
+    // tile / a group runs behind the launch of the block before; not after clear(), a history rebuild, a skipped block)
+    if (s->same_block) {
+      Tile &ta = s->tA;
+      const bool in_tile = ta.t0 >= 0 && k0 >= ta.t0 && k0 < ta.t0 + ta.K1;
+      const long long g0 = in_tile ? ta.group(k0) : -1;
+      if (!in_tile) { if (!run_head_sweep1(s, k0)) return false; }
+      else if (g0 != ta.t0 && ta.s0 != g0) {
+        if (k0 == g0) { if (!run_head_sweep2(s, g0)) return false; }
+        else if (!run_head_sweep1(s, k0)) return false;               // (mid-group without its rows: start over at k0)
+      }
+    } else if (s->ypre_block != k0 && !run_premultiply(s, k0)) return false;
     rvc::FusedArgs g{};
     g.in = d_in; g.in_chan_stride = (long long)in_stride;
     g.ring = s->xring; g.ring_chan_stride = (long long)s->ring_cap; g.ring_mask = s->ring_cap - 1;
@@ -1282,7 +1300,29 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       s->flag_count = rvc::fused_audio_workgroups(A.logB, s->nch);
       s->out_copy_len = 0;             // nothing to copy back, no event to record
     }
-    if (s->fold) {
+    if (s->same_block) {
+      // the patch wave of every workgroup adds, to block k0's sweep row, the partitions whose input arrived after that sweep and
+      // hands the row to the audio wave through LDS (FusedArgs::handover); the group's first block: the sweep row as it is
+      Tile &ta = s->tA;
+      const long long g0 = ta.group(k0);
+      rvc::FirArgs f = premultiply_args(s, k0);                        // partitions 2.., delay 2, one row
+      f.P = (int)std::min<long long>(k0 - g0, (long long)A.P - 2);
+      f.Yadd = tile_row(s, false, k0, &f.yadd_chan_stride);
+      f.Y = nullptr;
+      if (f.P < 0) f.P = 0;
+      g.Ypre = f.Yadd; g.ypre_chan_stride = f.yadd_chan_stride;       // (read when there is nothing to patch; a valid row anyway)
+      {
+        Timer t(s, 7, s->st_main);
+        RVC_CK(rvc::launch_fused2(A.logB, g, f, s->nch, s->st_main));
+      }
+      if (!emit_output_copy(s)) return false;
+      if (block_done) {      // behind the launch, off the call's latency path: the sweep that starts the next tile / group
+        const long long kn = k0 + 1;
+        if (!(kn > ta.t0 && kn < ta.t0 + ta.K1)) { if (!run_head_sweep1(s, kn)) return false; }
+        else if (ta.group(kn) == kn && ta.s0 != kn) { if (!run_head_sweep2(s, kn)) return false; }
+      }
+      s->ypre_block = -1;
+    } else if (s->fold) {
       // the workgroups appended to this launch prepare block k0+1's accumulator (other half of ypre)
       const long long kn = k0 + 1;
       rvc::FirArgs f = premultiply_args(s, kn);
@@ -2311,6 +2351,7 @@ int rvc_set_plan(const rvc_set *s, rvc_plan *out, size_t out_size) {
     p.block_path = k->block_general ? 1 : 0;
     p.long_call_block = k->T.PF > 0 ? k->T.B : 0;
     p.wide_block = k->W.P > 0 ? k->W.B : 0;
+    p.head_patch_in_launch = k->same_block ? 1 : 0;
     // the reference's structure at these sizes: head + tail0 cover IR[0, 2T) at the head block, the tail runs 2 blocks late
     p.reference_structure = (k->T.P == 0 || (k->T.delay == 2)) ? 1 : 0;
   }

@@ -123,6 +123,10 @@ struct FusedArgs {
   // Host-pointer calls: when set, every audio workgroup publishes `seq` to done_flag[workgroup]
   // (pinned host memory, system scope) right behind its output stores, and the host polls that
   // instead of waiting for an event behind the whole kernel.
+  // k_fused_block2w with a patch of THIS block (launch_fused2 sets it when FirArgs f describes block k's own accumulator,
+  // rvc::fused_same_block): the patch wave leaves sum_{i>=2, recent} H_i X_{k-i} + the sweep row in LDS, the audio wave adds it
+  // behind its forward transform -- the accumulator never travels through global memory (Ypre is not read).
+  int handover;
   unsigned *done_flag;
   unsigned seq;
   unsigned long long *dbg;  // development builds (tools/dev/instrumentation.patch): phase timestamps of workgroup 0, else nullptr
@@ -151,6 +155,10 @@ hipError_t launch_fused(int logB, const FusedArgs &a, int channels, hipStream_t 
 // One launch per block: the audio path with H_1 X_{k-1} folded in (a.Ypre = sum_{i>=2}) plus, when
 // f.P > 0, the workgroups that compute the next block's sum_{i>=2} (f: M = 1 row, any delay).
 bool fused_fold_supported(int logB);
+// head blocks whose folded launch is ONE workgroup of an audio wave + a patch wave per channel group (128 / 256 / 512): with a
+// time-tiled delay line the patch wave then works on the SAME block as the audio wave and hands its row over through LDS
+// (FusedArgs::handover): f = the patch of block a.k (Yadd = its sweep row, P recent partitions), f.Y unused
+bool fused_same_block(int logB);
 int fused_audio_workgroups(int logB, int channels);
 hipError_t launch_fused2(int logB, const FusedArgs &a, const FirArgs &f, int channels, hipStream_t st);
 hipError_t launch_ingest(const IngestArgs &a, int channels, hipStream_t st);

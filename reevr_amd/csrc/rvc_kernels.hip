@@ -1178,7 +1178,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv_loop(const InvArgs
 //  requests then go out one at a time, but 16 fewer registers are live, and the whole-block path every lock-step launch
 //  takes sets the kernel's budget: three waves per SIMD.)
 template <int LOGB, bool FOLD, bool SOLO = false, bool LEAN = false>
-__device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, const int wg) {
+__device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, const int wg, const float2 *hand = nullptr) {
   static_assert(!SOLO || Plan8<LOGB>::WG == 64, "SOLO: the workgroup's transform(s) live in one wave");
   static_assert(!LEAN || FOLD, "LEAN: the folded launch path only");
   typedef Tw8<LOGB, float, false, false, false, LEAN> TW;
@@ -1219,7 +1219,8 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
 #pragma unroll
     for (int e = 0; e < P::E; ++e) {
       h0[e] = H0[P::out_idx(tid, e)];
-      ypre[e] = Ypre[P::out_idx(tid, e)];
+      // (handover: the accumulator arrives through LDS behind the forward transform; until then ypre carries H_1 X_{k-1} only)
+      ypre[e] = (SOLO && a.handover) ? make_float2(0.f, 0.f) : Ypre[P::out_idx(tid, e)];
       if constexpr (FOLD) {
         // (clamped to row k when there is no block k-1: any resident row, the product is dropped below)
         const float2 *H1 = (fold ? a.H1 : a.H0) + (long long)c * a.h_chan_stride;
@@ -1325,9 +1326,30 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   // 2. forward transform, real split; X_k goes to the delay line and, times H0 plus the
   //    pre-multiplied accumulator, becomes Y_k
   fft8_core<LOGB, false, float, SOLO, TW>(v, lds, T, tid);
+  if constexpr (SOLO) {
+    if (a.handover) {                            // (launch-uniform) the patch wave's row of this block: sweep row + recent partitions
+      __syncthreads();                           // the one workgroup barrier of the launch: patch wave wrote, audio wave reads
+      if constexpr (!LEAN) {
+#pragma unroll
+        for (int e = 0; e < P::E; ++e) {
+          const float2 t = hand[sub * B + P::out_idx(tid, e)];
+          ypre[e].x += t.x; ypre[e].y += t.y;
+        }
+      }
+    }
+  }
   if constexpr (LEAN) {
     __builtin_amdgcn_sched_barrier(0);           // (nothing of what follows is requested above the transform)
     load_wso(); load_mac(); fold_in();
+    if constexpr (SOLO) {
+      if (a.handover) {
+#pragma unroll
+        for (int e = 0; e < P::E; ++e) {
+          const float2 t = hand[sub * B + P::out_idx(tid, e)];
+          ypre[e].x += t.x; ypre[e].y += t.y;
+        }
+      }
+    }
   } else {
     // the inverse split's twiddles (a table every channel shares: L2) are requested behind the forward transform: with the
     // 2 E sample requests in flight together their 2 E registers are what keeps the kernel at three waves per SIMD
@@ -1891,7 +1913,7 @@ k_fused_block2(const FusedArgs a, const FirArgs f, const int n_audio, const int 
 // per workgroup, 512 row entries in all): 4 x (64 lanes x 2 bins), the partitions in rounds of three (24 requests of
 // 16 bytes per lane in flight).
 template <int LOGB, bool NT, int CH = 3>
-__device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, const int channels) {
+__device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, const int channels, float2 *hand = nullptr) {
   typedef Plan8<LOGB> P8;
   static_assert(P8::B * P8::TPW == 512 && P8::B >= 128, "one wave patches 512 row entries");
   constexpr int NQ = 4;
@@ -1950,6 +1972,12 @@ __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, c
       }
     }
   }
+  if (hand) {            // same-block patch: the row goes to the audio wave through LDS (entry = channel-in-workgroup * B + bin)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) *reinterpret_cast<float4 *>(hand + q * 128 + lane * 2) = y[q];
+    __syncthreads();     // (the audio wave's matching barrier sits behind its forward transform)
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
     if (liveq[q]) *reinterpret_cast<float4 *>(Yq[q]) = y[q];
@@ -1972,11 +2000,18 @@ __device__ __forceinline__ void fdl_patch_wave(const FirArgs &a, const int wg, c
 // LEAN (measurement, block_occ = 4): the register budget of FOUR waves per SIMD -- the lean form of the audio path, two
 // partitions per round in the patch wave. Measured: no faster for configs 2 / 1, slower for config 3 (profiles/r3_tuning.txt
 // passes Q, T): every request on the wave's chain costs more than the fourth wave buys.
+template <int LOGB> __host__ __device__ constexpr size_t fused2w_hand_offset() {
+  size_t lds = sizeof(cx<float>) * Plan8<LOGB>::LDS_ELEMS * Plan8<LOGB>::TPW;
+  if (lds < sizeof(float2) * 4 * 64) lds = sizeof(float2) * 4 * 64;
+  return (lds + 15) & ~(size_t)15;
+}
 template <int LOGB, bool NT, bool LEAN>
 __global__ void __launch_bounds__(128, LEAN ? 4 : 2) k_fused_block2w(const FusedArgs a, const FirArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  if (threadIdx.x < 64) fused_audio<LOGB, true, true, LEAN>(a, smem_raw, blockIdx.x);
-  else if (f.P > 0) fdl_patch_wave<LOGB, NT, LEAN ? 2 : 3>(f, blockIdx.x, a.channels);
+  // (handover row: 512 entries behind the transform's exchange buffer, launch_fused2_t sizes the allocation)
+  float2 *hand = reinterpret_cast<float2 *>(smem_raw + fused2w_hand_offset<LOGB>());
+  if (threadIdx.x < 64) fused_audio<LOGB, true, true, LEAN>(a, smem_raw, blockIdx.x, hand);
+  else if (f.P > 0) fdl_patch_wave<LOGB, NT, LEAN ? 2 : 3>(f, blockIdx.x, a.channels, a.handover ? hand : nullptr);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -2187,6 +2222,9 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
   const bool patch = f.Yadd != nullptr && f.P <= kPatchMax && f.P >= 1;
   if constexpr (LOGB >= 7 && LOGB <= 9) {     // the audio workgroup is ONE wave: audio wave + patch wave per workgroup
     if (patch || f.P <= 0) {
+      // a patch of the block the audio wave works on (f.k0 == a.k): handed over through LDS, never written to memory
+      b.handover = (patch && f.k0 == a.k) ? 1 : 0;
+      lds = fused2w_hand_offset<LOGB>() + sizeof(float2) * 512;
       if (launch_tune().patch_nt == 2 && (long long)channels * P::B >= (1ll << 19)) RVC_LAUNCH((k_fused_block2w<LOGB, true, false>), dim3(n_audio), dim3(128), lds, st, b, f);
       else if (launch_tune().block_occ == 4 && n_audio >= 1024) RVC_LAUNCH((k_fused_block2w<LOGB, false, true>), dim3(n_audio), dim3(128), lds, st, b, f);
       else RVC_LAUNCH((k_fused_block2w<LOGB, false, false>), dim3(n_audio), dim3(128), lds, st, b, f);
@@ -2210,6 +2248,7 @@ int fused_audio_workgroups(int logB, int channels) {   // workgroups of the audi
 }
 
 bool fused_fold_supported(int logB) { return logB >= 6 && logB <= 12; }   // B = 8192: no registers left for the fold
+bool fused_same_block(int logB) { return logB >= 7 && logB <= 9; }          // (the k_fused_block2w sizes: launch_fused2_t)
 
 hipError_t launch_fused2(int logB, const FusedArgs &a, const FirArgs &f, int channels, hipStream_t st) {
   switch (logB) {

@@ -97,8 +97,11 @@ def test_stage_plan_policy():
 class _SetGeometry:
     """what bench.executed_bytes asks a ConvolverSet for"""
 
-    def __init__(self, parts, tiles, tail_block, subsets=1):
-        self._p, self._t, self.tail_block, self.subsets = parts, tiles, tail_block, subsets
+    def __init__(self, parts, tiles, tail_block, subsets=1, patch_in_launch=0):
+        self._p, self._t, self.tail_block, self.subsets, self._pil = parts, tiles, tail_block, subsets, patch_in_launch
+
+    def plan(self):
+        return {"head_patch_in_launch": self._pil}
 
     def partitions(self, stage):
         return self._p[stage]
