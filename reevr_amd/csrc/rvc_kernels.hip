@@ -970,6 +970,11 @@ template <typename R> __device__ __forceinline__ cx<R> eighth_turn(const int q) 
 // loop body touches memory for samples and spectra only. Launched only when every row is a whole one (launch_fft_fwd /
 // _inv check: no zero padding, no validity window cutting a row, no second source), everything else keeps the one-row form.
 // grid = workgroups the device holds at once (fft_loop_workgroups), item = row + rows * channel, strided over the grid.
+// (Round 5 tried the same for the transforms that take a whole CU per row -- 16384 bins in float, 8192 bins in double: the
+//  lock-step sets' tail inverse -- with twiddles fetched per pass: at 16 values (or 8 doubles) per thread a prefetched row does
+//  not fit the 128 registers of a 1024-thread workgroup (67 / 18 spilled dwords), and the spill reloads wait for the prefetch:
+//  forward 155 -> 260 us, inverse 140 -> 217 us per 2048 rows of 16384 bins, the double inverse 199 -> 211 us. Removed;
+//  profiles/r5_fft_loopg.txt.)
 // ----------------------------------------------------------------------------------------
 // (All global addresses inside the loops are a wave-uniform pointer -- scalar registers, recomputed per row for free --
 //  plus ONE of two per-thread byte offsets, 8 * tid and 8 * (NT - 1 - tid), plus a compile-time constant: per-value

@@ -1301,12 +1301,15 @@ def test_child_sets_with_empty_impulses_in_the_first_child():
         assert rel_rms(got[c], o.process(x4[c % 4])) <= TOL, c
 
 
-def test_row_looping_transforms_match_one_row_kernels():
-    """The row-looping 8192-bin transform kernels (k_fft8_fwd_loop / _inv_loop: many lock-step channels' tail jobs) against
-    the one-row kernels on the same set, and against the oracle: 600 channels (more rows than resident workgroups, so
-    workgroups really loop and prefetch), head 512 / tail 8192, short IRs with a tail stage."""
+@pytest.mark.parametrize("widen", [False, True], ids=["tail8192", "tail16384"])
+def test_row_looping_transforms_match_one_row_kernels(widen):
+    """The row-looping 8192-bin transform kernels (k_fft8_fwd_loop / _inv_loop: many lock-step channels' tail jobs; the inverse only
+    where it runs in float) against the one-row kernels on the same set, and against the oracle: 600 channels (more rows than
+    resident workgroups, so workgroups really loop and prefetch), head 512 / tail 8192, short IRs with a tail stage. tail8192: the
+    default of lock-step sets (forward float: loops; inverse double: one-row kernel either way); tail16384: the tail widened to
+    twice the block (forced): one-row kernels in both modes, the knob must change nothing."""
     import torch
-    nch, head, tail, nblk = 600, 512, 8192, 16 * 7
+    nch, head, tail, nblk = 600, 512, 8192, 16 * (10 if widen else 7)
     irs = [synth.synth_ir(2 * tail + 3 * tail - 101 * (c % 7), 1, 40 + c % 11)[0] for c in range(nch)]
     x = np.stack([synth.synth_input(head * nblk, 300 + c % 9) for c in range(nch)])
     dx = torch.from_numpy(x).cuda()
@@ -1314,8 +1317,9 @@ def test_row_looping_transforms_match_one_row_kernels():
     for mode in (0, 1):
         reevr_amd.set_tuning("fft_loop", mode)
         try:
-            s = reevr_amd.ConvolverSet(nch)
+            s = reevr_amd.ConvolverSet(nch, tune={"tail_slack": 1} if widen else None)
             assert s.init(head, tail, irs, max_len=head), s.last_error_string
+            assert s.tail_block == (2 * tail if widen else tail) and s.plan()["tail_f64"] == (0 if widen else 2)
             outs[mode] = s.process_device_blocks(dx, head).cpu().numpy()
             assert s.last_error == 0, s.last_error_string
             s.close()

@@ -205,6 +205,10 @@ def test_pmc_summary_kernel_families():
     assert fam("void rvc::k_fft8_inv<13, float, false>(rvc::InvArgs)") == "fft_inv_tail"
     assert fam("void rvc::k_fft8_fwd_loop<13>(rvc::FwdArgs, int)") == "fft_fwd_tail"
     assert fam("void rvc::k_fft8_fwd<13, double>(rvc::FwdArgs)") is None
+    # round 5: the three-product form of the LDS-fed sweep (one more template argument), the tail inverse in double
+    assert fam("void rvc::k_fdl_sweep_lds<16, 2, 1, 1, true, 4, true>(rvc::FirArgs, int)") == "sweep_tail"
+    assert fam("void rvc::k_fdl_sweep_lds<16, 2, 1, 0, true, 4, false>(rvc::FirArgs, int)") == "sweep_head"
+    assert fam("void rvc::k_fft8_inv<13, double, false, false>(rvc::InvArgs)") == "fft_inv_tail"
 
 
 

@@ -35,7 +35,7 @@ def family(name: str, head_log: int, tail_log: int):
         # second-level sweeps are exactly the own-tile K = 8 instantiation with ordinary loads (rvc_sweep.hip launch_stage)
         second = m.group(1) == "8" and m.group(2) == "1" and m.group(4) == "false"
         return ("sweep2_" if second else "sweep_") + st
-    m = re.search(r"k_fdl_sweep_lds<\d+, \d+, \d+, (\d), (?:true|false), \d+>", name)   # <KW, NKW, A, STAGE, NT, LB>: first level only
+    m = re.search(r"k_fdl_sweep_lds<\d+, \d+, \d+, (\d), (?:true|false), \d+(?:, (?:true|false))?>", name)   # <KW, NKW, A, STAGE, NT, LB, M3>: first level only
     if m:
         return "sweep_head" if m.group(1) == "0" else "sweep_tail"
     m = re.search(r"k_fft8_(fwd|inv)_loop<(\d+)>", name)
@@ -50,7 +50,8 @@ def family(name: str, head_log: int, tail_log: int):
     m = re.search(r"k_fir(?:_lds)?<(?:\d+, )?(\d)>", name)
     if m:
         return "fir_head" if m.group(1) == "0" else "fir_tail"   # <1> tail stage, <2> whole-IR line (timed as fir_tail)
-    m = re.search(r"k_fft8?_(fwd|inv)<(\d+), float(?:, (?:true|false))*>", name)
+    # (double: only the inverse -- the lock-step sets' tail inverse since round 5; the double FORWARD launches are the IR spectra at init)
+    m = re.search(r"k_fft8?_(fwd|inv)<(\d+), float(?:, (?:true|false))*>", name) or re.search(r"k_fft8?_(inv)<(\d+), double(?:, (?:true|false))*>", name)
     if m:
         lg = int(m.group(2))
         st = "head" if lg == head_log else ("tail" if lg >= tail_log else None)

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round 4: the rocprofv3 evidence behind bench.py's `roofline*.traffic` and the per-kernel durations, for BASELINE configs
+# Rounds 4-5: the rocprofv3 evidence behind bench.py's `roofline*.traffic` and the per-kernel durations, for BASELINE configs
 # 2 (headline), 1, 3 and 5 in the lock-step regime AT THE BENCH'S OWN LAUNCH SIZES (the engine's default: child sets).
 #   per config:  --kernel-trace --stats   -> <out>/config<C>/kernel_stats.csv, kernel_union.txt (union of dispatch intervals)
 #                --pmc FETCH_SIZE         -> FETCH_SIZE_per_kernel.csv   (own pass, MI355X_MICROARCH.md HBM section)
 #                --pmc WRITE_SIZE         -> WRITE_SIZE_per_kernel.csv   (own pass)
 #   once:        the same two counters over a 1 GiB copy (tools/pmc_calib.py) -> calib_*_per_kernel.csv
-# then tools/pmc_summarize.py -> <out>/config<C>/traffic.json, merged into <out>/traffic.json (= profiles/r4_traffic.json).
+# then tools/pmc_summarize.py -> <out>/config<C>/traffic.json, merged into <out>/traffic.json (= profiles/r5_traffic.json).
 #   usage (GPU box, repo root): tools/profile_configs.sh <out dir> [configs, default "2 1 3 5"]
 set -u
 OUT=$(realpath -m "${1:-gpurun_out/prof}")
@@ -50,6 +50,11 @@ for C in $CONFIGS; do
   find "$D/kt" -name '*kernel_stats.csv' -exec cp {} "$D/kernel_stats.csv" \;
   find "$D/kt" -name '*kernel_trace.csv' -exec python "$ROOT/tools/trace_union.py" {} \; > "$D/kernel_union.txt" 2>&1
   rm -rf "$D/kt"
+  # the same with the set on ONE queue (every launch has the device to itself): the per-launch averages bench.py's roofline.frac
+  # of the dominant kernel is checked against (rocprof_cross_check)
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$D/kt1" -o kt -- python "$ROOT/bench.py" $KT_ARGS --child-sets 0 > "$D/bench_under_rocprof_one_queue.json" 2> "$D/kt1.err"
+  find "$D/kt1" -name '*kernel_stats.csv' -exec cp {} "$D/kernel_stats_one_queue.csv" \;
+  rm -rf "$D/kt1"
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d "$D/pmc_$c" -o pmc -- python "$ROOT/bench.py" $ARGS > /dev/null 2> "$D/pmc_$c.err"
     find "$D/pmc_$c" -name '*counter_collection.csv' -exec cp {} "$D/$c.csv" \;
