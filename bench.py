@@ -81,7 +81,7 @@ SR = 48000
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3  # vector fp32 (same guide)
 K2 = 8                    # rvc::kSweepRows: the tile the per-block patches work on
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r4_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r5_traffic.json")
 
 # BASELINE.json configurations as lock-step workloads: IR length, host block, single-stage?, default channels per GPU,
 # host blocks per step (whole tail periods)
@@ -468,7 +468,7 @@ def roofline_tables(kern: dict, exe: dict, traffic: dict):
 
 
 def load_traffic(nch_per_launch: int, cfg: int, tiled: bool):
-    """Counter-measured HBM bytes per launch of each kernel family (profiles/r4_traffic.json: separate rocprofv3 --pmc
+    """Counter-measured HBM bytes per launch of each kernel family (profiles/r5_traffic.json: separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes of this command, gfx950-corrected). An entry only applies to launches of exactly the
     channel count it was measured with (`channels_per_launch`: the set's channels / its child sets): anything else is
     refused -- a figure taken at another launch size reads like a model error."""
@@ -481,7 +481,7 @@ def load_traffic(nch_per_launch: int, cfg: int, tiled: bool):
         return {}, None
     ent = ents[0]
     return ({k: v["traffic_bytes"] for k, v in ent.get("kernels", {}).items()},
-            "profiles/r4_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected; "
+            "profiles/r5_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected; "
             "%d channels per launch)" % nch_per_launch)
 
 
