@@ -259,7 +259,8 @@ typedef struct rvc_plan {
                                    it to the audio wave through LDS (head 128 / 256 / 512); 0: the launch prepares the next block's
                                    accumulator through memory, or the stage is not tiled */
 } rvc_plan;
-/* plan_size = sizeof(rvc_plan) as the caller compiled it (the struct may grow at its end). 1 = filled. */
+/* plan_size = sizeof(rvc_plan) as the caller compiled it: the struct only ever grows at its end, a caller compiled against a
+ * shorter one gets the fields it knows (bytes beyond the library's own struct are zeroed). 1 = filled. */
 int rvc_set_plan(const rvc_set *s, rvc_plan *plan, size_t plan_size);
 
 /* With RVC_FLAG_TIMING: accumulated HIP-event time of one kernel family since the last

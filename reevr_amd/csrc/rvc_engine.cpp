@@ -36,6 +36,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
@@ -2322,7 +2323,8 @@ const char *rvc_debug_tuning_keys(void) {
 }
 
 int rvc_set_plan(const rvc_set *s, rvc_plan *out, size_t out_size) {
-  if (!s || !out || out_size < sizeof(rvc_plan)) return 0;
+  // (the struct may grow at its end: a caller compiled against an earlier, shorter one gets the fields it knows)
+  if (!s || !out || out_size < offsetof(rvc_plan, head_block)) return 0;
   std::memset(out, 0, out_size);
   const rvc_set *k = s->kids.empty() ? s : s->kids[0];      // (children share one plan: rvc_set::plan_nch, longest_hint)
   rvc_plan p{};
@@ -2355,7 +2357,7 @@ int rvc_set_plan(const rvc_set *s, rvc_plan *out, size_t out_size) {
     // the reference's structure at these sizes: head + tail0 cover IR[0, 2T) at the head block, the tail runs 2 blocks late
     p.reference_structure = (k->T.P == 0 || (k->T.delay == 2)) ? 1 : 0;
   }
-  *out = p;
+  std::memcpy(out, &p, std::min(out_size, sizeof(p)));
   return 1;
 }
 

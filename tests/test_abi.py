@@ -123,6 +123,15 @@ def test_plan_and_per_set_knobs_without_gpu(lib):
     fields = [n for decl in re.findall(r"(?:int|size_t)\s+([a-z_0-9, ]+);", body) for n in re.split(r",\s*", decl.strip())]
     assert fields == [n for n, _ in _lib.Plan._fields_], fields
     assert lib.rvc_set_plan(None, None, 0) == 0
+    # a caller compiled against a shorter (earlier) struct gets the fields it knows; a longer buffer is zero-filled behind the struct
+    short = (ctypes.c_byte * _lib.Plan.head_partitions.offset)()
+    h = lib.rvc_set_create(3, 0, 0)
+    assert lib.rvc_set_plan(h, ctypes.byref(short), ctypes.sizeof(short)) == 1
+    assert ctypes.cast(short, ctypes.POINTER(ctypes.c_int))[0] == 3
+    long_buf = (ctypes.c_byte * (ctypes.sizeof(_lib.Plan) + 64))(*([0x55] * (ctypes.sizeof(_lib.Plan) + 64)))
+    assert lib.rvc_set_plan(h, ctypes.byref(long_buf), ctypes.sizeof(long_buf)) == 1 and not any(long_buf[ctypes.sizeof(_lib.Plan):])
+    assert lib.rvc_set_plan(h, ctypes.byref(short), 4) == 0
+    lib.rvc_set_destroy(h)
     # knobs
     keys = lib.rvc_debug_tuning_keys().decode().split(",")
     assert "k1" in keys and "sweep_lds" in keys and "mac3" in keys and sorted(keys) == sorted(reevr_amd.TUNING_DEFAULTS.keys())
