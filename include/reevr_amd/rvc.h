@@ -93,7 +93,7 @@ enum {
                                    between add their few recent partitions: same sums, same zero latency, ~3.5x fewer
                                    HBM bytes where the path is bandwidth-bound (many lock-step channels). Delay lines
                                    of more than 24 partitions get two levels of it: a first-level sweep every 16
-                                   blocks (32 from 80 partitions on) over all partitions, second-level sweeps every 8 blocks over what arrived
+                                   blocks (32 from 48 partitions on) over all partitions, second-level sweeps every 8 blocks over what arrived
                                    since (BASELINE config 3's 350 tail partitions: ~1.7x fewer bytes again). */
 
 #define RVC_FLAG_PERSISTENT 64u  /* REMOVED in round 4 (the resident-kernel mode of rounds 2-3 lost to ordinary launches on

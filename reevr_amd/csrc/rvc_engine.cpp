@@ -817,7 +817,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     tT.on = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
     // one level of 8 blocks, or -- long delay lines -- a first level of 16 / 32 blocks with second-level sweeps every 8
     auto first_level = [&](size_t P) -> int {
-      // knob k1: 0 = by length (16 above kTwoLevelMinP partitions, 32 from kLongLineMinP on: measured, profiles/r3_tuning.txt)
+      // knob k1: 0 = by length (16 above kTwoLevelMinP partitions, 32 from kLongLineMinP on: measured, profiles/r3_tuning.txt, r5_k1.txt)
       const int tk1 = s->tune.k1;
       int k1 = (tk1 == 32 || tk1 == 16 || tk1 == 8) ? tk1 : ((int)P >= rvc::kLongLineMinP ? 32 : 16);
       if (force2 && k1 == 8) k1 = 16;

@@ -209,7 +209,10 @@ constexpr int kSweepRows = 8;     // tile of the level the patches work on (seco
 constexpr int kSweepRowsMax = 32; // largest first-level tile
 constexpr int kTwoLevelMinP = 24; // up to this many partitions one level of 8 blocks is as good (P / 4 + 10 rows per block against
                                   // P / 8 + 12); measured at 32 partitions (config 2's zero-latency stage): 375 -> 365 B/sample, +2-4 %
-constexpr int kLongLineMinP = 80; // from this many partitions on the first level covers 32 blocks (BASELINE configs 1 and 3)
+constexpr int kLongLineMinP = 48; // from this many partitions on the first level covers 32 blocks. Round 3: 80 (the one-wave 32-block sweep ran at
+                                  // 0.50 of the HBM peak); with the LDS-fed three-product form (0.62-0.73) the longer tile pays earlier -- measured on
+                                  // MI355X (profiles/r5_k1.txt): 58 tail partitions of 8192 (config 2) 16.81 -> 17.33 Gsamples/s, 64 head partitions of
+                                  // 256 (config 3) 11.56 -> 11.87, 29 tail partitions (config 5's geometry) 22.25 -> 21.79: stays at 16
 constexpr int kSweepLagMax = 3;   // a sweep may run up to this many blocks before its first row is due (x_hi that much older)
 // M = 8, 16 or 32 output rows
 hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st);

@@ -37,12 +37,12 @@ for C in $CONFIGS; do
   case $C in
     1) GEO="--channels 8192 --subsets 4 --head-log 9 --tail-log 13 --k1-head 32 --k1-tail 0" ;;
     # (configs 2 / 5: the tail stage one block late over IR[T,..), the zero-latency stage half as long; config 3: the tail at block 16384)
-    2) GEO="--channels 4096 --subsets 2 --head-log 9 --tail-log 13 --k1-head 8 --k1-tail 16" ;;
-    3) GEO="--channels 2048 --subsets 2 --head-log 8 --tail-log 14 --k1-head 16 --k1-tail 32" ;;
+    2) GEO="--channels 4096 --subsets 2 --head-log 9 --tail-log 13 --k1-head 8 --k1-tail 32" ;;
+    3) GEO="--channels 2048 --subsets 2 --head-log 8 --tail-log 14 --k1-head 32 --k1-tail 32" ;;
     5) GEO="--channels 4096 --subsets 2 --head-log 12 --tail-log 13 --k1-head 0 --k1-tail 16 --patch0-family fir_head" ;;
   esac
   LS=""; [ "$C" = "5" ] && LS="--lockstep 1"     # (config 5's geometry in the lock-step regime: the entry `config5` of the default line)
-  [ "$C" = "3" ] && STEPS=8 || STEPS=3          # (config 3: whole first-level tiles of the tail stage = 32 blocks of 16384 = 8 steps)
+  STEPS=4; [ "$C" = "3" ] && STEPS=8          # (whole first-level tiles of the tail stage: config 3: 32 blocks of 16384 = 8 steps, config 2: 32 blocks of 8192 = 2 steps)
   [ "$C" = "3" ] && KSTEPS=24 || KSTEPS=20
   ARGS="--config $C $LS --steps $STEPS --warmup 1 --cpu-seconds 0 --side 0 --distinct 64"
   KT_ARGS="--config $C $LS --steps $KSTEPS --warmup 5 --cpu-seconds 0 --side 0 --distinct 64"
