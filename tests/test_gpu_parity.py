@@ -1175,10 +1175,12 @@ def test_child_sets_flag():
     long_calls.close()
 
 
-@pytest.mark.parametrize("kids", [2, 4])
+@pytest.mark.parametrize("kids", [2, 3, 4])
 def test_child_sets_match_single_set(kids):
     """A set served by child sets on their own streams (rvc_set_subsets) gives, bit for bit, what the same set gives
-    alone -- per-block device calls, a multi-block call, a host-pointer call, clear() -- and matches the oracle."""
+    alone -- per-block device calls, a multi-block call, a host-pointer call, clear() -- and matches the oracle. Three children
+    of eight channels: UNEVEN children (3 + 3 + 2; round 5: the remainder is dealt out one by one), partly filled workgroups
+    (four channels per workgroup at head 128)."""
     import torch
     nch, head, tail, nblk = 8, 128, 512, 120
     irs = [synth.synth_ir(2 * tail + 5 * tail - 31 * c, 1, 900 + c)[0] for c in range(nch)]
