@@ -438,7 +438,11 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
 #pragma unroll
     for (int i = 0; i < PRE / G::NW; ++i) {
       const int s = -PRE + wave + i * G::NW;
-      req_x(s, s + PRE);
+      // (a history row that does not count -- for a first-level sweep all but one of them: they have not arrived yet -- is not
+      //  requested at all: the waits below are "at most N outstanding", FEWER requests in front of the counted chunks keep them
+      //  valid, and the reader drops the slot's stale bytes. As clamped non-temporal requests they were 15 of a 58-partition
+      //  walk's 148 pieces and +6 % HBM traffic, PMC.)
+      if (valid_step(s)) req_x(s, s + PRE);
     }
   }
 #pragma unroll
@@ -463,7 +467,9 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
     constexpr bool GUARD = decltype(guard_tag)::value;
     sweep_wait_vm<(A - 1) * LPW>();                 // my pieces of this chunk have landed ...
     __builtin_amdgcn_s_barrier();                   // ... everybody's have, and everybody is done with the previous chunk,
-    {                                               // whose slots chunk + A now takes
+    // (the walk's last, guarded body: a chunk that lies wholly past the last partition is not requested -- fewer requests in
+    //  front of a counted wait keep it valid)
+    if (!GUARD || sc + A * C < P) {                 // whose slots chunk + A now takes
       const int hs = hrow >= C ? hrow - C : hrow - C + NH;
       const int xs = xrow + A * C >= XR ? xrow + A * C - XR : xrow + A * C;
       req_chunk(sc + A * C, hs, xs);
