@@ -129,10 +129,7 @@ def test_executed_bytes_model_against_the_committed_counter_passes():
         assert b.tail_stage_form(conv, head, tail).startswith({2: "delay 1, block T", 3: "delay 1, block 2T", 5: "delay 1, block T", 1: "none"}[cfg])
         for fam, measured in traffic.items():
             assert fam in exe, (cfg, fam)
-            # (the LDS-fed 32-block sweeps keep their hand-counted DMA requests uniform by re-requesting rows that do not count:
-            #  up to +6 % over the model on a 58-partition walk, PMC)
-            tol = 0.07 if fam.startswith("sweep") else 0.05
-            assert 1 - tol <= measured / exe[fam] <= 1 + tol, (cfg, fam, measured / exe[fam])
+            assert 0.95 <= measured / exe[fam] <= 1.05, (cfg, fam, measured / exe[fam])
 
 
 class _Imp:
