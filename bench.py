@@ -725,8 +725,7 @@ def compact_line(full: dict, full_path=None) -> dict:
     if cb:
         c = _pick(cb, ("value", "unit", "cores", "kind", "cpu_model"))
         c["sample"] = str(cb.get("sample", ""))[:160]
-        if cb.get("all_cores"):
-            c["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+        # (the all-cores figure -- a fixed wall budget on a shared host, 17-40x spread between threads -- stays in the full record only)
         line["cpu_baseline"] = c
     else:
         line["cpu_baseline"] = None
