@@ -96,12 +96,14 @@ struct Stage {
   float *d_ir = nullptr;   // time-domain partitions (kept so that a re-init only re-uploads and re-transforms)
   float2 *tw = nullptr, *wsplit = nullptr, *tw8 = nullptr;       // float twiddles
   double2 *twd = nullptr, *wsplitd = nullptr, *tw8d = nullptr;   // double twiddles (B <= 8192): IR spectra, f64 mode
+  double2 *tw8dh = nullptr;                                       // B = 8192: the per-pass tables of the 4096-point transform (k_fft8_inv_dif2)
   bool f64f = false, f64i = false;               // run this stage's forward / inverse transforms in double
   bool f64() const { return f64f || f64i; }      // (any of them: the float-only one-launch block kernel is out then)
   void set64(int mode) { f64f = (mode & 1) != 0; f64i = (mode & 2) != 0; }
   const void *twp(bool d) const { return d ? (const void *)twd : (const void *)tw; }
   const void *wsp(bool d) const { return d ? (const void *)wsplitd : (const void *)wsplit; }
   const void *t8p(bool d) const { return d ? (const void *)tw8d : (const void *)tw8; }
+  const void *t8h(bool d) const { return d ? (const void *)tw8dh : nullptr; }
 };
 
 struct TimedLaunch {
@@ -153,6 +155,7 @@ const TuneKey kTuneKeys[] = {
     {"patch_nt", nullptr, &rvc::LaunchTune::patch_nt}, {"sweep_split", nullptr, &rvc::LaunchTune::sweep_split},
     {"sweep_lw", nullptr, &rvc::LaunchTune::sweep_lw}, {"sweep_d", nullptr, &rvc::LaunchTune::sweep_d},
     {"sweep_lds", nullptr, &rvc::LaunchTune::sweep_lds}, {"mac3", nullptr, &rvc::LaunchTune::mac3},
+    {"inv_dif", nullptr, &rvc::LaunchTune::inv_dif},
 };
 int *tune_slot(Tuning &t, const std::string &key) {
   for (const TuneKey &k : kTuneKeys)
@@ -425,7 +428,7 @@ bool ensure_streams(rvc_set *s) {
 }
 
 void free_stage(rvc_set *s, Stage &g) {
-  void *all[] = {g.H, g.X, g.Y, g.d_ir, g.tw, g.wsplit, g.twd, g.wsplitd, g.tw8, g.tw8d};
+  void *all[] = {g.H, g.X, g.Y, g.d_ir, g.tw, g.wsplit, g.twd, g.wsplitd, g.tw8, g.tw8d, g.tw8dh};
   for (void *q : all) dev_free(s, q);
   g = Stage();
 }
@@ -529,28 +532,32 @@ bool make_twiddles(rvc_set *s, Stage &g) {
     RVC_CK(hipMemcpy(g.wsplitd, wsd.data(), sizeof(double2) * (nws + 1), hipMemcpyHostToDevice));
   }
   // per-pass tables of the radix-8 kernels (layout documented in rvc_internal.h)
-  const int n8e = rvc::fft8_table_entries(g.logB);
-  if (n8e > 0) {
-    std::vector<double2> t8d((size_t)n8e);
-    std::vector<float2> t8((size_t)n8e);
-    size_t o = 0;
-    const int N8 = g.logB / 3;
+  auto pass_tables = [](int logB, std::vector<double2> &t8d) {
+    const size_t Bt = (size_t)1 << logB;
+    const int N8 = logB / 3;
     for (int j = 1; j < N8; ++j) {            // leg-major [r][k]: coalesced per-leg loads (Plan8::off8)
       const size_t p = (size_t)1 << (3 * j);
       for (int r = 0; r < 8; ++r)
         for (size_t k = 0; k < p; ++k) {
           const double ang = -2.0 * kPi * (double)r * (double)k / (double)(8 * p);
-          t8d[o++] = make_double2(std::cos(ang), std::sin(ang));
+          t8d.push_back(make_double2(std::cos(ang), std::sin(ang)));
         }
     }
-    if (g.logB % 3 == 2) {
+    if (logB % 3 == 2) {
       for (int r = 0; r < 4; ++r)
-        for (size_t k = 0; k < B / 4; ++k) {
-          const double ang = -2.0 * kPi * (double)r * (double)k / (double)B;
-          t8d[o++] = make_double2(std::cos(ang), std::sin(ang));
+        for (size_t k = 0; k < Bt / 4; ++k) {
+          const double ang = -2.0 * kPi * (double)r * (double)k / (double)Bt;
+          t8d.push_back(make_double2(std::cos(ang), std::sin(ang)));
         }
     }
+  };
+  const int n8e = rvc::fft8_table_entries(g.logB);
+  if (n8e > 0) {
+    std::vector<double2> t8d;
+    pass_tables(g.logB, t8d);
+    const size_t o = t8d.size();
     if (o != (size_t)n8e) return fail(s, RVC_ERR_HIP, hipSuccess, "twiddle table layout");
+    std::vector<float2> t8(o);
     for (size_t i = 0; i < o; ++i) t8[i] = make_float2((float)t8d[i].x, (float)t8d[i].y);
     RVC_CK(dev_alloc(s, &g.tw8, sizeof(float2) * o));
     RVC_CK(hipMemcpy(g.tw8, t8.data(), sizeof(float2) * o, hipMemcpyHostToDevice));
@@ -558,6 +565,13 @@ bool make_twiddles(rvc_set *s, Stage &g) {
       RVC_CK(dev_alloc(s, &g.tw8d, sizeof(double2) * o));
       RVC_CK(hipMemcpy(g.tw8d, t8d.data(), sizeof(double2) * o, hipMemcpyHostToDevice));
     }
+  }
+  if (g.logB == 13) {                         // the double inverse as two half-size sub-transforms
+    std::vector<double2> th;
+    pass_tables(12, th);
+    if (th.size() != (size_t)rvc::fft8_table_entries(12)) return fail(s, RVC_ERR_HIP, hipSuccess, "twiddle table layout");
+    RVC_CK(dev_alloc(s, &g.tw8dh, sizeof(double2) * th.size()));
+    RVC_CK(hipMemcpy(g.tw8dh, th.data(), sizeof(double2) * th.size(), hipMemcpyHostToDevice));
   }
   return true;
 }
@@ -1034,7 +1048,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
     RVC_CK(rvc::launch_fir(r, s->nch, st));
   }
   rvc::InvArgs v{};
-  v.Y = yrows; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(T.f64i); v.wsplit = T.wsp(T.f64i); v.tw8 = T.t8p(T.f64i);
+  v.Y = yrows; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(T.f64i); v.wsplit = T.wsp(T.f64i); v.tw8 = T.t8p(T.f64i); v.tw8_half = T.t8h(T.f64i);
   v.blk0 = m_lo;
   v.dst = s->tailring; v.dst_chan_stride = (long long)s->ring_cap; v.dst_origin = 0; v.dst_mask = s->ring_cap - 1;
   v.lo = 0; v.hi = (long long)1 << 62;
@@ -1137,7 +1151,7 @@ bool head_stage(rvc_set *s, long long n0, long long na, long long nb, const floa
     else if (!tail_rows(s, (nb - 1) / (long long)T.B + 1, s->st_main)) return false;   // lazily, if skipped
   }
   rvc::InvArgs v{};
-  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(A.f64i); v.wsplit = A.wsp(A.f64i); v.tw8 = A.t8p(A.f64i);
+  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(A.f64i); v.wsplit = A.wsp(A.f64i); v.tw8 = A.t8p(A.f64i); v.tw8_half = A.t8h(A.f64i);
   v.blk0 = ka;
   v.dst = d_out + (na - n0); v.dst_chan_stride = (long long)out_stride; v.dst_origin = na; v.dst_mask = ~0ull;
   v.lo = na; v.hi = nb;
@@ -1454,7 +1468,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
     }
     rvc::InvArgs v{};
-    v.Y = W.Y; v.y_chan_stride = r.y_chan_stride; v.tw = W.twp(W.f64i); v.wsplit = W.wsp(W.f64i); v.tw8 = W.t8p(W.f64i);
+    v.Y = W.Y; v.y_chan_stride = r.y_chan_stride; v.tw = W.twp(W.f64i); v.wsplit = W.wsp(W.f64i); v.tw8 = W.t8p(W.f64i); v.tw8_half = W.t8h(W.f64i);
     v.blk0 = m_first;
     v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
     v.lo = n0; v.hi = n1;
@@ -1520,7 +1534,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
           RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
         }
         rvc::InvArgs v{};
-        v.Y = r.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(T.f64i); v.wsplit = T.wsp(T.f64i); v.tw8 = T.t8p(T.f64i);
+        v.Y = r.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(T.f64i); v.wsplit = T.wsp(T.f64i); v.tw8 = T.t8p(T.f64i); v.tw8_half = T.t8h(T.f64i);
         v.blk0 = r0;
         v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
         v.lo = n0; v.hi = n1;
@@ -2177,7 +2191,7 @@ static int debug_fft(int device, size_t n, int f64, bool inverse, const float *i
     }
     ok = hipMemcpy(d_f, Y.data(), sizeof(float2) * 2 * B, hipMemcpyHostToDevice) == hipSuccess;
     rvc::InvArgs v{};
-    v.Y = d_f; v.y_chan_stride = (long long)(2 * B); v.tw = g.twp(g.f64i); v.wsplit = g.wsp(g.f64i); v.tw8 = g.t8p(g.f64i);
+    v.Y = d_f; v.y_chan_stride = (long long)(2 * B); v.tw = g.twp(g.f64i); v.wsplit = g.wsp(g.f64i); v.tw8 = g.t8p(g.f64i); v.tw8_half = g.t8h(g.f64i);
     v.blk0 = 0; v.dst = d_t; v.dst_chan_stride = (long long)n; v.dst_origin = 0; v.dst_mask = ~0ull;
     v.lo = 0; v.hi = (long long)n; v.add = nullptr;
     ok = ok && rvc::launch_fft_inv(logB, g.f64i, v, 2, 1, s->st_main) == hipSuccess &&

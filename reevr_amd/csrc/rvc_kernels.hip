@@ -235,6 +235,8 @@ __host__ __device__ constexpr int lpad_leg(int p, int r) {
   return p >= 16 ? r * p + (r * p) / 16 : (p == 8 ? 8 * r + (r >> 1) : r);
 }
 
+template <typename R> __device__ __forceinline__ cx<R> csq(const cx<R> w) { return mk<R>(w.x * w.x - w.y * w.y, (R)2 * w.x * w.y); }
+
 template <typename R, bool INV>
 __device__ __forceinline__ void dft4(cx<R> &u0, cx<R> &u1, cx<R> &u2, cx<R> &u3) {
   const cx<R> a = cadd(u0, u2), b = csub(u0, u2), c = cadd(u1, u3), d = csub(u1, u3);
@@ -325,8 +327,13 @@ __device__ __forceinline__ cx<R> wave_partner_pos(const cx<R> *v, const int tid,
 // INLDS: the pass twiddles are parked in the thread's own column of an LDS table ([slot][thread]: written and read by the
 // same thread, so no barrier) and read back one pass ahead -- for the inverse loop kernel, whose register budget they
 // do not fit in (a spilled twiddle is reloaded behind a wait for EVERY outstanding load, the row prefetch included).
-template <int LOGB, typename R, bool HELD_ = false, bool CONJ_ = false, bool INLDS_ = false, bool NOEAGER_ = false> struct Tw8 {
+template <int LOGB, typename R, bool HELD_ = false, bool CONJ_ = false, bool INLDS_ = false, bool NOEAGER_ = false, bool SQ_ = false>
+struct Tw8 {
   typedef Plan8<LOGB> P;
+  // SQ (fetched per pass, double): only w^k of a pass is fetched, w^2k and w^4k are its squares -- 16 instead of 48 bytes per
+  // thread and pass through the CU's one vector-memory path (a double transform moved more twiddle than data bytes through
+  // it); the squares' error (a few 1e-16) is nothing beside the float the result is stored as.
+  static constexpr bool SQ = SQ_;
   static constexpr bool HELD = HELD_;
   static constexpr bool CONJ = CONJ_;   // HELD: held conjugated (the inverse kernel: no per-pass negation, no second copy)
   static constexpr bool INLDS = INLDS_;
@@ -447,7 +454,9 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const TW &T, con
   auto fetch8 = [&](const int j) {
 #pragma unroll
     for (int s = 0; s < P::S; ++s) {
-      nxt[s][0] = T.w8(j, s, 1); nxt[s][1] = T.w8(j, s, 2); nxt[s][2] = T.w8(j, s, 4);
+      nxt[s][0] = T.w8(j, s, 1);
+      if constexpr (TW::SQ) { nxt[s][1] = nxt[s][0]; nxt[s][2] = nxt[s][0]; }   // (squared where they are used, behind the wait)
+      else { nxt[s][1] = T.w8(j, s, 2); nxt[s][2] = T.w8(j, s, 4); }
     }
   };
   auto fetchq = [&]() {
@@ -527,6 +536,7 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const TW &T, con
           // Fetch w^k, w^2k, w^4k only and build the other four with one complex multiply each: the seven
           // twiddles of a butterfly are more bytes than its data (twiddle error <= 2 roundings instead of 1).
           C w1 = cur[s][0], w2 = cur[s][1], w4 = cur[s][2];
+          if constexpr (TW::SQ) { w2 = csq(w1); w4 = csq(w2); }
           if (INV && !TW::CONJ) { w1.y = -w1.y; w2.y = -w2.y; w4.y = -w4.y; }
           const C w3 = cmul(w1, w2), w5 = cmul(w1, w4), w6 = cmul(w2, w4);
           const C w7 = cmul(w3, w4);
@@ -948,6 +958,119 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_inv(cons
         if (n + 1 >= a.lo && n + 1 < a.hi) dst[(unsigned long long)(n + 1 - a.dst_origin) & a.dst_mask] = t1;
       }
     }
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// Round 5: the 8192-bin inverse in DOUBLE -- the tail inverse of every lock-step set since the reference's known-answer rule is
+// met by default -- as TWO 4096-point sub-transforms in two workgroups. The one-row double kernel needs 136 KiB of LDS: one
+// workgroup per CU, nobody to run under its five barrier-separated exchanges (0.26 of the HBM peak). Decimation in frequency
+// splits z[n] = sum_k Z[k] w^{-kn} by the parity of n:
+//   z[2m]     = IDFT_{B/2}( Z[k] + Z[k + B/2] )[m],      z[2m + 1] = IDFT_{B/2}( (Z[k] - Z[k + B/2]) w^{-k} )[m],   w = e^{-2 pi i / B}:
+// two independent half-size transforms (68 KiB of LDS each: two workgroups per CU, 512 threads), each fed by the whole spectrum
+// row. The inverse real split that makes Z from the packed bins pairs k with B - k; the half-size inputs pair k with k + B/2:
+// one thread per k < B/4 loads the four bins k, B - k, B/2 - k, B/2 + k, forms Z at all four, combines them into its own input
+// u[k] (or v[k]) and the input of its mirror u[B/2 - k], which goes to its owner through LDS -- the one-row kernel's prologue with
+// two pairs instead of one. The two workgroups of a row sit 8 apart in the grid (same XCD, dispatched together: the second
+// read of the row comes from that XCD's L2); each writes every other sample PAIR of the block.
+// Launched only for whole blocks going to an aligned, unwrapped run of the destination, no add stream (launch_fft_inv).
+// ----------------------------------------------------------------------------------------
+template <int LOGBH, typename R>
+__global__ void __launch_bounds__(Plan8<LOGBH>::WG, 2) k_fft8_inv_dif2(const InvArgs a, const int items) {
+  typedef Plan8<LOGBH> P;
+  typedef cx<R> C;
+  typedef Tw8<LOGBH, R, false, false, false, false, true> TW;    // (w^2k, w^4k of a pass squared from w^k: a third of the fetches)
+  static_assert(P::TPW == 1 && P::S == 1 && P::Q == 1 && P::kLin && !TW::EAGER, "a big single-transform plan without a final pass");
+  static_assert(2 * P::B == 16 * P::NT, "the constant turns between a thread's four bins below");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int BH = P::B, B = 2 * BH, NT = P::NT;
+  const int tid = threadIdx.x;
+  C *lds = reinterpret_cast<C *>(smem_raw);
+  // jobs (row, channel) in chunks of 8; workgroups j and j + 8 of a chunk are the two halves of job 8 chunk + (j & 7)
+  const int chunk = blockIdx.x >> 4, j16 = blockIdx.x & 15;
+  const int w = chunk * 8 + (j16 & 7), par = j16 >> 3;
+  if (w >= items) return;                                    // (uniform: the last chunk's unused slots)
+  const int r_ = w % a.rows, c = w / a.rows;
+  const long long nblk = (a.blk0 + r_) * (long long)B;
+  const float2 *Y = a.Y + (long long)c * a.y_chan_stride + (long long)r_ * B;
+  TW T;
+  T.load(reinterpret_cast<const C *>(a.tw8_half), nullptr, tid);   // (no final radix-2 / 4 pass: the second table is never read)
+  const R sc = (R)0.5 / (R)B;
+  const int lt = lpad(tid), ln = lpad_neg(tid);
+  C v[P::E];
+  // The self-paired bins (thread 0's; every thread asks for the same four addresses, one transaction each -- in flight
+  // with the rest instead of a dependent round trip of one lane behind the loop).
+  const float2 y0 = Y[0], yh = Y[B / 2], yq = Y[B / 4], yqc = Y[3 * B / 4];
+  // e^{-i pi k / B} of the thread's first bin, k = tid; its other bins sit NT = B/16 apart: a constant turn each. Everything
+  // else the split needs follows from it: e^{-i pi (k + B/2) / B} = -i e^{-i pi k / B}, w^{-k} = conj of its square.
+  const C wk0 = reinterpret_cast<const C *>(a.wsplit)[tid];
+  // With E = Y[k] + conj Y[B-k], D = Y[k] - conj Y[B-k] and E', D' the same of the pair (k + B/2, B/2 - k), cw = e^{+i pi k / B}:
+  //   Z[k] = E + i cw D,  Z[k + B/2] = E' - cw D',  Z[B - k] = conj E + i conj(cw D),  Z[B/2 - k] = conj E' + conj(cw D')
+  // so the half-size inputs of index k and of its mirror B/2 - k are  A + i Q  and  conj A + i conj Q  with
+  //   sums (even samples):          A = E + E',            Q = cw (D + i D')
+  //   differences times w^{-index}: A = (E - E') w^{-k},   Q = cw w^{-k} (D - i D')        (w^{-(B/2 - k)} = -conj w^{-k})
+  // -- the one-row kernel's real split at half the size, one complex product (three) per pair of pairs.
+  float2 ya[4], yb[4], yc[4], yd[4];                          // (all sixteen requests go out before the first is waited for)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned k = (unsigned)(tid + e * NT);             // < B / 4
+    ya[e] = Y[k]; yb[e] = Y[((unsigned)B - k) & (unsigned)(B - 1)];            // (k = 0 reads bin 0 twice: replaced below)
+    yc[e] = Y[k + (unsigned)(B / 2)]; yd[e] = Y[(unsigned)(B / 2) - k];
+  }
+  auto pair_of_pairs = [&](const int e, auto odd) {
+    const C turn = e == 1 ? mk<R>((R)0.98078528040323044913, (R)-0.19509032201612826785)      // e^{-i pi e / 16}
+                 : e == 2 ? mk<R>((R)0.92387953251128675613, (R)-0.38268343236508977173)
+                          : mk<R>((R)0.83146961230254523708, (R)-0.55557023301960222474);
+    const C wk = e == 0 ? wk0 : cmul(wk0, turn);
+    const C Ev = mk<R>((R)ya[e].x + (R)yb[e].x, (R)ya[e].y - (R)yb[e].y), Dv = mk<R>((R)ya[e].x - (R)yb[e].x, (R)ya[e].y + (R)yb[e].y);
+    const C Ep = mk<R>((R)yc[e].x + (R)yd[e].x, (R)yc[e].y - (R)yd[e].y), Dp = mk<R>((R)yc[e].x - (R)yd[e].x, (R)yc[e].y + (R)yd[e].y);
+    C A, Q;
+    if constexpr (!decltype(odd)::value) {
+      A = cadd(Ev, Ep);
+      Q = cmul(cconj(wk), mk<R>(Dv.x - Dp.y, Dv.y + Dp.x));
+    } else {
+      const C w2 = csq(wk);                                  // conj = w^{-k}
+      A = cmul(csub(Ev, Ep), cconj(w2));
+      Q = cmul(cconj(cmul(wk, w2)), mk<R>(Dv.x + Dp.y, Dv.y - Dp.x));
+    }
+    v[e] = mk<R>(sc * (A.x - Q.y), sc * (A.y + Q.x));
+    if (e > 0 || tid != 0) lds[ln + lpad_c(BH - e * NT)] = mk<R>(sc * (A.x + Q.y), sc * (Q.x - A.y));
+  };
+  if (par == 0) {                                            // (uniform)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pair_of_pairs(e, std::false_type());
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pair_of_pairs(e, std::true_type());
+  }
+  if (tid == 0) {
+    // index 0: Z[0] from the packed (DC, Nyquist) bin with Z[B/2] = conj(Y[B/2]) / B; mirror slot = index B/4: Z[B/4] with Z[3B/4]
+    const C z0 = mk<R>(sc * ((R)y0.x + (R)y0.y), sc * ((R)y0.x - (R)y0.y));
+    const C zh = mk<R>((R)2 * sc * (R)yh.x, -(R)2 * sc * (R)yh.y);
+    const R h = (R)0.70710678118654752440;
+    const C Eq = mk<R>(sc * ((R)yq.x + (R)yqc.x), sc * ((R)yq.y - (R)yqc.y)), Dq = mk<R>(sc * ((R)yq.x - (R)yqc.x), sc * ((R)yq.y + (R)yqc.y));
+    const C O = cmul(mk<R>(h, h), Dq);                       // e^{+i pi / 4} D
+    const C zq = mk<R>(Eq.x - O.y, Eq.y + O.x), zqc = mk<R>(Eq.x + O.y, O.x - Eq.y);
+    if (par == 0) {
+      v[0] = cadd(z0, zh);
+      lds[lpad(BH / 2)] = cadd(zq, zqc);
+    } else {
+      const C d = csub(zq, zqc);
+      v[0] = csub(z0, zh);
+      lds[lpad(BH / 2)] = mk<R>(-d.y, d.x);                  // w^{-B/4} = +i
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 4; e < P::E; ++e) v[e] = lds[lt + lpad_c(e * NT)];
+  __syncthreads();                                           // the transform's first exchange overwrites the buffer
+  fft8_core<LOGBH, true, R, false, TW>(v, lds, T, tid);
+  // sub-transform output m = z[2m + par]; the block's samples are z[B/2 .. B) = sample pairs: m >= BH/2, pair index 2 (m - BH/2) + par
+  float2 *ob = reinterpret_cast<float2 *>(a.dst + (long long)c * a.dst_chan_stride + ((unsigned long long)(nblk - a.dst_origin) & a.dst_mask));
+#pragma unroll
+  for (int e = 4; e < P::E; ++e) {
+    const int m = tid + e * NT;
+    ob[2 * (m - BH / 2) + par] = make_float2((float)v[e].x, (float)v[e].y);
   }
 }
 
@@ -2150,6 +2273,15 @@ static bool inv_rows_loopable(const InvArgs &a, int rows) {
          (n0 - a.dst_origin) % B == 0 && (reinterpret_cast<uintptr_t>(a.dst) & 7u) == 0 && (a.dst_chan_stride & 1) == 0;
 }
 
+// whole blocks to an aligned run of the destination that does not wrap inside a block (a ring of whole blocks, or linear memory)
+static bool inv_rows_flat(const InvArgs &a, int rows) {
+  constexpr long long B = 1ll << kLoopLogB;
+  const long long n0 = a.blk0 * B;
+  const bool linear = a.dst_mask == ~0ull;
+  return a.add == nullptr && a.lo <= n0 && n0 + rows * B <= a.hi && (linear || (long long)(a.dst_mask + 1ull) % B == 0) &&
+         (n0 - a.dst_origin) % B == 0 && (reinterpret_cast<uintptr_t>(a.dst) & 7u) == 0 && (a.dst_chan_stride & 1) == 0;
+}
+
 hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int channels, hipStream_t st) {
   if (rows <= 0 || channels <= 0) return hipSuccess;
   if (logB == kLoopLogB && !f64 && launch_tune().fft_loop != 0 && fwd_rows_loopable(a, rows)) {
@@ -2190,6 +2322,17 @@ hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int ch
       RVC_LAUNCH((k_fft8_inv_loop<kLoopLogB>), dim3(grid), dim3(P::WG), fft_loop_lds_bytes(true), st, b, (int)items);
       return hipGetLastError();
     }
+  }
+  // the 8192-bin inverse in double (lock-step sets' tail stage): two half-size sub-transforms per row in two workgroups
+  const long long items = (long long)rows * channels;
+  if (logB == kLoopLogB && f64 && a.tw8_half && launch_tune().inv_dif != 0 && inv_rows_flat(a, rows) && items < (1ll << 26) &&
+      (launch_tune().inv_dif > 0 || items >= 64)) {
+    typedef Plan8<kLoopLogB - 1> PH;
+    InvArgs b = a;
+    b.rows = rows;
+    RVC_LAUNCH((k_fft8_inv_dif2<kLoopLogB - 1, double>), dim3((unsigned)(16 * ((items + 7) / 8))), dim3(PH::WG),
+               sizeof(cx<double>) * PH::LDS_ELEMS, st, b, (int)items);
+    return hipGetLastError();
   }
   if (f64) {
     switch (logB) { RVC_CASES_0_13(launch_inv_t, double, a, rows, channels, st) default: return hipErrorInvalidValue; }
@@ -2348,6 +2491,7 @@ hipError_t prepare_kernels() {
     if (e != hipSuccess) return e;
   }
   const void *big[] = {reinterpret_cast<const void *>(k_fft8_fwd_loop<kLoopLogB>), reinterpret_cast<const void *>(k_fft8_inv_loop<kLoopLogB>),
+                       reinterpret_cast<const void *>(k_fft8_inv_dif2<kLoopLogB - 1, double>),
                        reinterpret_cast<const void *>(k_fft8_fwd<13, float>), reinterpret_cast<const void *>(k_fft8_inv<13, float, true>),
                        reinterpret_cast<const void *>(k_fft8_inv<13, float, false>),
                        reinterpret_cast<const void *>(k_fft8_fwd<14, float>), reinterpret_cast<const void *>(k_fft8_inv<14, float, true>),

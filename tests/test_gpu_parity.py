@@ -1336,6 +1336,53 @@ def test_row_looping_transforms_match_one_row_kernels(widen):
         assert rel_rms(outs[1][c], o.process(x[c])) <= TOL, c
 
 
+def test_double_inverse_as_two_half_transforms(golden):
+    """k_fft8_inv_dif2 -- the 8192-bin inverse in double as two 4096-point sub-transforms in two workgroups, the tail inverse of
+    lock-step sets from 64 rows on -- against the one-row double kernel ("inv_dif" 0) and the known answers: (1) the bare
+    transform on the reference's AudioFFT spectrum (tests/golden/audiofft.npz, n = 16384), both forms within the f64 tolerance
+    of the golden round trip and within 1e-7 of each other; (2) a 601-channel set (an odd job count: the last chunk of 8 has
+    unused slots), head 512 / tail 8192, both forms sample against sample and against the oracle."""
+    import torch
+    from reevr_amd import _lib
+    L = _lib.lib()
+    g = golden["audiofft"]
+    n = 16384
+    fp = lambda a: a.ctypes.data_as(_lib.F32P)
+    wre = np.ascontiguousarray(g[f"n{n}/re"], np.float32)
+    wim = np.ascontiguousarray(g[f"n{n}/im"], np.float32)
+    wrt = g[f"n{n}/rt"].astype(np.float64)
+    rts = {}
+    for mode in (0, 1):
+        reevr_amd.set_tuning("inv_dif", mode)
+        try:
+            rt = np.full(n, np.nan, np.float32)
+            assert L.rvc_debug_irfft(0, n, 1, fp(rt), fp(wre), fp(wim)) == 1
+            rts[mode] = rt.astype(np.float64)
+        finally:
+            reevr_amd.set_tuning("inv_dif", -1)
+        assert np.sqrt(np.mean((rts[mode] - wrt) ** 2)) / np.sqrt(np.mean(wrt ** 2)) <= 3e-7, mode
+    assert np.sqrt(np.mean((rts[1] - rts[0]) ** 2)) / np.sqrt(np.mean(wrt ** 2)) <= 1e-7
+    nch, head, tail, nblk = 601, 512, 8192, 16 * 7
+    irs = [synth.synth_ir(2 * tail + 3 * tail - 101 * (c % 7), 1, 40 + c % 11)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 300 + c % 9) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    outs = {}
+    for mode in (0, -1):
+        s = reevr_amd.ConvolverSet(nch, tune={"inv_dif": mode})
+        assert s.init(head, tail, irs, max_len=head), s.last_error_string
+        assert s.tail_block == tail and s.plan()["tail_f64"] == 2
+        outs[mode] = s.process_device_blocks(dx, head).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        s.close()
+    assert np.isfinite(outs[-1]).all()
+    for c in range(nch):
+        assert rel_rms(outs[-1][c], outs[0][c]) <= 1e-6, c
+    for c in (0, 300, 600):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(outs[-1][c], o.process(x[c])) <= TOL, c
+
+
 @pytest.mark.parametrize("seed", [0, 3, 7, 11, 226])
 def test_guard_bands_stay_intact_and_outputs_finite(seed):
     """Out-of-bounds net (rvc_debug_guard_check): every device allocation of the set between NaN-filled guard bands and
