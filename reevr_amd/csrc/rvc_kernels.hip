@@ -609,7 +609,7 @@ template <int LOGB, typename R, bool MANY = false>
 __global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_fwd(const FwdArgs a) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
-  typedef Tw8<LOGB, R, false, false, false, MANY> TW;
+  typedef Tw8<LOGB, R, false, false, false, MANY, sizeof(R) == 8> TW;   // (double, fetched per pass: w^2k, w^4k squared from w^k)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int B = P::B;
   const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;   // sub-transform of this workgroup
@@ -808,7 +808,7 @@ template <int LOGB, typename R, bool ADD = true, bool MANY = false>
 __global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_inv(const InvArgs a) {
   typedef Plan8<LOGB> P;
   typedef cx<R> C;
-  typedef Tw8<LOGB, R, false, false, false, MANY> TW;
+  typedef Tw8<LOGB, R, false, false, false, MANY, sizeof(R) == 8> TW;   // (double, fetched per pass: w^2k, w^4k squared from w^k)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int B = P::B;
   const int sub = threadIdx.x / P::NT, tid = threadIdx.x % P::NT;

@@ -211,6 +211,7 @@ def test_pmc_summary_kernel_families():
     assert fam("void rvc::k_fdl_sweep_lds<16, 2, 1, 1, true, 4, true>(rvc::FirArgs, int)") == "sweep_tail"
     assert fam("void rvc::k_fdl_sweep_lds<16, 2, 1, 0, true, 4, false>(rvc::FirArgs, int)") == "sweep_head"
     assert fam("void rvc::k_fft8_inv<13, double, false, false>(rvc::InvArgs)") == "fft_inv_tail"
+    assert fam("void rvc::k_fft8_inv_dif2<12, double>(rvc::InvArgs, int)") == "fft_inv_tail"
 
 
 
