@@ -182,7 +182,7 @@ struct LaunchTune {
   int sweep_lw = 0;      // 4 = 16-byte lanes for the 16-block first-level sweeps (default by row length)
   int sweep_d = 0;       // 8 = eight row pairs requested ahead in the long-tile sweeps (default 4)
   int sweep_lds = -1;    // LDS-fed first-level sweeps, accumulators split over waves (rvc_sweep.hip): -1 default / 0 off / 1 / 2 / 3
-  int inv_dif = -1;      // 8192-bin DOUBLE inverse as two 4096-point sub-transforms in two workgroups (k_fft8_inv_dif2): -1 from 64 rows on / 0 / 1
+  int inv_dif = -1;      // 8192-bin DOUBLE inverse as two 4096-point sub-transforms in two workgroups (k_fft8_inv_dif2): 0 off / else on
   int mac3 = -1;         // three-product complex multiply-accumulate in the LDS-fed 32-block sweeps: -1 default / 0 off / 1 on
 };
 void set_launch_tune(const LaunchTune *t);   // thread-local; nullptr = the defaults above

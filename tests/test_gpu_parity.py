@@ -1338,7 +1338,7 @@ def test_row_looping_transforms_match_one_row_kernels(widen):
 
 def test_double_inverse_as_two_half_transforms(golden):
     """k_fft8_inv_dif2 -- the 8192-bin inverse in double as two 4096-point sub-transforms in two workgroups, the tail inverse of
-    lock-step sets from 64 rows on -- against the one-row double kernel ("inv_dif" 0) and the known answers: (1) the bare
+    lock-step sets -- against the one-row double kernel ("inv_dif" 0) and the known answers: (1) the bare
     transform on the reference's AudioFFT spectrum (tests/golden/audiofft.npz, n = 16384), both forms within the f64 tolerance
     of the golden round trip and within 1e-7 of each other; (2) a 601-channel set (an odd job count: the last chunk of 8 has
     unused slots), head 512 / tail 8192, both forms sample against sample and against the oracle."""
