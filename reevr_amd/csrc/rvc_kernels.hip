@@ -969,10 +969,13 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG, MANY ? 8 : 1) k_fft8_inv(cons
 //   z[2m]     = IDFT_{B/2}( Z[k] + Z[k + B/2] )[m],      z[2m + 1] = IDFT_{B/2}( (Z[k] - Z[k + B/2]) w^{-k} )[m],   w = e^{-2 pi i / B}:
 // two independent half-size transforms (68 KiB of LDS each: two workgroups per CU, 512 threads), each fed by the whole spectrum
 // row. The inverse real split that makes Z from the packed bins pairs k with B - k; the half-size inputs pair k with k + B/2:
-// one thread per k < B/4 loads the four bins k, B - k, B/2 - k, B/2 + k, forms Z at all four, combines them into its own input
-// u[k] (or v[k]) and the input of its mirror u[B/2 - k], which goes to its owner through LDS -- the one-row kernel's prologue with
-// two pairs instead of one. The two workgroups of a row sit 8 apart in the grid (same XCD, dispatched together: the second
-// read of the row comes from that XCD's L2); each writes every other sample PAIR of the block.
+// one thread per k < B/4 loads the four bins k, B - k, B/2 - k, B/2 + k and forms, straight from the two pairs' sums and
+// differences (formulas at the loop below), its own input u[k] (or v[k]) and the input of its mirror u[B/2 - k], which goes to its
+// owner through LDS -- the one-row kernel's prologue at half the size. The two workgroups of a row sit 8 apart in the grid (same
+// XCD, dispatched together: the second read of the row comes from that XCD's L2; PMC: 65.9 KB fetched per row); each writes every
+// other sample PAIR of the block. Twiddles are derived, not fetched (one split twiddle per thread, w^k per pass): the CU's one
+// vector-memory path was a third of a row's time when every thread fetched 21 of them (profiles/r5_inv_dif2.txt).
+// Measured: 134 us per 4096 rows against 196 (one-row kernel), 0.37 of the HBM peak; bound by f64 issue and the LDS pipe.
 // Launched only for whole blocks going to an aligned, unwrapped run of the destination, no add stream (launch_fft_inv).
 // ----------------------------------------------------------------------------------------
 template <int LOGBH, typename R>
