@@ -29,6 +29,17 @@ template <bool NT> __device__ __forceinline__ float4 sweep_ld(const float4 *p) {
   if constexpr (NT) { const vf4 v = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
   else return *p;
 }
+// Accumulator rows of LONG delay-line rows (the tail stages: B >= 2048) are written once and read once, gigabytes later, by the
+// next level / the patch: stored non-temporally (nts; measured with the IR rows' loads -- fdl_sweep_own, loadH -- on MI355X,
+// profiles/r5_sweep_nt.txt). Short rows (a zero-latency stage's: tens of MB per set) stay ordinary stores.
+__device__ __forceinline__ void sweep_st(float2 *p, const float2 v, const bool nts) {
+  if (nts) { vf2 t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<vf2 *>(p)); }
+  else *p = v;
+}
+__device__ __forceinline__ void sweep_st(float4 *p, const float4 v, const bool nts) {
+  if (nts) { vf4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, reinterpret_cast<vf4 *>(p)); }
+  else *p = v;
+}
 __device__ __forceinline__ float2 sweep_zero(float2) { return make_float2(0.f, 0.f); }
 __device__ __forceinline__ float4 sweep_zero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void sweep_add(float2 &r, const float2 o) { r.x += o.x; r.y += o.y; }
@@ -194,7 +205,7 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
 // body's FMAs) at the end of each body. The circular window of fdl_sweep_body has to be unrolled over K steps: 4096 FMAs
 // = 32 KiB of code per walk at K = 32 -- more than the instruction cache feeds to waves in different phases of it (measured:
 // 0.73 / 0.65 / 0.49 of the HBM peak at 4 / 16 / 32 KiB bodies); this body is 8 KiB at K = 32.
-template <int K, int D, int LW, bool NT>
+template <int K, int D, int LW, bool NT, bool NTH = NT>   // NTH: the IR rows' loads non-temporal (also where the delay line's are ordinary)
 __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_tile, const int c) {
   constexpr int U = 8, WN = K + U - 1;
   static_assert(U % D == 0 && K % U == 0, "queue / window indexing");
@@ -222,9 +233,13 @@ __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_til
     const char *rp = reinterpret_cast<const char *>(Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B);
     return sweep_ld<NT>(reinterpret_cast<const V *>(rp + boff));
   };
+  // (an IR row piece is read by ONE wave per sweep: non-temporal in the tail stage's second-level sweeps too -- their ordinary
+  //  loads are for the delay-line rows, whose clamped requests must hit a cache. Measured on MI355X with the non-temporal row
+  //  stores (sweep_st): config 2's second-level tail sweeps 2.71 -> 2.60-2.66 ms per launch, the first-level one 7.97 -> 7.78;
+  //  on a zero-latency stage's short rows -- config 3's 256-bin second-level head sweeps -- it cost 3 %: tail stage only.)
   auto loadH = [&](int i) -> V {
     const char *rp = reinterpret_cast<const char *>(Hc + (long long)i * B);
-    return sweep_ld<NT>(reinterpret_cast<const V *>(rp + boff));
+    return sweep_ld<NTH>(reinterpret_cast<const V *>(rp + boff));
   };
   V acc[K], W[WN];                                   // W[j] = delay-line row cbase - s0 - (U - 1) + j of the current body
 #pragma unroll
@@ -278,6 +293,7 @@ __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_til
   }
   if (active) {
     float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
+    const bool nts = a.B >= 2048;                    // (uniform)
     if (a.Ybase) {
       // second level: + the first-level rows. ALL K requests first, then the stores: written as load / add / store per row
       // the compiler has to keep the order (the rows could alias) and waits for each load AND the previous store in turn --
@@ -285,16 +301,16 @@ __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_til
       const float2 *Yb = a.Ybase + (long long)c * a.ybase_chan_stride + bin;
       V yb[K];
 #pragma unroll
-      for (int t = 0; t < K; ++t) yb[t] = *reinterpret_cast<const V *>(Yb + (long long)((unsigned)(a.k0 + t) & a.ybase_row_mask) * B);
+      for (int t = 0; t < K; ++t) yb[t] = sweep_ld<true>(reinterpret_cast<const V *>(Yb + (long long)((unsigned)(a.k0 + t) & a.ybase_row_mask) * B));
 #pragma unroll
       for (int t = 0; t < K; ++t) {
         V r = acc[t];
         sweep_add(r, yb[t]);
-        *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
+        sweep_st(reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B), r, nts);
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < K; ++t) *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = acc[t];
+      for (int t = 0; t < K; ++t) sweep_st(reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B), acc[t], nts);
     }
   }
 }
@@ -525,6 +541,7 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
     for (int t = 0; t < KW; ++t) acc[t] = make_float2(acc[t].x - acc3[t], packed ? acc[t].y : acc[t].x + acc[t].y);
   }
   float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
+  const bool nts = a.B >= 2048;                     // (uniform; sweep_st)
   const long long k1 = a.k0 + (long long)kw * KW;
   if (a.Ybase) {                                    // (+ rows of a level below: all requests first, then the stores)
     const float2 *Yb = a.Ybase + (long long)c * a.ybase_chan_stride + bin;
@@ -535,11 +552,11 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
     for (int t = 0; t < KW; ++t) {
       V r = acc[t];
       sweep_add(r, yb[t]);
-      Yc[(long long)((unsigned)(k1 + t) & a.y_row_mask) * B] = r;
+      sweep_st(Yc + (long long)((unsigned)(k1 + t) & a.y_row_mask) * B, r, nts);
     }
   } else {
 #pragma unroll
-    for (int t = 0; t < KW; ++t) Yc[(long long)((unsigned)(k1 + t) & a.y_row_mask) * B] = acc[t];
+    for (int t = 0; t < KW; ++t) sweep_st(Yc + (long long)((unsigned)(k1 + t) & a.y_row_mask) * B, acc[t], nts);
   }
 }
 
@@ -550,7 +567,7 @@ __global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a, const in
   // rot: the bin tiles of channel c are taken in the order rotated by c (see launch_variant)
   const int bx = rot ? (int)((blockIdx.x + blockIdx.y * (unsigned)rot) % gridDim.x) : (int)blockIdx.x;
   if constexpr (SPLIT == 1) {
-    fdl_sweep_own<K, D, LW, NT>(a, bx, blockIdx.y);
+    fdl_sweep_own<K, D, LW, NT, NT || STAGE == 1>(a, bx, blockIdx.y);
   } else {
     __shared__ V red[SPLIT][K][64];
     fdl_sweep_body<K, D, SPLIT, LW, NT>(a, reinterpret_cast<V (*)[K][64]>(red), bx, blockIdx.y);
