@@ -71,6 +71,8 @@ struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency
   const float2 *Ybase;      // sweep: optional rows added to the output rows
   long long ybase_chan_stride;
   unsigned ybase_row_mask;
+  int stream;               // sweep (set by launch_fdl_sweep): the stage's IR spectra of this launch exceed the last-level cache:
+                            // accumulator rows are stored non-temporally, second-level sweeps load their IR rows non-temporally
 };
 
 struct InvArgs {            // spectrum row(s) -> last B samples of the inverse transform (overlap-save)
@@ -182,6 +184,7 @@ struct LaunchTune {
   int sweep_lw = 0;      // 4 = 16-byte lanes for the 16-block first-level sweeps (default by row length)
   int sweep_d = 0;       // 8 = eight row pairs requested ahead in the long-tile sweeps (default 4)
   int sweep_lds = -1;    // LDS-fed first-level sweeps, accumulators split over waves (rvc_sweep.hip): -1 default / 0 off / 1 / 2 / 3
+  int sweep_nt = -1;     // sweeps of a stage stream (non-temporal accumulator-row stores, second-level IR loads): -1 by the stage's size / 0 / 1
   int inv_dif = -1;      // 8192-bin DOUBLE inverse as two 4096-point sub-transforms in two workgroups (k_fft8_inv_dif2): 0 off / else on
   int mac3 = -1;         // three-product complex multiply-accumulate in the LDS-fed 32-block sweeps: -1 default / 0 off / 1 on
 };

@@ -29,9 +29,10 @@ template <bool NT> __device__ __forceinline__ float4 sweep_ld(const float4 *p) {
   if constexpr (NT) { const vf4 v = __builtin_nontemporal_load(reinterpret_cast<const vf4 *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
   else return *p;
 }
-// Accumulator rows of LONG delay-line rows (the tail stages: B >= 2048) are written once and read once, gigabytes later, by the
-// next level / the patch: stored non-temporally (nts; measured with the IR rows' loads -- fdl_sweep_own, loadH -- on MI355X,
-// profiles/r5_sweep_nt.txt). Short rows (a zero-latency stage's: tens of MB per set) stay ordinary stores.
+// Accumulator rows of a stage whose IR spectra exceed the last-level cache (FirArgs::stream: the tail stages of many-channel sets,
+// a zero-latency stage of thousands of channels) are written once and read once, gigabytes of traffic later, by the next level /
+// the patch: stored non-temporally (nts; measured with the IR rows' loads -- fdl_sweep_own, loadH -- on MI355X,
+// profiles/r5_sweep_nt.txt). Small stages (tens of MB per set) keep ordinary stores: their rows are still cached when read.
 __device__ __forceinline__ void sweep_st(float2 *p, const float2 v, const bool nts) {
   if (nts) { vf2 t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, reinterpret_cast<vf2 *>(p)); }
   else *p = v;
@@ -233,10 +234,11 @@ __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_til
     const char *rp = reinterpret_cast<const char *>(Xc + (long long)((unsigned long long)rr & a.x_row_mask) * B);
     return sweep_ld<NT>(reinterpret_cast<const V *>(rp + boff));
   };
-  // (an IR row piece is read by ONE wave per sweep: non-temporal in the tail stage's second-level sweeps too -- their ordinary
-  //  loads are for the delay-line rows, whose clamped requests must hit a cache. Measured on MI355X with the non-temporal row
-  //  stores (sweep_st): config 2's second-level tail sweeps 2.71 -> 2.60-2.66 ms per launch, the first-level one 7.97 -> 7.78;
-  //  on a zero-latency stage's short rows -- config 3's 256-bin second-level head sweeps -- it cost 3 %: tail stage only.)
+  // (an IR row piece is read by ONE wave per sweep: non-temporal in the second-level sweeps of a big stage too (NTH) -- their
+  //  ordinary loads are for the delay-line rows, whose clamped requests must hit a cache. Measured on MI355X with the non-temporal
+  //  row stores (sweep_st): config 2's second-level tail sweeps 2.66 -> 2.44 ms per launch on one queue, the first-level one 7.58 ->
+  //  7.18; config 1's 8192-channel zero-latency stage +4-10 % overall; on a small stage -- config 3's 134 MB of 256-bin head
+  //  spectra per child set -- it cost 3 %: chosen by the size of the stage, launch_stage.)
   auto loadH = [&](int i) -> V {
     const char *rp = reinterpret_cast<const char *>(Hc + (long long)i * B);
     return sweep_ld<NTH>(reinterpret_cast<const V *>(rp + boff));
@@ -293,7 +295,7 @@ __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_til
   }
   if (active) {
     float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
-    const bool nts = a.B >= 2048;                    // (uniform)
+    const bool nts = a.stream != 0;                  // (uniform)
     if (a.Ybase) {
       // second level: + the first-level rows. ALL K requests first, then the stores: written as load / add / store per row
       // the compiler has to keep the order (the rows could alias) and waits for each load AND the previous store in turn --
@@ -541,7 +543,7 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
     for (int t = 0; t < KW; ++t) acc[t] = make_float2(acc[t].x - acc3[t], packed ? acc[t].y : acc[t].x + acc[t].y);
   }
   float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
-  const bool nts = a.B >= 2048;                     // (uniform; sweep_st)
+  const bool nts = a.stream != 0;                   // (uniform; sweep_st)
   const long long k1 = a.k0 + (long long)kw * KW;
   if (a.Ybase) {                                    // (+ rows of a level below: all requests first, then the stores)
     const float2 *Yb = a.Ybase + (long long)c * a.ybase_chan_stride + bin;
@@ -561,13 +563,13 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
 }
 
 // grid (bin tiles, channels), block 256. STAGE names the instantiation for profilers (0 head, 1 tail).
-template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
+template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT, bool NTH = NT>
 __global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a, const int rot) {
   typedef typename SweepVec<LW>::T V;
   // rot: the bin tiles of channel c are taken in the order rotated by c (see launch_variant)
   const int bx = rot ? (int)((blockIdx.x + blockIdx.y * (unsigned)rot) % gridDim.x) : (int)blockIdx.x;
   if constexpr (SPLIT == 1) {
-    fdl_sweep_own<K, D, LW, NT, NT || STAGE == 1>(a, bx, blockIdx.y);
+    fdl_sweep_own<K, D, LW, NT, NTH>(a, bx, blockIdx.y);
   } else {
     __shared__ V red[SPLIT][K][64];
     fdl_sweep_body<K, D, SPLIT, LW, NT>(a, reinterpret_cast<V (*)[K][64]>(red), bx, blockIdx.y);
@@ -575,7 +577,7 @@ __global__ void __launch_bounds__(256, LB) k_fdl_sweep(const FirArgs a, const in
 }
 
 
-template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT>
+template <int K, int SPLIT, int STAGE, int LW, int D, int LB, bool NT, bool NTH = NT>
 static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
   const int tiles = (a.B + 32 * LW - 1) / (32 * LW);
   const dim3 grid(SPLIT == 1 ? (tiles + 3) / 4 : tiles, channels), block(256);
@@ -585,8 +587,8 @@ static void launch_variant(const FirArgs &a, int channels, hipStream_t st) {
   const int rot = (grid.x >= 8 && launch_tune().tile_rot) ? 1 : 0;
   hipEvent_t ea, eb;
   get_launch_events(&ea, &eb);
-  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, ea, eb, 0, a, rot);
-  else hipLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT>), grid, block, 0, st, a, rot);
+  if (ea) hipExtLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT, NTH>), grid, block, 0, st, ea, eb, 0, a, rot);
+  else hipLaunchKernelGGL((k_fdl_sweep<K, SPLIT, STAGE, LW, D, LB, NT, NTH>), grid, block, 0, st, a, rot);
 }
 
 template <int KW, int NKW, int A, int STAGE, bool NT, int LB, bool M3 = false>
@@ -656,14 +658,22 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
     if (split) launch_variant<8, 4, STAGE, 4, 4, 3, false>(a, channels, st);
     // (second-level sweeps: ordinary loads -- most rows of their walk do not count and are clamped to ONE row, which then
     //  stays in the cache; with non-temporal loads those requests went to HBM: +10 % traffic)
+    else if (a.Ybase && a.stream) launch_variant<8, 1, STAGE, 4, 4, 3, false, true>(a, channels, st);   // (IR rows non-temporal: fdl_sweep_own)
     else if (a.Ybase) launch_variant<8, 1, STAGE, 4, 4, 3, false>(a, channels, st);
     else launch_variant<8, 1, STAGE, 4, 4, 3, true>(a, channels, st);
   }
 }
 
-hipError_t launch_fdl_sweep(const FirArgs &a, int channels, hipStream_t st) {
-  if (channels <= 0 || a.P <= 0) return hipSuccess;
-  if (a.M != 8 && a.M != 16 && a.M != 32) return hipErrorInvalidValue;
+hipError_t launch_fdl_sweep(const FirArgs &a0, int channels, hipStream_t st) {
+  if (channels <= 0 || a0.P <= 0) return hipSuccess;
+  if (a0.M != 8 && a0.M != 16 && a0.M != 32) return hipErrorInvalidValue;
+  // Does anything of this stage survive in a cache between two visits? Its IR spectra alone (h_chan_stride = all partitions of a
+  // channel) against twice the 256 MiB last-level cache: config 2's tail 7.8 GB and config 1's 8192-channel head 790 MB per child
+  // set stream (non-temporal row stores / second-level IR loads: +2-4 % / +4-10 %), config 2's and 3's heads (134 MB per child,
+  // 268 MB on one queue) do not (config 3's second-level head sweeps lost 3 % streaming). profiles/r5_sweep_nt.txt
+  FirArgs a = a0;
+  a.stream = (long long)channels * a.h_chan_stride * (long long)sizeof(float2) >= (512ll << 20) ? 1 : 0;
+  if (launch_tune().sweep_nt >= 0) a.stream = launch_tune().sweep_nt;
   if (a.tag == 0) launch_stage<0>(a, channels, st);
   else launch_stage<1>(a, channels, st);
   return hipGetLastError();

@@ -212,6 +212,11 @@ def test_pmc_summary_kernel_families():
     assert fam("void rvc::k_fdl_sweep_lds<16, 2, 1, 0, true, 4, false>(rvc::FirArgs, int)") == "sweep_head"
     assert fam("void rvc::k_fft8_inv<13, double, false, false>(rvc::InvArgs)") == "fft_inv_tail"
     assert fam("void rvc::k_fft8_inv_dif2<12, double>(rvc::InvArgs, int)") == "fft_inv_tail"
+    # the sweeps' trailing NTH argument (IR rows non-temporal where the delay-line rows' loads are ordinary: big stages' second level)
+    assert fam("void rvc::k_fdl_sweep<8, 1, 1, 4, 4, 3, false, true>(rvc::FirArgs, int)") == "sweep2_tail"
+    assert fam("void rvc::k_fdl_sweep<8, 1, 0, 4, 4, 3, false, false>(rvc::FirArgs, int)") == "sweep2_head"
+    assert fam("void rvc::k_fdl_sweep<8, 1, 0, 4, 4, 3, true, true>(rvc::FirArgs, int)") == "sweep_head"
+    assert fam("void rvc::k_fdl_sweep<16, 1, 1, 4, 4, 2, true, true>(rvc::FirArgs, int)") == "sweep_tail"
 
 
 

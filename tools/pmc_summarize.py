@@ -29,7 +29,7 @@ PATCH0_FAMILY = "premultiply"     # k_fdl_patch<0, ..>: the zero-latency stage's
 def family(name: str, head_log: int, tail_log: int):
     if "k_fused_block" in name or "k_block_step" in name:
         return "fused_block"
-    m = re.search(r"k_fdl_sweep<(\d+), (\d+), (\d), \d+, \d+, \d+, (true|false)>", name)   # <K, SPLIT, STAGE, LW, D, LB, NT>
+    m = re.search(r"k_fdl_sweep<(\d+), (\d+), (\d), \d+, \d+, \d+, (true|false)(?:, (?:true|false))?>", name)   # <K, SPLIT, STAGE, LW, D, LB, NT[, NTH]>
     if m:
         st = "head" if m.group(3) == "0" else "tail"
         # second-level sweeps are exactly the own-tile K = 8 instantiation with ordinary loads (rvc_sweep.hip launch_stage)
