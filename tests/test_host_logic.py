@@ -220,6 +220,32 @@ def test_pmc_summary_kernel_families():
 
 
 
+def test_every_hot_kernel_of_the_committed_summaries_has_a_family():
+    """The rocprofv3 summaries kept under profiles/r5_config<C>/ list C++ kernel names; tools/pmc_summarize.py (and through it
+    bench.py's `traffic`) sorts them into families by those names. Every kernel that takes more than 0.2 % of a kept run must map
+    to a family -- a renamed or new kernel that silently drops out of the accounting fails here -- except the launches of init time
+    (the IR spectra's double forward transforms, the runtime's fill / copy kernels)."""
+    import csv
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_summarize", os.path.join(ROOT, "tools", "pmc_summarize.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    geometry = {1: (9, 13), 2: (9, 13), 3: (8, 14), 5: (12, 13)}          # (head, tail) log2 block sizes: tools/profile_configs.sh
+    init_only = ("k_fft8_fwd<13, double", "k_fft8_fwd<14, double", "k_fft8_fwd<12, double", "__amd_rocclr_")
+    seen = set()
+    for cfg, (hl, tl) in geometry.items():
+        for name in ("kernel_stats.csv", "kernel_stats_one_queue.csv"):
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r5_config{cfg}", name))))
+            total = sum(float(r["TotalDurationNs"]) for r in rows)
+            for r in rows:
+                if float(r["TotalDurationNs"]) / total <= 0.002 or any(t in r["Name"] for t in init_only):
+                    continue
+                fam = m.family(r["Name"], hl, tl)
+                assert fam is not None, (cfg, name, r["Name"])
+                seen.add(fam)
+    assert {"fused_block", "sweep_tail", "sweep2_tail", "sweep_head", "fir_tail", "fft_fwd_tail", "fft_inv_tail"} <= seen
+
+
 def test_compact_bench_line_fits_and_carries_the_contract():
     """bench.py prints ONE compact line last (the driver parses it; round 4's 24 KB line could not be parsed) and writes the
     full record to a side file: the line builder on a canned full record (round 4's, the largest so far) and on an inflated
