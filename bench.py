@@ -81,7 +81,8 @@ SR = 48000
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3  # vector fp32 (same guide)
 K2 = 8                    # rvc::kSweepRows: the tile the per-block patches work on
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r5_traffic.json")
+PROFILE_ROUND = "r5"      # the round whose committed rocprofv3 passes annotate the record (profiles/<round>_config<C>/, <round>_traffic.json)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")
 
 # BASELINE.json configurations as lock-step workloads: IR length, host block, single-stage?, default channels per GPU,
 # host blocks per step (whole tail periods)
@@ -95,6 +96,35 @@ WORKLOADS = {
     5: dict(ir_len=240000, host_block=4096, single=False, channels=4096, blocks=32,
             text="mono channels, 5 s IR @ 48 kHz, block=4096 (head 4096 / tail 8192), TwoStage convolver"),
 }
+
+# What the DEFAULT set of each lock-step workload runs (rvc_set_plan; everything but the channel count). bench.py checks its own
+# sets against this table (`config.plan_as_tested`), and tests/test_gpu_steady_state.py compares sets with exactly these plans with
+# the pinned oracle in steady state -- so the benchmark cannot drift away from what the parity tests cover.
+HEADLINE_PLANS = {
+    1: dict(subsets=4, two_stage=0, tail_on_second_stream=0, head_block=512, tail_block=0, zero_latency_samples=0,
+            head_partitions=94, tail_partitions=0, tail_delay=0, head_f64=0, tail_f64=0, head_tile_blocks=32, tail_tile_blocks=0,
+            block_path=0, head_patch_in_launch=1),
+    2: dict(subsets=2, two_stage=1, tail_on_second_stream=0, head_block=512, tail_block=8192, zero_latency_samples=8192,
+            head_partitions=16, tail_partitions=58, tail_delay=1, head_f64=0, tail_f64=2, head_tile_blocks=8, tail_tile_blocks=32,
+            block_path=0, head_patch_in_launch=1, reference_structure=0),
+    3: dict(subsets=2, two_stage=1, tail_on_second_stream=0, head_block=256, tail_block=16384, zero_latency_samples=16384,
+            head_partitions=64, tail_partitions=175, tail_delay=1, head_f64=0, tail_f64=0, head_tile_blocks=32, tail_tile_blocks=32,
+            block_path=0, head_patch_in_launch=1, reference_structure=0),
+    5: dict(subsets=2, two_stage=1, tail_on_second_stream=0, head_block=4096, tail_block=8192, zero_latency_samples=8192,
+            head_partitions=2, tail_partitions=29, tail_delay=1, head_f64=2, tail_f64=2, head_tile_blocks=0, tail_tile_blocks=16,
+            block_path=1, head_patch_in_launch=0, reference_structure=0),
+}
+
+
+def plan_as_tested(conv, cfg: int):
+    """None when the set runs HEADLINE_PLANS[cfg], else {field: (runs, tested)} -- a knob, a flag or another channel count
+    changed the plan and the steady-state parity tests no longer describe this run."""
+    want = HEADLINE_PLANS.get(cfg)
+    if want is None:
+        return {"config": (cfg, "no tested plan")}
+    got = conv.plan()
+    diff = {k: (got.get(k), v) for k, v in want.items() if got.get(k) != v}
+    return diff or None
 
 
 def alg_bytes_block(B: int, P: int) -> int:
@@ -477,7 +507,7 @@ def roofline_tables(kern: dict, exe: dict, traffic: dict):
 
 
 def load_traffic(nch_per_launch: int, cfg: int, tiled: bool):
-    """Counter-measured HBM bytes per launch of each kernel family (profiles/r5_traffic.json: separate rocprofv3 --pmc
+    """Counter-measured HBM bytes per launch of each kernel family (profiles/<PROFILE_ROUND>_traffic.json: separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes of this command, gfx950-corrected). An entry only applies to launches of exactly the
     channel count it was measured with (`channels_per_launch`: the set's channels / its child sets): anything else is
     refused -- a figure taken at another launch size reads like a model error."""
@@ -490,7 +520,7 @@ def load_traffic(nch_per_launch: int, cfg: int, tiled: bool):
         return {}, None
     ent = ents[0]
     return ({k: v["traffic_bytes"] for k, v in ent.get("kernels", {}).items()},
-            "profiles/r5_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected; "
+            "profiles/" + PROFILE_ROUND + "_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950-corrected; "
             "%d channels per launch)" % nch_per_launch)
 
 
@@ -518,7 +548,7 @@ def side_config(torch, reevr_amd, synth, KERNEL_NAMES, cfg: int, channels: int, 
         "partitions": {"zero-latency stage": ls.conv.partitions(0), "tail stage": ls.conv.partitions(1)},
         "tail_block_run": ls.tail_used, "tail_stage": tail_stage_form(ls.conv, ls.head, ls.tail),
         "tile_blocks": {"zero-latency stage": ls.conv.tile_rows(0), "tail stage": ls.conv.tile_rows(1)},
-        "subsets": ls.conv.subsets,
+        "subsets": ls.conv.subsets, "plan_as_tested": plan_as_tested(ls.conv, cfg) is None,
         "executed_bytes_per_sample": round(exe_bps, 1) if exe_bps else None,
         "frac_of_hbm_peak_executed_bytes": round(rate * exe_bps / 1e9 / HBM_PEAK_GBS, 4) if exe_bps else None,
         "alg_bytes_per_sample": round(bps, 1),
@@ -667,25 +697,27 @@ FAMILY_KERNEL = {"fused_block": "k_fused_block", "fir_tail": "k_fdl_patch<1", "f
 
 
 def rocprof_cross_check(roof: dict, cfg: int, one_queue: bool) -> dict:
-    """The committed `rocprofv3 --kernel-trace --stats` summary of this command (profiles/r5_config<C>/kernel_stats*.csv, older
-    rounds as a fallback): the dominant kernel's average duration there, and the fraction of the HBM peak it gives with this
-    run's bytes per launch -- the figure DESIGN.md quotes; `frac` beside it is this run's own HIP-event measurement."""
+    """HISTORICAL annotation, full record only (never the parsed line): the dominant kernel's average duration in the COMMITTED
+    `rocprofv3 --kernel-trace --stats` summary of this command (profiles/<PROFILE_ROUND>_config<C>/kernel_stats*.csv -- this
+    round's only, no fallback to an older build's profile) and the fraction of the HBM peak it gives with this run's bytes per
+    launch. `frac` beside it is this run's own HIP-event measurement; after a kernel change the two differ until the profile
+    is taken again (tools/profile_configs.sh)."""
     import csv
     pat = FAMILY_KERNEL.get(roof.get("kernel", ""))
     if not pat or not roof.get("bytes_per_launch"):
         return {}
-    for rnd in ("r5", "r4"):
-        f = os.path.join(ROOT, "profiles", "%s_config%d" % (rnd, cfg), "kernel_stats_one_queue.csv" if one_queue else "kernel_stats.csv")
-        if not os.path.exists(f):
-            continue
-        rows = [r for r in csv.DictReader(open(f)) if pat in r["Name"]]
-        if not rows:
-            continue
-        r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-        avg_ms = float(r["AverageNs"]) * 1e-6
-        return {"rocprof_avg_launch_ms": round(avg_ms, 5), "frac_rocprof": round(roof["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "rocprof_summary": os.path.relpath(f, ROOT)}
-    return {}
+    f = os.path.join(ROOT, "profiles", "%s_config%d" % (PROFILE_ROUND, cfg), "kernel_stats_one_queue.csv" if one_queue else "kernel_stats.csv")
+    if not os.path.exists(f):
+        return {}
+    rows = [r for r in csv.DictReader(open(f)) if pat in r["Name"]]
+    if not rows:
+        return {}
+    r = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    avg_ms = float(r["AverageNs"]) * 1e-6
+    return {"rocprof_committed": {"avg_launch_ms": round(avg_ms, 5),
+                                  "frac": round(roof["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "summary": os.path.relpath(f, ROOT),
+                                  "note": "committed profile of an earlier run of this command, not this run's measurement"}}
 
 
 COMPACT_LIMIT = 4096
@@ -705,14 +737,14 @@ def compact_line(full: dict, full_path=None) -> dict:
     line["config"] = _pick(cfg, ("workload", "baseline_config", "channels_per_gpu", "instances_total", "frames_per_channel_per_step",
                                  "host_block", "calls_per_step", "partitions", "tail_stage", "transforms", "tail_block_run", "tile_blocks", "subsets",
                                  "resident_GB", "schedule", "gather", "gathered_channels_per_gpu", "gather_matches_output", "devices",
-                                 "shared_device", "tune"))
+                                 "shared_device", "tune", "plan_as_tested"))
     if len(str(line["config"].get("workload", ""))) > 200:
         line["config"]["workload"] = line["config"]["workload"][:197] + "..."
     roof = full.get("roofline")
     if roof:
         r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms",
                          "traffic_over_model", "alg_frac_reference_schedule", "alg_equiv", "frac_whole_step_executed_bytes",
-                         "default_run_frac", "rocprof_avg_launch_ms", "frac_rocprof", "rocprof_summary"))
+                         "default_run_frac"))
         for k in ("traffic_source", "measured_in"):
             if roof.get(k):
                 r[k] = str(roof[k])[:120]
@@ -921,6 +953,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # the plan this set runs against the one the steady-state parity tests cover (None = the same; literal config 5: no table entry)
+    plan_diff = None if long_call else plan_as_tested(conv, wcfg)
     pre = ls.preroll()
     ls_period = ls.tile_period_steps()     # (a fair average needs --steps to be a multiple of this: 1 except for --config 3, where it is 4)
     for _ in range(args.warmup):
@@ -1146,6 +1180,7 @@ def main():
                             "device-resident I/O, %d input/output batches rotated" % (host_block, nbuf)),
                    "tile_period_steps": ls_period, "pre_roll_steps": pre, "gather": do_gather, "gathered_channels_per_gpu": gch if do_gather else 0,
                    "gather_matches_output": gather_ok, "tune": args.tune,
+                   "plan_as_tested": (plan_diff is None) if not long_call else None, "plan_diff": plan_diff,
                    "sharding": "instances dealt to ranks, equal shards, no data-path collective"
                                + (f"; one RCCL all_gather of the output blocks of {gch} channels per GPU per step, overlapped with the next step" if do_gather else "")},
         "roofline": roof,

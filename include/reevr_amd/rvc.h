@@ -72,7 +72,12 @@ enum {
                                        the inverse transform's -- small outputs sharing a 4096-point transform with outputs of
                                        1.5e7 --; with it in double all 58 of the reference's cases pass that rule (margin <= 0.16)
                                        at -2.4 % on BASELINE config 2 at 4096 channels (both in double: -5.3 %).
-                                   rvc_set_plan reports what runs (head_f64 / tail_f64: bit 0 forward, bit 1 inverse). */
+                                   rvc_set_plan reports what runs (head_f64 / tail_f64: bit 0 forward, bit 1 inverse).
+                                   Latency: the one-launch block kernel is float only. A zero-latency stage with a transform in
+                                   double -- any head with this flag; heads of 2048 .. 8192 in sets of more than 8 channels by
+                                   default (inverse in double) -- serves per-block calls with transform / delay-line / inverse
+                                   launches instead (rvc_plan::block_path = 1: no completion flags, no zero-copy host path);
+                                   RVC_FLAG_FFT_F32 keeps the one-launch path for such heads. */
 #define RVC_FLAG_FFT_F32 256u   /* float32 transforms throughout, whatever the set size (~1e-7 relative, 100x inside the 1e-5 RMS
                                    parity bound; the reference's own rule then fails by up to 10 % on 4 of its 58 cases) */
 #define RVC_FLAG_FFT_F64_LONG 2048u /* the small sets' default rule for a set of ANY size: stages with partitions of 2048 ... 8192

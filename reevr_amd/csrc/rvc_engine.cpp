@@ -35,6 +35,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <climits>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -184,9 +187,14 @@ bool apply_knobs(Tuning &t, const char *knobs) {
     if (eq == std::string::npos || eq == 0 || eq + 1 >= item.size()) return false;
     int *slot = tune_slot(t, item.substr(0, eq));
     if (!slot) return false;
+    // a plain decimal integer that fits an int: "-1", "32" -- not "+5", " 7", "0x10", nor anything out of range (the knobs are
+    // fixed for the set's lifetime and k1 / subsets feed allocation sizes)
+    const char *num = item.c_str() + eq + 1;
+    if (!(std::isdigit((unsigned char)num[0]) || (num[0] == '-' && std::isdigit((unsigned char)num[1])))) return false;
     char *rest = nullptr;
-    const long v = std::strtol(item.c_str() + eq + 1, &rest, 10);
-    if (!rest || *rest != '\0') return false;
+    errno = 0;
+    const long v = std::strtol(num, &rest, 10);
+    if (!rest || *rest != '\0' || errno == ERANGE || v < (long)INT_MIN || v > (long)INT_MAX) return false;
     *slot = (int)v;
   }
   return true;
@@ -1697,7 +1705,9 @@ void release_after_failed_init(rvc_set *s) {
 bool zero_device_out(rvc_set *s, float *d_out, size_t out_stride, size_t len) {
   if (len == 0 || !d_out) return true;
   if (s->streams_ok) {
-    if (hipSetDevice(s->device) != hipSuccess) return true;
+    // (a set that has streams but cannot select its device any more: the caller would read stale output with last_error OK)
+    const hipError_t e = hipSetDevice(s->device);
+    if (e != hipSuccess) return fail(s, RVC_ERR_NO_DEVICE, e, "hipSetDevice (zeroing the output of a failed / empty set)");
     RVC_CK(hipMemset2DAsync(d_out, out_stride * sizeof(float), 0, len * sizeof(float), (size_t)s->nch, s->st_main));
   } else if (hipSetDevice(s->device) == hipSuccess) {   // never initialised with a non-empty IR: no stream yet
     (void)hipMemset2D(d_out, out_stride * sizeof(float), 0, len * sizeof(float), (size_t)s->nch);
@@ -2364,7 +2374,9 @@ int rvc_set_plan(const rvc_set *s, rvc_plan *out, size_t out_size) {
     p.tail_f64 = k->T.P > 0 ? ((k->T.f64f ? 1 : 0) | (k->T.f64i ? 2 : 0)) : 0;
     p.head_tile_blocks = k->tA.on ? k->tA.K1 : 0;
     p.tail_tile_blocks = k->tT.on ? k->tT.K1 : 0;
-    p.block_path = k->block_general ? 1 : 0;
+    // (the one-launch block kernel is float only: a zero-latency stage with a transform in double -- heads of 2048 .. 8192 in sets
+    //  of more than 8 channels by default, any head with RVC_FLAG_FFT_F64 -- takes the general path too)
+    p.block_path = (k->block_general || !rvc::fused_supported(k->A.logB, k->A.f64())) ? 1 : 0;
     p.long_call_block = k->T.PF > 0 ? k->T.B : 0;
     p.wide_block = k->W.P > 0 ? k->W.B : 0;
     p.head_patch_in_launch = k->same_block ? 1 : 0;

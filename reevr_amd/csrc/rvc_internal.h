@@ -133,7 +133,7 @@ struct FusedArgs {
   int handover;
   unsigned *done_flag;
   unsigned seq;
-  unsigned long long *dbg;  // development builds (tools/dev/instrumentation.patch): phase timestamps of workgroup 0, else nullptr
+  unsigned long long *dbg;  // always nullptr in the shipped build (rounds 2-3 stamped workgroup 0's phases through it: docs/history.md section 5b)
 };
 
 struct IngestArgs {

@@ -28,8 +28,8 @@
 //    times per wave and 64 times per workgroup (k_fir_lds stages both operands in LDS).
 //  * The real split pairs bin k with bin B - k: through a wavefront shuffle (lane reversal) where a transform lives in one
 //    wave (blocks of 64 and 512), through LDS otherwise (WaveSplit / wave_partner).
-//  * The ablation / timestamp switches behind the measurements quoted in DESIGN.md are not in this file: they live in
-//    tools/dev/instrumentation.patch (apply to a scratch copy; they produce wrong results by design).
+//  * The ablation / timestamp switches behind the measurements of rounds 2-3 (docs/history.md section 5b) are not in this
+//    file and no longer in the tree: FusedArgs::dbg stays nullptr.
 #include "rvc_internal.h"
 #include "rvc_fft_lds.hpp"
 

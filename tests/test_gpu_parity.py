@@ -860,55 +860,8 @@ def test_time_tiling_many_channels_device_blocks():
         assert rel_rms(outs[True][c], o.process(x[c])) <= TOL, c
 
 
-def test_lockstep_1024_channels_at_bench_geometry():
-    """The bench's regime at a size the oracle can follow: 1024 lock-step channels (8 GB resident), 10 s IRs, head 512 /
-    tail 8192, 300 per-block calls through the device entry (two tail sweep tiles, 37 head tiles; several workgroup rounds
-    per launch). Six channels spread over the set against the oracle; and channel pairs that were given the same IR and
-    the same input must agree bit for bit wherever they run."""
-    import torch
-    nch, head, tail, nblk = 1024, 512, 8192, 300
-    base = [synth.synth_ir(480000, 2, inst=i) for i in range(4)]
-    irs = [base[(c // 2) % 4][c % 2] for c in range(nch)]
-    xs = [synth.synth_input(head * nblk, 90 + i) for i in range(8)]
-    x = np.stack([xs[c % 8] for c in range(nch)])            # channels c and c + 8 share IR and input
-    s = reevr_amd.ConvolverSet(nch)
-    assert s.init(head, tail, irs, max_len=head), s.last_error_string
-    got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
-    assert s.last_error == 0, s.last_error_string
-    s.close()
-    for c in (0, 1, 6, 511, 777, 1023):
-        o = O.TwoStageFFTConvolver("orc")
-        assert o.init(head, tail, irs[c])
-        assert rel_rms(got[c], o.process(x[c])) <= TOL, c
-    for c in range(8):
-        for d in range(c + 8, nch, 8):
-            assert np.array_equal(got[c], got[d]), (c, d)
-
-
-def test_lockstep_4096_channels_impulse_identity():
-    """bench.py's default size (4096 lock-step channels, 33 GB resident, several workgroup rounds per launch) through
-    size-independent properties: a unit impulse in gives the IR out (the definition of the convolution) on channels
-    spread over the set, and all channels that share an IR agree bit for bit -- compared on the device."""
-    import torch
-    nch, head, tail, nblk, at = 4096, 512, 8192, 200, 5
-    base = [synth.synth_ir(480000, 2, inst=i) for i in range(4)]
-    irs = [base[(c // 2) % 4][c % 2] for c in range(nch)]
-    s = reevr_amd.ConvolverSet(nch)
-    assert s.init(head, tail, irs, max_len=head), s.last_error_string
-    n = head * nblk
-    dx = torch.zeros((nch, n), device="cuda")
-    dx[:, at] = 1.0
-    dy = s.process_device_blocks(dx, head)
-    assert s.last_error == 0, s.last_error_string
-    s.close()
-    for c in range(8):                                   # 8 distinct (IR, channel) combinations, cycled
-        ref = dy[c]
-        want = np.zeros(n, np.float32)
-        want[at:] = irs[c][:n - at]
-        err = np.sqrt(np.mean((ref.cpu().numpy().astype(np.float64) - want) ** 2))
-        assert err <= 1e-7, (c, err)
-        same = dy[c::8]
-        assert bool((same == ref.unsqueeze(0)).all()), c
+# (test_lockstep_1024_channels_at_bench_geometry / test_lockstep_4096_channels_impulse_identity of rounds 2-5 stopped before the
+#  delay lines were full; their steady-state successors at bench.py's own plans live in tests/test_gpu_steady_state.py.)
 
 
 @pytest.mark.parametrize("tiling", [False, True, "force", "force2"])
