@@ -9,7 +9,7 @@ LIB   := $(CSRC)/libreevr_amd.so
 
 all: $(LIB) oracle
 
-$(LIB): $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_sweep.hip $(CSRC)/rvc_impulse.hip $(CSRC)/rvc_engine.cpp $(CSRC)/rvc_internal.h $(CSRC)/rvc_fft_lds.hpp include/reevr_amd/rvc.h
+$(LIB): $(CSRC)/rvc_kernels.hip $(CSRC)/rvc_sweep.hip $(CSRC)/rvc_impulse.hip $(CSRC)/rvc_plan.cpp $(CSRC)/rvc_state.cpp $(CSRC)/rvc_schedule.cpp $(CSRC)/rvc_abi.cpp $(CSRC)/rvc_set.h $(CSRC)/rvc_internal.h $(CSRC)/rvc_fft_lds.hpp include/reevr_amd/rvc.h
 	python -m reevr_amd.build --force     # hipcc -c per source (rvc_sweep.hip with -fno-slp-vectorize), then link
 
 oracle:

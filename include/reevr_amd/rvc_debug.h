@@ -63,7 +63,7 @@ const char *rvc_debug_tuning_keys(void);
  * 0 sweeps and patches on long rows take channel c's bin tiles in the order rotated by c; "tail_slack" what the tail's period of
  * slack buys (rvc.h, RVC_MAX_BLOCK): -1 by size / 0 nothing (the reference's structure, delay 2) / 1 a tail at twice the block /
  * 2 half the zero-latency stage, wherever supported (tests force both on small sets); "sweep_lds", "fft_many", "kid_fence",
- * "sweep_lw", "sweep_d", "patch_nt", "block_occ", "mac3", "inv_dif", "sweep_nt": kernel / schedule variants (rvc_internal.h LaunchTune, rvc_engine.cpp
+ * "sweep_lw", "sweep_d", "patch_nt", "block_occ", "mac3", "inv_dif", "sweep_nt": kernel / schedule variants (rvc_internal.h LaunchTune, rvc_set.h
  * Tuning). */
 int rvc_debug_set_tuning(const char *key, int value);
 /* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set

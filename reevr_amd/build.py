@@ -15,13 +15,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libreevr_amd.so")
-SOURCES = ["rvc_kernels.hip", "rvc_sweep.hip", "rvc_impulse.hip", "rvc_engine.cpp"]
+SOURCES = ["rvc_kernels.hip", "rvc_sweep.hip", "rvc_impulse.hip", "rvc_plan.cpp", "rvc_state.cpp", "rvc_schedule.cpp", "rvc_abi.cpp"]
 # per-source extra flags: the kernels are built WITHOUT the SLP vectoriser (rvc_sweep.hip: the comment at its top;
 # rvc_kernels.hip: v_pk_* issues at half the rate of the scalar ops on gfx950 and costs a register shuffle per operand pair --
 # the 8192-bin inverse transform 614 -> 679 instructions but 239 packed + 168 moves -> 424 scalar + 36 moves, 56 -> 40 registers,
 # 115 -> 108 us per 4096 rows; no kernel spills any more)
 EXTRA_FLAGS = {"rvc_sweep.hip": ["-fno-slp-vectorize"], "rvc_kernels.hip": ["-fno-slp-vectorize"]}
-HEADERS = ["rvc_internal.h", "rvc_fft_lds.hpp", os.path.join("..", "..", "include", "reevr_amd", "rvc.h"),
+HEADERS = ["rvc_internal.h", "rvc_set.h", "rvc_fft_lds.hpp", os.path.join("..", "..", "include", "reevr_amd", "rvc.h"),
            os.path.join("..", "..", "include", "reevr_amd", "rvc_debug.h")]
 
 

@@ -1,4 +1,4 @@
-// rvc_internal.h -- launch interface between the engine (rvc_engine.cpp) and the gfx950
+// rvc_internal.h -- launch interface between the engine (rvc_plan / rvc_state / rvc_schedule / rvc_abi .cpp, rvc_set.h) and the gfx950
 // kernels (rvc_kernels.hip). Not part of the public ABI.
 #pragma once
 
@@ -173,7 +173,7 @@ void get_launch_events(hipEvent_t *a, hipEvent_t *b);   // (for launchers in oth
 hipError_t prepare_kernels();
 // Kernel / schedule variants the launchers choose between. Every set carries its own copy (rvc_set::tune, fixed when the set
 // is created); the engine announces it to the launchers of THIS thread for the duration of an entry point (TuneScope in
-// rvc_engine.cpp), so two handles used from two threads never see each other's knobs. Defaults = what ships.
+// rvc_set.h), so two handles used from two threads never see each other's knobs. Defaults = what ships.
 struct LaunchTune {
   int fft_loop = -1;     // row-looping form of the 8192-bin transforms: -1 by size, 0 never, 1 whenever legal
   int fft_many = -1;     // many-rows form of the 4096-bin transforms (twiddles per pass, 4 workgroups per CU): -1 from 2048 rows on / 0 / 1

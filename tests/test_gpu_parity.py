@@ -1166,7 +1166,7 @@ def test_child_sets_match_single_set(kids):
 
 
 def test_tail_slack_policy_and_children():
-    """The delay-1 tail stage (rvc_engine.cpp do_init): lock-step sets of >= 256 channels whose tail job runs on the set's own
+    """The delay-1 tail stage (rvc_plan.cpp plan_stages, rvc_state.cpp do_init): lock-step sets of >= 256 channels whose tail job runs on the set's own
     stream spend the tail period of slack the reference keeps for its background thread -- long tails (>= 128 partitions) run at
     TWICE the requested block, the others give half of the zero-latency stage to the tail; sets with the tail on a second
     stream, fixed partitions, the reference-order schedule or fewer channels keep the reference's structure; the children of a
@@ -1434,7 +1434,7 @@ def test_two_wave_block_kernel_small_heads(head, block):
 def test_many_channels_large_head_block_general_path(fft_many):
     """Many lock-step channels with a LARGE head block (BASELINE config 5's geometry: head 4096 / tail 8192): per-block
     calls are served by transform / delay-line / inverse launches instead of the one-workgroup-per-channel latency kernel
-    (rvc_engine.cpp block_general; the head transform reads the block from the caller's buffer and appends it to the ring,
+    (rvc_state.cpp block_general; the head transform reads the block from the caller's buffer and appends it to the ring,
     the tail job runs behind it); tail stage time-tiled; block calls, then a ragged pair, against the oracle. fft_many: the
     many-rows form of the 4096-bin transforms (twiddles per pass: launches of >= 2048 rows by default) forced on / off."""
     import torch

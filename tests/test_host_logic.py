@@ -63,7 +63,7 @@ def test_bench_traffic_lookup_is_keyed_on_the_launch_size():
 
 
 def test_stage_plan_policy():
-    """rvc_debug_plan (the pure function rvc_set_init applies, rvc_engine.cpp plan_stages): the reference's structure -- zero-latency
+    """rvc_debug_plan (the pure function rvc_set_init applies, rvc_plan.cpp plan_stages): the reference's structure -- zero-latency
     stage over IR[0,2T), tail at block T two blocks late (TwoStageFFTConvolver.cpp:117-138, :213-222) -- for small sets, sets with
     the tail on a second stream, fixed partitions or the reference-order schedule; for lock-step sets of >= 256 channels the tail one
     block late: at block 2T for tails of >= 128 partitions (>= 48 when 2T < 16384), else over IR[T,..) with half the zero-latency
