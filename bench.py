@@ -106,13 +106,13 @@ HEADLINE_PLANS = {
             block_path=0, head_patch_in_launch=1),
     2: dict(subsets=2, two_stage=1, tail_on_second_stream=0, head_block=512, tail_block=8192, zero_latency_samples=8192,
             head_partitions=16, tail_partitions=58, tail_delay=1, head_f64=0, tail_f64=2, head_tile_blocks=8, tail_tile_blocks=32,
-            block_path=0, head_patch_in_launch=1, reference_structure=0),
+            block_path=0, head_patch_in_launch=1, reference_structure=0, tail_spread=0, tail_phase_groups=8),
     3: dict(subsets=2, two_stage=1, tail_on_second_stream=0, head_block=256, tail_block=16384, zero_latency_samples=16384,
             head_partitions=64, tail_partitions=175, tail_delay=1, head_f64=0, tail_f64=0, head_tile_blocks=32, tail_tile_blocks=32,
-            block_path=0, head_patch_in_launch=1, reference_structure=0),
+            block_path=0, head_patch_in_launch=1, reference_structure=0, tail_spread=0, tail_phase_groups=8),
     5: dict(subsets=2, two_stage=1, tail_on_second_stream=0, head_block=4096, tail_block=8192, zero_latency_samples=8192,
             head_partitions=2, tail_partitions=29, tail_delay=1, head_f64=2, tail_f64=2, head_tile_blocks=0, tail_tile_blocks=16,
-            block_path=1, head_patch_in_launch=0, reference_structure=0),
+            block_path=1, head_patch_in_launch=0, reference_structure=0, tail_spread=0, tail_phase_groups=8),
 }
 
 
@@ -272,9 +272,18 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
     exe["premultiply"] = 2.0 * max(PA - 2, 0) * row_h + row_h
     if tail and PT:
         if KT:
-            exe["sweep_tail"] = (2 * PT + KT) * row_t
-            exe["sweep2_tail"] = sweep2_rows(KT, PT, 2) * row_t
-            exe["fir_tail"] = ((K2 / 2.0) * 2 + 2) * row_t   # patch: t = 1..7 recent partitions (mean 4) + the sweep row, 1 row out
+            # (spread sweeps, rvc_plan::tail_spread: a sweep is `slices` launches of a share of the channels each, leaves its
+            #  newest row to the patches -- one partition more per patch -- and the second-level window is one row longer)
+            pl = conv.plan()
+            sp, slices = pl.get("tail_spread", 0), max(1, pl.get("tail_sweep_slices", 1))
+            G = max(1, pl.get("tail_phase_groups", 1))   # phase groups: every sweep / patch launch covers 1 / G of the channels
+            l1, l2 = sp & 1, (sp >> 1) & 1
+            exe["sweep_tail"] = (2 * PT + KT) * row_t / (slices if l1 else 1) / G
+            exe["sweep2_tail"] = (sweep2_rows(KT, PT, 2) + 2 * l1) * row_t / (slices if l2 else 1) / G
+            # patch: the sweep row + the recent partitions (a group's first block needs none when its sweep is not spread), 1 row out
+            depth = [j + (l1 if g == 0 else l2) for g in range(max(1, KT // K2)) for j in range(K2)]
+            per = [2 * d + 2 for d in depth if d > 0]
+            exe["fir_tail"] = float(np.mean(per)) * row_t / G
         else:
             exe["fir_tail"] = (2.0 * PT + 1) * row_t
         exe["fft_fwd_tail"] = float(n1 * (4 * 2 * tail_x + 8 * tail_x))
@@ -453,6 +462,32 @@ class Lockstep:
         self.conv.set_timing(False)
         self.conv.kernel_time_reset()
         return kern
+
+    def call_latency(self, steps: int = 0) -> dict:
+        """What each per-block call costs the device in the back-to-back loop: the block loop with a completion stamp behind
+        every call (HIP events on the set's streams, every child set; rvc_set_process_device_blocks_stamped), over whole
+        first-level tiles. The reference evens this out with its background thread (src/dsp/Convolver.cpp:84-95); here the
+        tail stage's sweeps are spread over the calls of a tail period (rvc_plan::tail_spread)."""
+        if self.long_call:
+            return {}
+        steps = steps or max(2, self.tile_period_steps())
+        gaps = []
+        for _ in range(steps):
+            b = self.i % self.nbuf
+            self.i += 1
+            xi, yo = self.batch(b)
+            _, done = self.conv.process_device_blocks_stamped(xi, self.host_block, yo)
+            self.last_out = yo
+            gaps.append(np.diff(done))                       # (the step's first call carries the loop's start-up: dropped)
+        g = np.sort(np.concatenate(gaps)) * 1e3
+        sr = 96000 if self.cfg == 3 else SR
+        period_us = self.host_block / sr * 1e6
+        p = self.conv.plan()
+        return {"calls": int(len(g)), "mean": round(float(g.mean()), 2), "p50": round(float(g[len(g) // 2]), 2),
+                "p99": round(float(g[int(len(g) * 0.99)]), 2), "max": round(float(g[-1]), 2), "unit": "us",
+                "block_period_us": round(period_us, 1), "max_over_block_period": round(float(g[-1]) / period_us, 4),
+                "tail_spread": p.get("tail_spread", 0), "sweep_slices": p.get("tail_sweep_slices", 1),
+                "tail_phase_groups": p.get("tail_phase_groups", 1)}
 
     def tile_period_steps(self) -> int:
         """steps one first-level tile of the longest-tiled stage spans: a first-level sweep runs once per tile, so only a whole
@@ -775,6 +810,13 @@ def compact_line(full: dict, full_path=None) -> dict:
         line["other_configs"] = others
         optional.append("other_configs")
     side = {}
+    cu = full.get("call_us")
+    if cu:                                  # what each per-block call of the timed set costs the device (stamped loop)
+        line["call_us"] = _pick(cu, ("p50", "p99", "max", "block_period_us", "max_over_block_period", "tail_spread", "tail_phase_groups"))
+        optional.append("call_us")
+    if (full.get("bg_stream") or {}).get("call_us"):
+        side["bg_stream_Msamples_s"] = full["bg_stream"]["value"]
+        side["bg_stream_call_us_p99_max"] = [full["bg_stream"]["call_us"]["p99"], full["bg_stream"]["call_us"]["max"]]
     if full.get("reference_schedule"):
         side["reference_schedule_Msamples_s"] = full["reference_schedule"]["value"]
     if full.get("one_queue"):
@@ -993,6 +1035,7 @@ def main():
 
     # ---- per-kernel durations, live, with HIP events on the streams the kernels run on ----
     kern = ls.kernel_times(KERNEL_NAMES)
+    call_us = ls.call_latency() if (not long_call and world == 1) else None     # cost of each per-block call, stamped on the device
     PA, PT = conv.partitions(0), conv.partitions(1)
     transforms = transforms_form(conv)
     tail_x = ls.tail_used                 # the tail block the set runs (twice the requested one where the engine widens long tails)
@@ -1091,6 +1134,21 @@ def main():
                                  for k, v in oroof.items()},
                 "note": "RVC_FLAG_NO_SUBSETS run of the headline loop (same channels, inputs, call pattern): one set on one queue; "
                         "frac = bytes per launch / mean launch duration / 8 TB/s"}
+        if not args.bg_stream and tail:
+            # the reference's own structure: the tail job on a second stream (RVC_FLAG_BG_STREAM, delay 2, Convolver.cpp:84-95) -- rate
+            # and what each call costs the FOREGROUND stream
+            bgl = Lockstep(torch, reevr_amd, synth, wcfg, instances, local_rank, True, True, blocks, irs=irs, x=x)
+            bgl.preroll()
+            brate, bms = bgl.timed(max(2, args.steps // 4), 1)
+            bprobe = bgl.check_probe()
+            bgl.conv.check()
+            blat = bgl.call_latency()
+            side["bg_stream"] = {"value": round(brate / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(bms, 4),
+                                 "probe_ok": bool(bprobe and bprobe["ok"]), "call_us": blat, "subsets": bgl.conv.subsets,
+                                 "tail_stage": tail_stage_form(bgl.conv, head, tail),
+                                 "note": "RVC_FLAG_BG_STREAM: the reference's stage split, tail job on a second HIP stream; call_us = "
+                                         "completion stamps on the foreground streams"}
+            bgl.close()
         if args.config == 2:
             side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
     if world == 1 and args.cpu_seconds > 0 and lockstep_cfg:
@@ -1185,6 +1243,7 @@ def main():
                                + (f"; one RCCL all_gather of the output blocks of {gch} channels per GPU per step, overlapped with the next step" if do_gather else "")},
         "roofline": roof,
         "probe": probe,
+        "call_us": call_us,
         "roofline_all": roof_all,
         "path_roofline": path,
         "kernels_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()},

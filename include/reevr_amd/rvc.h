@@ -263,6 +263,14 @@ typedef struct rvc_plan {
   int head_patch_in_launch;     /* 1: time-tiled zero-latency stage whose per-block launch patches its OWN block's accumulator and hands
                                    it to the audio wave through LDS (head 128 / 256 / 512); 0: the launch prepares the next block's
                                    accumulator through memory, or the stage is not tiled */
+  int tail_spread;              /* tail-stage sweeps issued one tail period early, in channel slices behind the per-block calls, so that no
+                                   call carries a whole sweep (the reference evens its calls out with a background thread, Convolver.cpp:
+                                   84-95): bit 0 the first-level sweeps, bit 1 the second-level ones; 0 = every sweep inside the call
+                                   that completes its tail block */
+  int tail_sweep_slices;        /* launches a spread sweep is cut into (1 when nothing is spread) */
+  int tail_phase_groups;        /* the tail stage's time tiles run in this many channel groups whose tiles are out of phase: in every tail
+                                   period ONE group sweeps (its channels only) and every group patches at its own depth, so no call
+                                   carries a sweep over the whole set; 1 = all channels in phase */
 } rvc_plan;
 /* plan_size = sizeof(rvc_plan) as the caller compiled it: the struct only ever grows at its end, a caller compiled against a
  * shorter one gets the fields it knows (bytes beyond the library's own struct are zeroed). 1 = filled. */

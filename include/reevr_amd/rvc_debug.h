@@ -17,6 +17,15 @@ extern "C" {
 void rvc_set_process_host_blocks_timed(rvc_set *s, const float *const *in, float *const *out, size_t len, size_t block,
                                        double *us_per_call);
 
+/* rvc_set_process_device_blocks with a completion stamp behind every call: done_ms[i] (ceil(len / block) entries, may be NULL)
+ * receives the time, in milliseconds after the loop started on the device, at which EVERYTHING call i enqueued -- the per-block
+ * launch and the sweeps / tail job behind it, on every child set -- had completed (HIP events on the sets' streams, read after
+ * the loop; the host never waits inside it). done_ms[i] - done_ms[i - 1] is what call i cost the device in the back-to-back loop:
+ * the distribution bench.py reports as `call_us` (the reference evens this out with its background thread, src/dsp/
+ * Convolver.cpp:84-95). Synchronises the set at the end. Returns the number of stamps written, -1 on failure. */
+long rvc_set_process_device_blocks_stamped(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride,
+                                           size_t len, size_t block, double *done_ms);
+
 /* Known-answer entries for the transforms alone: one n-point real transform (n = 2 * partition size, a power
  * of two, 2 <= n <= 2 * RVC_MAX_BLOCK; half that with f64) through the SAME forward / inverse kernels and twiddle
  * tables the convolver stages use, with the reference facade's conventions (AudioFFT::fft / ifft,

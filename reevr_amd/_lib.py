@@ -41,6 +41,8 @@ SIGNATURES = {
     "rvc_set_process_device_blocks": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                              C.c_size_t]),
     "rvc_set_process_host_blocks_timed": (None, [C.c_void_p, F32PP, F32PP, C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]),
+    "rvc_set_process_device_blocks_stamped": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                                          C.POINTER(C.c_double)]),
     "rvc_set_clear": (None, [C.c_void_p]),
     "rvc_set_reset": (None, [C.c_void_p]),
     "rvc_set_is_finished": (C.c_int, [C.c_void_p]),
@@ -116,7 +118,8 @@ class Plan(C.Structure):                # struct rvc_plan
                 ("wide_partitions", C.c_int), ("tail_delay", C.c_int), ("head_f64", C.c_int), ("tail_f64", C.c_int),
                 ("head_tile_blocks", C.c_int), ("tail_tile_blocks", C.c_int), ("block_path", C.c_int),
                 ("reference_structure", C.c_int), ("long_call_block", C.c_size_t), ("wide_block", C.c_size_t),
-                ("head_patch_in_launch", C.c_int)]
+                ("head_patch_in_launch", C.c_int), ("tail_spread", C.c_int), ("tail_sweep_slices", C.c_int),
+                ("tail_phase_groups", C.c_int)]
 
 
 class ImpulseParams(C.Structure):       # struct rvc_impulse_params

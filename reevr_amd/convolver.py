@@ -219,6 +219,25 @@ class ConvolverSet:
             self._order_torch_after(ext)
         return d_out
 
+    def process_device_blocks_stamped(self, d_in, block: int, d_out=None):
+        """process_device_blocks with a completion stamp behind every call (rvc_set_process_device_blocks_stamped): returns
+        (d_out, done_ms) -- done_ms[i] = milliseconds after the loop's start at which everything call i enqueued had completed on
+        the device; np.diff(done_ms) is the cost of each call in the back-to-back loop. Synchronous."""
+        import torch
+        assert d_in.is_cuda and d_in.dtype == torch.float32 and d_in.dim() == 2 and d_in.stride(1) == 1
+        assert d_in.shape[0] == self.n_channels
+        if d_out is None:
+            d_out = torch.empty_like(d_in)
+        torch.cuda.current_stream().synchronize()
+        calls = -(-d_in.shape[1] // block)
+        done = np.zeros(calls, np.float64)
+        n = self._lib.rvc_set_process_device_blocks_stamped(self._h, d_in.data_ptr(), d_in.stride(0), d_out.data_ptr(), d_out.stride(0),
+                                                            d_in.shape[1], block, done.ctypes.data_as(C.POINTER(C.c_double)))
+        if n != calls:
+            raise RvcError("rvc_set_process_device_blocks_stamped failed")
+        self.check()
+        return d_out, done
+
     # -- state --------------------------------------------------------------------------
     def clear(self):
         self._lib.rvc_set_clear(self._h)

@@ -170,6 +170,46 @@ void rvc_set_process_device_blocks(rvc_set *s, const float *d_in, size_t in_stri
     rvc_set_process_device(s, d_in + done, in_stride, d_out + done, out_stride, std::min(block, len - done));
 }
 
+long rvc_set_process_device_blocks_stamped(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride,
+                                           size_t len, size_t block, double *done_ms) {
+  if (!s || block == 0) return -1;
+  std::vector<rvc_set *> units = s->kids.empty() ? std::vector<rvc_set *>{s} : s->kids;
+  for (rvc_set *u : units)
+    if (!u->streams_ok) return -1;
+  if (hipSetDevice(s->device) != hipSuccess) return -1;
+  const size_t calls = (len + block - 1) / block, nu = units.size();
+  std::vector<hipEvent_t> ev((calls + 1) * nu, nullptr);
+  bool ok = true;
+  for (hipEvent_t &e : ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+  if (ok) {
+    rvc_set_sync(s);
+    if (!s->kids.empty()) (void)fence_children_in(s);
+    for (size_t u = 0; u < nu; ++u) ok = ok && hipEventRecord(ev[u], units[u]->st_main) == hipSuccess;     // the loop starts
+    size_t call = 0;
+    for (size_t done = 0; done < len; done += block, ++call) {
+      const size_t n = std::min(block, len - done);
+      if (!s->kids.empty()) forward_device_call(s, d_in + done, in_stride, d_out + done, out_stride, n);
+      else rvc_set_process_device(s, d_in + done, in_stride, d_out + done, out_stride, n);
+      for (size_t u = 0; u < nu; ++u) ok = ok && hipEventRecord(ev[(call + 1) * nu + u], units[u]->st_main) == hipSuccess;
+    }
+    if (!s->kids.empty()) (void)fence_children_out(s);
+    rvc_set_sync(s);
+    // one clock: the children's first stamps were recorded back to back on idle streams; later stamps relative to the earliest
+    for (size_t i = 0; ok && i < calls; ++i) {
+      double t = 0.0;
+      for (size_t u = 0; u < nu; ++u) {
+        float ms = 0.f;
+        ok = ok && hipEventElapsedTime(&ms, ev[0], ev[(i + 1) * nu + u]) == hipSuccess;
+        t = std::max(t, (double)ms);
+      }
+      if (done_ms) done_ms[i] = t;
+    }
+  }
+  for (hipEvent_t e : ev)
+    if (e) hipEventDestroy(e);
+  return ok ? (long)calls : -1;
+}
+
 // The host's per-block loop over HOST buffers with a stopwatch around every call: what the plug-in's audio thread sees
 // per process() (pinned staging + hand-off + kernel + copy back), measured without any host-language overhead.
 void rvc_set_process_host_blocks_timed(rvc_set *s, const float *const *in, float *const *out, size_t len, size_t block,
@@ -297,7 +337,7 @@ void rvc_set_clear(rvc_set *s) {
   s->xa_next = 0;
   s->w_next = 0;
   s->xt_valid_lo = 0;
-  s->tA.drop(); s->tT.drop();
+  s->tA.restart(); s->tT.restart();
 }
 
 void rvc_set_reset(rvc_set *s) {
@@ -651,6 +691,9 @@ int rvc_set_plan(const rvc_set *s, rvc_plan *out, size_t out_size) {
     p.long_call_block = k->T.PF > 0 ? k->T.B : 0;
     p.wide_block = k->W.P > 0 ? k->W.B : 0;
     p.head_patch_in_launch = k->same_block ? 1 : 0;
+    p.tail_spread = k->tT.on ? (k->tT.lag1 | (k->tT.lag2 << 1)) : 0;
+    p.tail_sweep_slices = p.tail_spread ? sweep_slices(k) : 1;
+    p.tail_phase_groups = k->tT.on ? k->tT.G : 1;
     // the reference's structure at these sizes: head + tail0 cover IR[0, 2T) at the head block, the tail runs 2 blocks late
     p.reference_structure = (k->T.P == 0 || (k->T.delay == 2)) ? 1 : 0;
   }

@@ -73,6 +73,8 @@ struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency
   unsigned ybase_row_mask;
   int stream;               // sweep (set by launch_fdl_sweep): the stage's IR spectra of this launch exceed the last-level cache:
                             // accumulator rows are stored non-temporally, second-level sweeps load their IR rows non-temporally
+  int stage_channels;       // sweeps and patches: this launch covers a SLICE of the channels of a stage of stage_channels of them (0: all of
+                            // them are in this launch): kernel form and cache policy are chosen for the whole stage, so slices agree
 };
 
 struct InvArgs {            // spectrum row(s) -> last B samples of the inverse transform (overlap-save)

@@ -2441,9 +2441,10 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
   }
   // a few recent partitions on top of a sweep row -- or, many channels: any short single-row sum (the streaming form:
   // 16 bytes per lane, all requests of a thread in flight at once; the row kernel below is built for the latency of a few)
-  if (a.M == 1 && a.P <= kPatchMax && (a.B % 2) == 0 && (a.Yadd != nullptr || (long long)channels * a.B >= (1ll << 18))) {
+  const long long nch_all = a.stage_channels > 0 ? a.stage_channels : channels;      // (a slice takes the form of the whole stage)
+  if (a.M == 1 && a.P <= kPatchMax && (a.B % 2) == 0 && (a.Yadd != nullptr || nch_all * a.B >= (1ll << 18))) {
     const dim3 grid((a.B + 511) / 512, channels), block(256);
-    const bool nt = launch_tune().patch_nt != 0 && (long long)channels * a.B >= (1ll << 20);    // (a few channels: rows stay in the L2 / MALL)
+    const bool nt = launch_tune().patch_nt != 0 && nch_all * a.B >= (1ll << 20);    // (a few channels: rows stay in the L2 / MALL)
     const int rot = (grid.x >= 8 && launch_tune().tile_rot) ? 1 : 0;
     if (a.tag == 0) { if (nt) RVC_LAUNCH((k_fdl_patch<0, true>), grid, block, 0, st, a, rot); else RVC_LAUNCH((k_fdl_patch<0, false>), grid, block, 0, st, a, rot); }
     else { if (nt) RVC_LAUNCH((k_fdl_patch<1, true>), grid, block, 0, st, a, rot); else RVC_LAUNCH((k_fdl_patch<1, false>), grid, block, 0, st, a, rot); }

@@ -94,8 +94,8 @@ rvc::FirArgs sweep1_args(rvc_set *s, bool tail, long long k0, long long x_hi) {
   r.k0 = k0; r.M = t.K1; r.x_hi = x_hi;
   return r;
 }
-// second level: blocks [g0, g0 + 8) of the tile that started at t0: first-level rows + the input rows t0 - L + 1 .. g0 - L
-// (L = stage_lag)
+// second level: blocks [g0, g0 + 8) of the tile that started at t0: first-level rows + the input rows the first-level sweep left
+// out, t0 - L - lag1 + 1 .. g0 - L - lag2 (L = stage_lag; lag1 / lag2: Tile, spread sweeps leave the newest row to the patches)
 rvc::FirArgs sweep2_args(rvc_set *s, bool tail, long long g0) {
   const Tile &t = tail ? s->tT : s->tA;
   const long long K = rvc::kSweepRows;
@@ -103,9 +103,9 @@ rvc::FirArgs sweep2_args(rvc_set *s, bool tail, long long g0) {
   r.Y = t.s2; r.y_chan_stride = K * r.B; r.y_row_mask = (unsigned)(K - 1);
   r.Ybase = t.s1; r.ybase_chan_stride = (long long)t.rows1 * r.B; r.ybase_row_mask = (unsigned)(t.rows1 - 1);
   const long long L = stage_lag(s, tail);
-  r.k0 = g0; r.M = (int)K; r.x_from = t.t0 - L + 1; r.x_hi = g0 - L;
-  // the oldest row that counts (t0 - L + 1) meets block g0 + 7 in partition g0 + 7 - delay - (t0 - L + 1)
-  r.P = (int)std::min<long long>(r.P, g0 - t.t0 + K - 1 + L - r.delay);
+  r.k0 = g0; r.M = (int)K; r.x_from = t.t0 - L - t.lag1 + 1; r.x_hi = g0 - L - t.lag2;
+  // the oldest row that counts (x_from) meets block g0 + 7 in partition g0 + 7 - delay - x_from
+  r.P = (int)std::min<long long>(r.P, g0 - t.t0 + K - 1 + L + t.lag1 - r.delay);
   return r;
 }
 // where the partial sums of block b live -- b inside the current first-level tile, and past its first group only once
@@ -160,6 +160,72 @@ bool ensure_tail_spectra(rvc_set *s, long long lo, hipStream_t st) {
   return true;
 }
 
+// ---- uniform call cost: spread sweeps -----------------------------------------------------------------------------------------
+// The reference moves the tail convolution to a background thread so that every process() call costs the same (src/dsp/
+// Convolver.cpp:84-95, TwoStageFFTConvolver.cpp:213-222). A time-tiled lock-step set without a second stream runs its tail job
+// inside the call that completes a tail block -- and with it, every K1-th / 8-th tail block, a first- / second-level sweep over the
+// WHOLE delay line: milliseconds in one call where the others take tens of microseconds. With Tile::lag1 / lag2 = 1 a sweep leaves
+// out the newest row that exists when its first block is due (the patches add that row's partition, one more each), so everything
+// it reads exists ONE TAIL PERIOD earlier: it is planned right behind the tail job of the block before (plan_next_tail_sweep) and
+// issued in channel slices behind the per-block launches of the period in between (issue_tail_slices, one slice per call, spaced
+// over the period); whatever is left when its first block is due is issued then (flush_tail_sweep: ragged call patterns).
+bool launch_sweep_slice(rvc_set *s, Tile &t, int count, hipStream_t st) {
+  Tile::Pending &q = t.pend;
+  while (q.on && count-- > 0) {
+    const int c0 = q.next, n = std::min(q.per, s->nch - c0);
+    rvc::FirArgs a = q.a;
+    a.H += (long long)c0 * a.h_chan_stride; a.X += (long long)c0 * a.x_chan_stride; a.Y += (long long)c0 * a.y_chan_stride;
+    if (a.Ybase) a.Ybase += (long long)c0 * a.ybase_chan_stride;
+    a.stage_channels = s->nch;
+    {
+      Timer tm(s, q.timer_id, st);
+      RVC_CK(rvc::launch_fdl_sweep(a, n, st));
+    }
+    q.next += n; ++q.issued;
+    if (q.next >= s->nch) q.on = false;
+  }
+  return true;
+}
+bool flush_tail_sweep(rvc_set *s, hipStream_t st) { return launch_sweep_slice(s, s->tT, 1 << 30, st); }
+// one per-block call has been enqueued: the slices that are due by now (evenly over the calls of a tail period but the last)
+bool issue_tail_slices(rvc_set *s) {
+  Tile::Pending &q = s->tT.pend;
+  if (!q.on) return true;
+  ++q.calls;
+  const long long due = ((long long)q.calls * q.slices + q.budget - 1) / q.budget;
+  return launch_sweep_slice(s, s->tT, (int)std::min<long long>(due, q.slices) - q.issued, s->st_main);
+}
+// calls of a tail period that can carry a slice: all but the one that completes the tail block (it carries the tail job)
+static int slice_budget(const rvc_set *s) {
+  return std::max(1, (int)std::max<long long>(1, (long long)s->T.B / (long long)s->A.B) - 1);
+}
+static int slice_channels(const rvc_set *s) {
+  const int want = std::max(1, std::min({slice_budget(s), 16, s->nch}));
+  return (s->nch + want - 1) / want;
+}
+int sweep_slices(const rvc_set *s) { const int per = slice_channels(s); return (s->nch + per - 1) / per; }
+void plan_sweep(rvc_set *s, Tile &t, const rvc::FirArgs &a, int timer_id) {
+  Tile::Pending &q = t.pend;
+  q = Tile::Pending();
+  q.on = true; q.a = a; q.timer_id = timer_id;
+  q.budget = slice_budget(s);
+  q.per = slice_channels(s);
+  q.slices = sweep_slices(s);
+}
+// behind the tail job of block m: the sweep block m + 1 will need, if it is a spread one
+void plan_next_tail_sweep(rvc_set *s, long long m) {
+  Tile &t = s->tT;
+  const long long next = m + 1, td = s->T.delay;
+  if (!t.holds(next)) {
+    if (!t.lag1) return;
+    t.start(next, t.K1);
+    plan_sweep(s, t, sweep1_args(s, true, next, next - td - t.lag1), 10);
+  } else if (t.K1 > rvc::kSweepRows && t.group(next) == next && t.s0 != next && t.lag2) {
+    plan_sweep(s, t, sweep2_args(s, true, next), 12);
+    t.s0 = next;
+  }
+}
+
 // Tail contributions (IR[2T,..), delivered T.delay tail blocks late) for output blocks
 // [tail_out_done, m_hi) into the time-indexed tail ring. Needs spectra of blocks < m_hi - T.delay.
 bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
@@ -175,37 +241,86 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
   r.Y = T.Y; r.y_chan_stride = (long long)T.mcap * tb;
   r.k0 = m_lo; r.M = (int)(m_hi - m_lo); r.P = T.P; r.delay = (int)td; r.B = (int)tb; r.tag = 1;
   const float2 *yrows = T.Y;                      // where the inverse transforms read the spectra
-  if (s->tT.on && r.M == 1) {
-    // block-synchronous streaming, time-tiled: output block m_lo either lies in the current tile -- then only the
-    // partitions whose input arrived after the (second-level) sweep are added to that sweep's row -- or starts a new tile
+  const bool tiled_row = s->tT.on && r.M == 1;
+  if (tiled_row && s->tT.G > 1) {
+    // Phase groups (Tile::G): every group of channels runs the schedule below on its own clock -- exactly one group is at the start
+    // of a second-level group or of a tile in any tail period, and sweeps over ITS channels only; every group patches at its own
+    // depth (a group whose sweep row is complete copies it) into T.Y, which ONE inverse launch then reads for all channels.
     Tile &t = s->tT;
-    if (t.t0 >= 0 && m_lo > t.t0 && m_lo < t.t0 + t.K1) {
+    for (int p = 0; p < t.G; ++p) {
+      const Tile::Phase &q = t.ph[p];
+      if (q.n <= 0) continue;
+      auto ranged = [&](rvc::FirArgs a) {            // the launch's share of the channels
+        a.H += (long long)q.c0 * a.h_chan_stride; a.X += (long long)q.c0 * a.x_chan_stride;
+        if (a.Y) a.Y += (long long)q.c0 * a.y_chan_stride;
+        if (a.Ybase) a.Ybase += (long long)q.c0 * a.ybase_chan_stride;
+        if (a.Yadd) a.Yadd += (long long)q.c0 * a.yadd_chan_stride;
+        a.stage_channels = s->nch;
+        return a;
+      };
+      t.load_phase(p);
+      if (!t.holds(m_lo)) {
+        const int len = t.fresh ? std::max(1, t.K1 - q.phi) : t.K1;
+        t.start(m_lo, len);
+        const rvc::FirArgs w = ranged(sweep1_args(s, true, m_lo, m_lo - td));
+        Timer tm(s, 10, st);
+        RVC_CK(rvc::launch_fdl_sweep(w, q.n, st));
+      }
       const long long g0 = t.group(m_lo);
-      if (g0 != t.t0 && t.s0 != g0) {              // entering the next group of 8: second-level sweep
-        const rvc::FirArgs w = sweep2_args(s, true, g0);
+      if (g0 != t.t0 && t.s0 != g0) {
+        const rvc::FirArgs w = ranged(sweep2_args(s, true, g0));
         Timer tm(s, 12, st);
-        RVC_CK(rvc::launch_fdl_sweep(w, s->nch, st));
+        RVC_CK(rvc::launch_fdl_sweep(w, q.n, st));
         t.s0 = g0;
       }
       long long stride = 0;
       const float2 *row = tile_row(s, true, m_lo, &stride);
-      const long long recent = m_lo - g0;          // input rows g0-td+1 .. m_lo-td came after the sweep
+      const long long recent = m_lo - g0;
       if (recent > 0) {
-        r.P = (int)std::min<long long>(recent, T.P);
-        r.Yadd = row; r.yadd_chan_stride = stride;
+        rvc::FirArgs f = r;
+        f.P = (int)std::min<long long>(recent, T.P);
+        f.Yadd = row; f.yadd_chan_stride = stride;
+        f = ranged(f);
         Timer tm(s, 5, st);
-        RVC_CK(rvc::launch_fir(r, s->nch, st));
-      } else {                                     // the group's first block: its sweep row is complete
-        yrows = row; r.y_chan_stride = stride;
+        RVC_CK(rvc::launch_fir(f, q.n, st));
+      } else {                                       // the group's first block: its sweep row is complete
+        RVC_CK(hipMemcpy2DAsync(T.Y + (long long)q.c0 * r.y_chan_stride, sizeof(float2) * (size_t)r.y_chan_stride,
+                                row + (long long)q.c0 * stride, sizeof(float2) * (size_t)stride, sizeof(float2) * (size_t)tb,
+                                (size_t)q.n, hipMemcpyDeviceToDevice, st));
       }
-    } else {
-      const rvc::FirArgs w = sweep1_args(s, true, m_lo, m_lo - td);  // (m_lo - td: the newest delay-line row that exists)
-      {
-        Timer tm(s, 10, st);
-        RVC_CK(rvc::launch_fdl_sweep(w, s->nch, st));
-      }
-      t.t0 = m_lo; t.s0 = -1;
-      yrows = tile_row(s, true, m_lo, &r.y_chan_stride);             // (row m_lo is complete)
+      t.store_phase(p);
+    }
+  } else if (tiled_row) {
+    // block-synchronous streaming, time-tiled: output block m_lo lies in the current tile -- whose sweeps have run, were spread over
+    // the calls since the block before, or run now -- and only the partitions whose input arrived after the (second-level) sweep
+    // are added to that sweep's row
+    Tile &t = s->tT;
+    if (!flush_tail_sweep(s, st)) return false;     // (whatever the calls in between did not carry)
+    if (!t.holds(m_lo)) {
+      const int len = (t.fresh && t.first_len > 0) ? std::min(t.first_len, t.K1) : t.K1;
+      t.start(m_lo, len);
+      const rvc::FirArgs w = sweep1_args(s, true, m_lo, m_lo - td - t.lag1);   // (m_lo - td: the newest delay-line row that exists)
+      Timer tm(s, 10, st);
+      RVC_CK(rvc::launch_fdl_sweep(w, s->nch, st));
+    }
+    const long long g0 = t.group(m_lo);
+    if (g0 != t.t0 && t.s0 != g0) {                // entering the next group of 8: second-level sweep
+      const rvc::FirArgs w = sweep2_args(s, true, g0);
+      Timer tm(s, 12, st);
+      RVC_CK(rvc::launch_fdl_sweep(w, s->nch, st));
+      t.s0 = g0;
+    }
+    long long stride = 0;
+    const float2 *row = tile_row(s, true, m_lo, &stride);
+    // input rows that came after the sweep: g0 - td - lag + 1 .. m_lo - td (lag: that of the sweep the row is from)
+    const long long recent = m_lo - g0 + (g0 == t.t0 ? t.lag1 : t.lag2);
+    if (recent > 0) {
+      r.P = (int)std::min<long long>(recent, T.P);
+      r.Yadd = row; r.yadd_chan_stride = stride;
+      Timer tm(s, 5, st);
+      RVC_CK(rvc::launch_fir(r, s->nch, st));
+    } else {                                       // the group's first block of an un-spread sweep: its row is complete
+      yrows = row; r.y_chan_stride = stride;
     }
   } else {
     s->tT.drop();                                  // several rows at once: plain delay line, any tile is dropped
@@ -223,6 +338,8 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
     RVC_CK(rvc::launch_fft_inv(T.logB, T.f64i, v, r.M, s->nch, st));
   }
   s->tail_out_done = m_hi;
+  // the next block's sweep, if a spread one is due: planned now (everything it reads exists), issued in slices by the calls to come
+  if (tiled_row && st == s->st_main && (s->tT.lag1 || s->tT.lag2)) plan_next_tail_sweep(s, m_lo);
   return true;
 }
 
@@ -351,7 +468,7 @@ bool run_head_sweep1(rvc_set *s, long long kb) {
     Timer t(s, 9, s->st_main);
     RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
   }
-  s->tA.t0 = kb; s->tA.s0 = -1;
+  s->tA.start(kb, s->tA.K1);
   s->ypre_block = kb;
   s->ypre_cur = tile_row(s, false, kb, &s->ypre_cur_stride);
   return true;
@@ -553,8 +670,9 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       if (!emit_output_copy(s)) return false;
     }
     s->xa_next = block_done ? k0 + 1 : k0;
-    // off the latency path: the tail job if a tail block just completed, and (two-launch scheme) the
-    // pre-multiplied accumulator of the next block if this one is complete
+    // off the latency path: this call's share of a spread tail sweep, the tail job if a tail block just completed, and (two-launch
+    // scheme) the pre-multiplied accumulator of the next block if this one is complete
+    if (has_tail && block_done && !issue_tail_slices(s)) return false;
     if (has_tail && !run_tail_job(s, n0, n1, nullptr, in_stride, bg)) return false;
     if (!s->fold && block_done && !run_premultiply(s, k0 + 1)) return false;
     mark_long_stage_stale(s, n1);
@@ -731,6 +849,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
     //  waited for by the next call's head stage, as the bg path does.)
     if (bg || (has_tail && T.delay < 1)) return fail(s, RVC_ERR_HIP, hipSuccess, "block_call: tail job must follow the head stage on st_main with delay >= 1");
     if (!head_stage(s, n0, n0, n1, src2, in_stride, d_out, out_stride, bg, n0)) return false;
+    if (has_tail && !issue_tail_slices(s)) return false;
     if (has_tail && !run_tail_job(s, n0, n1, nullptr, in_stride, bg)) return false;
     mark_long_stage_stale(s, n1);
     s->n = n1;

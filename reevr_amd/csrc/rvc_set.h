@@ -38,6 +38,16 @@ constexpr int kWidenMinPShort = 48;
 // noise that breaks the rule is the inverse transform's (its small outputs share a transform with outputs of 1.5e7) --; BASELINE
 // config 2 at 4096 channels: 17.06 (float) / 16.64 / 16.65 (inverse: -2.4 %) / 16.15 (both) Gsamples/s.
 constexpr int kMix64Default = 2;
+// Spread tail sweeps (Tile::lag1 / lag2; rvc_schedule.cpp "uniform call cost"): lock-step sets of at least kSpreadMinChannels channels
+// without a second stream issue the tail stage's sweeps a tail period early, in channel slices behind the per-block launches.
+// kSpreadDefault: bit 0 first-level sweeps, bit 1 second-level sweeps. Measured on MI355X: profiles/r6_spread.txt
+constexpr int kSpreadMinChannels = 256;
+constexpr int kSpreadDefault = 0;
+constexpr bool kKidStaggerDefault = false;
+// Phase groups of the tail tiles of such sets (Tile::G). Measured on MI355X (profiles/r6_call_cost.txt), BASELINE config 2 at 4096
+// channels, cost of the worst per-block call / rate: in phase 8.6 ms / 18.26 Gsamples/s; 2 groups 4.6 / 18.20; 4: 3.0 / 18.40;
+// 8: 1.8 ms / 18.21 -- against spread sweeps: first level 3.8 / 17.88, both levels 1.3 ms / 17.10 (a partition more per patch)
+constexpr int kPhasesDefault = 8;
 
 inline size_t next_pow2(size_t v) {   // Utilities.h:280-289
   size_t p = 1;
@@ -88,10 +98,46 @@ struct Tile {
   int K1 = rvc::kSweepRows;      // blocks per first-level tile: 8 (one level), 16 or 32
   int rows1 = rvc::kSweepRows;   // rows of s1 per channel (= K1)
   float2 *s1 = nullptr, *s2 = nullptr;   // [nch][rows1][B], [nch][kSweepRows][B]
-  long long t0 = -1;             // blocks [t0, t0 + K1) have first-level rows; -1: none
+  long long t0 = -1;             // blocks [t0, end) have first-level rows; -1: none
+  long long end = -1;            // t0 + K1 -- less for the FIRST tile after the clock (re)starts of a child set (first_len)
   long long s0 = -1;             // blocks [s0, s0 + kSweepRows), s0 > t0, have second-level rows; -1: none
-  void drop() { t0 = s0 = -1; }
-  // start of the kSweepRows-block group of the current tile that block b (t0 <= b < t0 + K1) lies in
+  // Spread sweeps (tail stage of many-channel sets, rvc_schedule.cpp "Uniform call cost"): a sweep with lag 1 leaves out the newest
+  // row that exists when its first block is due (x_hi one older; the patches add one more partition), so it can be issued ONE
+  // TAIL PERIOD EARLIER -- in channel slices behind the per-block launches of that period instead of inside the one call that
+  // completes the tail block. lag1: first-level sweeps, lag2: second-level sweeps.
+  int lag1 = 0, lag2 = 0;
+  int first_len = 0;             // length of the first tile after init / clear() (0 = K1): the children of a set start their tiles
+                                 // out of phase, so that their un-spread sweeps fall into different calls
+  bool fresh = true;             // no tile since init / clear() yet
+  struct Pending {               // a spread sweep, partly issued: channels [next, nch) are still to be launched
+    bool on = false;
+    rvc::FirArgs a{};
+    int timer_id = 0;
+    int next = 0, per = 0, calls = 0, slices = 0, issued = 0, budget = 0;
+  } pend;
+  // Phase groups (tail stage of many-channel sets, rvc_schedule.cpp "uniform call cost"): the channels of the set are dealt to G
+  // groups whose tiles are OUT OF PHASE -- group p's first tile after init / clear() is phi[p] blocks short, and the phi are
+  // distinct modulo 8 --, so in every tail period exactly one group is at the start of a second-level group (or of a tile) and runs
+  // its sweep over 1 / G of the channels, and every group patches at its own depth: no call carries a sweep over the whole set.
+  // Same sums per channel (the association of a channel's partial sums depends on its group's phase: channels of different groups
+  // agree to the last bit or two, channels of one group bit for bit). t0 / end / s0 above are the CURRENT group's while tail_rows
+  // works on it (load_phase / store_phase); the zero-latency stage has one group and uses them directly.
+  static constexpr int kMaxPhases = 8;
+  int G = 1;
+  struct Phase { long long t0 = -1, end = -1, s0 = -1; bool fresh = true; int phi = 0; int c0 = 0, n = 0; } ph[kMaxPhases];
+  void load_phase(int p) { t0 = ph[p].t0; end = ph[p].end; s0 = ph[p].s0; fresh = ph[p].fresh; }
+  void store_phase(int p) { ph[p].t0 = t0; ph[p].end = end; ph[p].s0 = s0; ph[p].fresh = fresh; }
+  void start(long long b, int len) { t0 = b; end = b + len; s0 = -1; fresh = false; }
+  void drop() {
+    t0 = s0 = end = -1; pend.on = false;
+    for (Phase &q : ph) q.t0 = q.s0 = q.end = -1;
+  }
+  void restart() {                              // init / clear(): the next tile is a first tile again
+    drop(); fresh = true;
+    for (Phase &q : ph) q.fresh = true;
+  }
+  bool holds(long long b) const { return t0 >= 0 && b >= t0 && b < end; }
+  // start of the kSweepRows-block group of the current tile that block b (t0 <= b < end) lies in
   long long group(long long b) const { return t0 + (b - t0) / rvc::kSweepRows * rvc::kSweepRows; }
 };
 
@@ -111,6 +157,10 @@ struct Tuning {
                           // (rounds 2-4) instead of handing THIS block's over through LDS
   int mix64 = -1;         // "mix64": sets of more than 8 channels, stages with partitions of 2048 .. 8192 samples: -1 default (kMix64Default),
                           // 0 float transforms, 1 forward in double, 2 inverse in double, 3 both (= RVC_FLAG_FFT_F64_LONG)
+  int tail_spread = -1;   // "tail_spread": sweeps of the tail stage issued a tail period early in channel slices behind the per-block
+                          // launches (Tile::lag1 / lag2): -1 by size, else bit 0 the first-level sweeps, bit 1 the second-level ones
+  int kid_stagger = -1;   // "kid_stagger": child k of n starts its tail tiles k * 8 / n blocks out of phase: -1 default / 0 off / 1 on
+  int tail_phases = -1;   // "tail_phases": phase groups of the tail stage's tiles (Tile::G): -1 by size, else 1 (none) .. 8
   rvc::LaunchTune launch; // kernel variants the launchers choose between (rvc_internal.h)
 };
 
@@ -148,6 +198,7 @@ struct rvc_set {
   int nch = 0;
   int plan_nch = 0;              // child sets: the channel count of the WHOLE set -- the stage plan (delay-1 tail, transform
                                  // precision) is the parent's, whatever share of the channels a child serves; 0 for a set of its own
+  int kid_index = 0, kid_count = 1;   // child sets: which of how many (their tail tiles start out of phase, Tile::first_len)
   int device = 0;
   unsigned flags = 0;
   Tuning tune;                   // this set's measurement knobs (fixed at create)
@@ -286,6 +337,7 @@ bool fence_children_in(rvc_set *s, bool explicit_call = false);
 bool fence_children_out(rvc_set *s, bool explicit_call = false);
 void forward_device_call(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, size_t out_stride, size_t len);
 bool zero_device_out(rvc_set *s, float *d_out, size_t out_stride, size_t len);
+int sweep_slices(const rvc_set *s);      // launches a spread tail sweep of this set is cut into
 
 // Announces the set's kernel variants to the launchers of this thread for the duration of an entry point.
 struct TuneScope {

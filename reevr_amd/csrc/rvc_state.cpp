@@ -390,7 +390,7 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     if (pf > 0 && !upload_ir_stage(s, s->T, irs, len, on_device)) { free_device_state(s); return false; }
     if (pw > 0 && !upload_ir_stage(s, s->W, irs, len, on_device)) { free_device_state(s); return false; }
     s->n = 0; s->tail_fft_done = 0; s->tail_out_done = td; s->xa_next = 0; s->ypre_block = -1;
-    s->w_next = 0; s->xt_valid_lo = 0; s->tA.drop(); s->tT.drop();
+    s->w_next = 0; s->xt_valid_lo = 0; s->tA.restart(); s->tT.restart();
     return true;
   }
 
@@ -480,6 +480,31 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
       if (tT.K1 > (int)K) RVC_CK(dev_alloc(s, &tT.s2, sizeof(float2) * (size_t)s->nch * K * T.B));
     }
   }
+  // Spread tail sweeps (rvc_schedule.cpp "uniform call cost"): sets whose tail job runs on their own stream; knob "tail_spread"
+  {
+    Tile &tT = s->tT;
+    const int nch_all = s->plan_nch ? s->plan_nch : s->nch;
+    const bool can = tT.on && (s->flags & RVC_FLAG_BG_STREAM) == 0;
+    const int spread = s->tune.tail_spread >= 0 ? s->tune.tail_spread : (nch_all >= kSpreadMinChannels ? kSpreadDefault : 0);
+    tT.lag1 = (can && (spread & 1)) ? 1 : 0;
+    tT.lag2 = (can && (spread & 2) && tT.K1 > rvc::kSweepRows) ? 1 : 0;
+    const bool stagger = s->tune.kid_stagger >= 0 ? s->tune.kid_stagger != 0 : kKidStaggerDefault;
+    tT.first_len = (can && stagger && s->kid_count > 1) ? std::max(1, tT.K1 - s->kid_index * rvc::kSweepRows / s->kid_count) : 0;
+    // phase groups: G contiguous channel ranges; group p's first tile is phi[p] = p + 8 (p mod K1/8) blocks short (distinct modulo
+    // 8: one group per patch depth; spread over the K1 blocks of a tile: one first-level sweep every K1 / G periods)
+    int G = s->tune.tail_phases >= 0 ? s->tune.tail_phases : (nch_all >= kSpreadMinChannels ? kPhasesDefault : 1);
+    G = std::max(1, std::min({G, Tile::kMaxPhases, s->nch}));
+    if (!tT.on || tT.lag1 || tT.lag2) G = 1;               // (spread sweeps and phase groups are alternatives)
+    tT.G = G;
+    for (int p = 0; p < G; ++p) {
+      Tile::Phase &q = tT.ph[p];
+      q = Tile::Phase();
+      q.c0 = (int)((long long)s->nch * p / G);
+      q.n = (int)((long long)s->nch * (p + 1) / G) - q.c0;
+      // (+ 2 per child set: the children's first-level sweeps -- one group's every K1 / G periods -- fall into different periods)
+      q.phi = G > 1 ? (p * rvc::kSweepRows / G + rvc::kSweepRows * (p % std::max(1, tT.K1 / rvc::kSweepRows)) + 2 * s->kid_index) % tT.K1 : 0;
+    }
+  }
   s->same_block = s->tA.on && rvc::fused_same_block(A.logB) && s->tune.same_block != 0;
   RVC_CK(dev_alloc(s, &s->d_in, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(dev_alloc(s, &s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
@@ -540,6 +565,7 @@ bool make_kids(rvc_set *s, int n) {
     c->is_kid = true;
     c->tune = s->tune;
     c->plan_nch = s->nch;
+    c->kid_index = k; c->kid_count = n;
     s->kids.push_back(c);
     s->kid_c0.push_back(c0);
     c0 += mine;

@@ -607,10 +607,11 @@ static void launch_lds_variant(const FirArgs &a, int channels, hipStream_t st) {
 
 template <int STAGE>
 static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
+  const int nch_all = a.stage_channels > 0 ? a.stage_channels : channels;   // (a slice takes the form of the whole sweep)
   // Partition-split form: few waves otherwise (a stereo pair's tail stage: 2 x 64 tiles of 128 bins), and large rows with
   // many partitions (the tail stage: measured 10 % faster there on MI355X, 15 % slower on 512-bin rows). Not for second-
   // level sweeps and long tiles: every wave of the split form reads K rows of window besides its share of the partitions.
-  const long long waves1 = (long long)((a.B + 127) / 128) * channels;
+  const long long waves1 = (long long)((a.B + 127) / 128) * nch_all;
   bool split = a.M == kSweepRows && a.Ybase == nullptr && (waves1 < 2048 || a.B >= 2048);
   if (a.M > kSweepRows) split = false;      // (long tiles: every wave of the split form reads K window rows besides its share)
   else if (launch_tune().sweep_split >= 0) split = launch_tune().sweep_split != 0;
@@ -672,7 +673,7 @@ hipError_t launch_fdl_sweep(const FirArgs &a0, int channels, hipStream_t st) {
   // set stream (non-temporal row stores / second-level IR loads: +2-4 % / +4-10 %), config 2's and 3's heads (134 MB per child,
   // 268 MB on one queue) do not (config 3's second-level head sweeps lost 3 % streaming). profiles/r5_sweep_nt.txt
   FirArgs a = a0;
-  a.stream = (long long)channels * a.h_chan_stride * (long long)sizeof(float2) >= (512ll << 20) ? 1 : 0;
+  a.stream = (long long)(a.stage_channels > 0 ? a.stage_channels : channels) * a.h_chan_stride * (long long)sizeof(float2) >= (512ll << 20) ? 1 : 0;
   if (launch_tune().sweep_nt >= 0) a.stream = launch_tune().sweep_nt;
   if (a.tag == 0) launch_stage<0>(a, channels, st);
   else launch_stage<1>(a, channels, st);

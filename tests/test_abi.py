@@ -37,7 +37,7 @@ def test_header_symbols_all_exported(lib):
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
     # rvc.h is the reference's surface plus the set API: no measurement / development entry in it
-    dbg = lambda n: n.startswith("rvc_debug_") or n.endswith("_timed") or n.endswith("_tuned")
+    dbg = lambda n: n.startswith("rvc_debug_") or n.endswith("_timed") or n.endswith("_tuned") or n.endswith("_stamped")
     assert not [n for n in declared_symbols(HEADER) if dbg(n)]
     assert all(dbg(n) for n in declared_symbols(DEBUG_HEADER))
 

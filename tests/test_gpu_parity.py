@@ -686,12 +686,22 @@ def test_fuzz_geometry_and_call_pattern(seed, tiling):
                                   f"bg {bg} fixed {fixed} clear {clear_at}: rel rms {err / ref:.3e}")
 
 
-@pytest.mark.parametrize("tiling", [True, False, "force", "force2", "force2_k32", "widen", "shrink_force2"])
+@pytest.mark.parametrize("tiling", [True, False, "force", "force2", "force2_k32", "widen", "shrink_force2",
+                                    "spread1_force2_k32", "spread3_force2", "spread3_shrink_force2", "spread3_widen", "spread2_force2_k32",
+                                    "phases_force2_k32", "phases_force2", "phases_shrink_force2", "phases_widen", "phases_force"])
 @pytest.mark.parametrize("seed", list(range(24)) + [226])   # 226: 3 tail partitions on 4 sweep waves (a wave without work)
 def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     """The plug-in's calling pattern -- one call per host block, now and then a ragged one, several calls inside one
     block, a multi-block call or a block-aligned clear() -- over many sweep tiles (8 blocks each), with the causal
-    time tiling off, on by size (default) and forced: every output sample against the oracle."""
+    time tiling off, on by size (default) and forced: every output sample against the oracle.
+    spreadN_*: the tail stage's sweeps issued a tail period early in channel slices behind the per-block calls (knob
+    tail_spread = N: bit 0 first-level, bit 1 second-level sweeps; what sets of >= 256 channels run by default) on top of the
+    named tiling mode -- planned sweeps meeting ragged calls, multi-block calls (which drop them) and clear()."""
+    spread = phases = 0
+    if str(tiling).startswith("spread"):
+        spread, tiling = int(tiling[6]), tiling[8:]
+    elif str(tiling).startswith("phases_"):      # the tail tiles in channel groups out of phase (tail_phases; one group per channel here)
+        phases, tiling = 8, tiling[7:]
     rng = np.random.RandomState(4200 + seed)
     head = int(rng.choice([64, 128, 256, 512]))
     tail = int(rng.choice([2 * head, 4 * head, 16 * head]))
@@ -723,9 +733,15 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     if slack > 0:
         bg = False
         tiling = "force" if slack == 1 else "force2"
-    with reevr_amd.tuning(k1=32 if tiling == "force2_k32" else 0, tail_slack=slack):   # (k1 = 32: first-level tiles of 32 blocks)
+    if spread:
+        bg = False                                               # (a tail job on the second stream is never spread)
+    with reevr_amd.tuning(k1=32 if tiling == "force2_k32" else 0, tail_slack=slack, tail_spread=spread, tail_phases=phases or -1):   # (k1 = 32: first-level tiles of 32 blocks)
         s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling="force2" if tiling == "force2_k32" else tiling, fft_f32=slack > 0)
         assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
+    if spread and s.tile_rows(1):
+        assert s.plan()["tail_spread"] == (spread if s.tile_rows(1) > 8 else spread & 1)
+    if phases and s.tile_rows(1):
+        assert s.plan()["tail_phase_groups"] == min(nch, 8)
     if slack == 1:
         assert s.tail_block == 2 * tail and s.partitions(0) == 2 * tail // head
     elif slack == 2:
@@ -791,12 +807,17 @@ def test_fuzz_child_sets_call_patterns(seed):
         done += n
     bg = bool(rng.randint(0, 2))
     tiling = ["force", "force2", True][seed % 3]
+    # every other seed: spread tail sweeps (tail_spread 1 / 3) with the children's tiles out of phase (kid_stagger)
+    spread = [0, 3, 0, 1][seed % 4]
+    phases = [0, 0, 4, 0][seed % 4]           # seeds 2, 6: the tail tiles of each child in channel groups out of phase
+    if spread:
+        bg = False
     x = np.stack([synth.synth_input(total, 13 * seed + c) for c in range(nch)])
     dx = torch.from_numpy(x).cuda()
     clear_at = int(rng.randint(len(sched) // 4, len(sched))) if rng.randint(0, 2) == 0 else -1
     outs, start = [], 0
     for kids in (2, 1):
-        with reevr_amd.tuning(subsets=kids):
+        with reevr_amd.tuning(subsets=kids, tail_spread=spread, kid_stagger=1 if spread else -1, tail_phases=phases or -1):
             s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling=tiling)
             assert s.init(head, tail, irs, max_len=max(n for n, _ in sched)), s.last_error_string
         assert s.subsets == kids

@@ -44,22 +44,39 @@ def assert_bench_plan(s, cfg):
     assert not diff, f"config {cfg}: plan differs from bench.HEADLINE_PLANS (got, want): {diff}"
 
 
-def run_lockstep(nch, cfg, irs, xs, period, nblk, host_block, tail, subsets, check):
+def run_lockstep(nch, cfg, irs, xs, period, nblk, host_block, tail, subsets, check, tune=None, stamped=False):
     """nch lock-step channels, channel c = (irs[c % period], xs[c % period]), one process() per host block through the device
     entry; returns the output rows of `check` (host) after asserting that every channel equals its twin c % period bit for bit"""
     import torch
     full_irs = [irs[c % period] for c in range(nch)]
     dx = torch.from_numpy(np.stack(xs)).cuda().repeat(nch // period, 1)     # row c = xs[c % period]
-    s = reevr_amd.ConvolverSet(nch, tune=dict(subsets=subsets))
+    s = reevr_amd.ConvolverSet(nch, tune=dict(tune or {}, subsets=subsets))
     ok = s.init(host_block, tail, full_irs, max_len=host_block) if tail else s.init_uniform(host_block, full_irs, max_len=host_block)
     assert ok, s.last_error_string
-    assert_bench_plan(s, cfg)
-    dy = s.process_device_blocks(dx, host_block)
+    if tune is None:
+        assert_bench_plan(s, cfg)
+    if stamped:                                           # (the loop with a completion stamp behind every call: same samples)
+        dy, done = s.process_device_blocks_stamped(dx, host_block)
+        assert len(done) == nblk and np.all(np.diff(done) >= 0) and done[0] > 0
+    else:
+        dy = s.process_device_blocks(dx, host_block)
     assert s.last_error == 0, s.last_error_string
+    s_plan = s.plan()
     s.close()
     assert bool(torch.isfinite(dy).all())
-    twins = dy.view(nch // period, period, -1)
-    assert bool((twins == twins[0:1]).all()), "channels with the same IR and input differ"
+    # twins: bit for bit inside one child set's phase group (children / phase groups run their tiles out of phase: the partial
+    # sums of a channel are associated by its group's phase -- agreement to the last bits across groups, checked against the oracle)
+    pl = s_plan
+    parts = subsets * max(1, pl["tail_phase_groups"])
+    if nch % (parts * period) == 0 and (pl["tail_phase_groups"] > 1 or (tune or {}).get("kid_stagger", 0) > 0):
+        twins = dy.view(parts, nch // parts // period, period, -1)
+        assert bool((twins == twins[:, 0:1]).all()), "channels with the same IR and input in one phase group differ"
+        first = twins[:, 0].double()
+        dev = float(((first - first[0:1]) ** 2).mean().sqrt() / (first[0:1] ** 2).mean().sqrt())
+        assert dev <= 2e-6, dev
+    else:
+        twins = dy.view(nch // period, period, -1)
+        assert bool((twins == twins[0:1]).all()), "channels with the same IR and input differ"
     got = {c: dy[c].cpu().numpy() for c in check}
     del dx, dy, twins
     torch.cuda.empty_cache()
@@ -86,6 +103,27 @@ def test_config2_plan_steady_state_vs_oracle():
         # ... and over the last first-level tile alone (the steady state must not hide behind the louder start)
         lo = 65 * tail
         assert rel_rms(got[c][lo:], want[lo:]) <= TOL, c
+
+
+@pytest.mark.parametrize("spread,stagger,phases", [(1, 0, 1), (3, 1, 1), (2, 1, 1), (0, 0, 8), (0, 0, 4)])
+def test_config2_geometry_spread_tail_sweeps_vs_oracle(spread, stagger, phases):
+    """The same set with the tail stage's sweeps SPREAD (knob tail_spread: bit 0 the 32-block first-level sweeps, bit 1 the
+    second-level ones: issued a tail period early in 15 channel slices behind the per-block launches, their newest row left to
+    the patches) and the two children's tiles out of phase (kid_stagger), or -- tail_phases -- its tiles run in 8 / 4 channel groups
+    out of phase with each other: no call carries a sweep over the whole set -- the reference's reason for its background
+    thread, Convolver.cpp:84-95. 512 channels, through the stamped loop, against the oracle."""
+    nch, head, tail, nblk, period = 512, 512, 8192, 1600, 8
+    base = [synth.synth_ir(480000, 2, inst=i) for i in range(4)]
+    irs = [base[(c // 2) % 4][c % 2] for c in range(period)]
+    xs = [synth.synth_input(head * nblk, 90 + i) for i in range(period)]
+    check = (0, 1, 255, 256, 300, 511)
+    got = run_lockstep(nch, 2, irs, xs, period, nblk, head, tail, 2, check, tune=dict(tail_spread=spread, kid_stagger=stagger, tail_phases=phases), stamped=True)
+    for c in check:
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c % period])
+        want = o.process(xs[c % period])
+        assert rel_rms(got[c], want) <= TOL, c
+        assert rel_rms(got[c][65 * tail:], want[65 * tail:]) <= TOL, c
 
 
 def test_config1_plan_steady_state_vs_oracle():
@@ -163,6 +201,7 @@ def test_lockstep_4096_channels_impulse_identity_past_the_ir():
     dx[:, at] = 1.0
     dy = s.process_device_blocks(dx, head)
     assert s.last_error == 0, s.last_error_string
+    s_subsets, s_phases = s.subsets, max(1, s.plan()["tail_phase_groups"])
     s.close()
     for c in range(8):                                   # 8 distinct (IR, channel) combinations, cycled
         ref = dy[c]
@@ -175,5 +214,11 @@ def test_lockstep_4096_channels_impulse_identity_past_the_ir():
         # the last tail partition alone (the part of the IR only a FULL-length run reaches)
         lo = at + 57 * tail + tail
         assert np.sqrt(np.mean((got[lo:] - want[lo:]) ** 2)) <= 1e-7, c
-        same = dy[c::8]
-        assert bool((same == ref.unsqueeze(0)).all()), c
+        # channels c, c + 8, ..: bit for bit inside one phase group of one child set (each group runs its tiles on its own phase and
+        # associates its partial sums accordingly), every group against the impulse response
+        groups = s_subsets * s_phases
+        same = dy[c::8].view(groups, nch // 8 // groups, n)
+        assert bool((same == same[:, 0:1]).all()), c
+        heads = same[:, 0].cpu().numpy().astype(np.float64)
+        for g in range(groups):
+            assert np.sqrt(np.mean((heads[g] - want) ** 2)) <= 1e-7, (c, g)

@@ -23,7 +23,8 @@ def main():
                 full = json.load(open(tf.name))
                 fam = {k: [round(v["avg_launch_ms"], 4), v["frac"], v.get("frac_per_launch")] for k, v in (full.get("roofline_all") or {}).items()}
                 rec = {"spec": spec, "value": full["value"], "ms_per_step": full["ms_per_step"], "probe": (full.get("probe") or {}).get("rms_error"),
-                       "subsets": full["config"]["subsets"], "families[avg_ms, frac(union), frac_per_launch]": fam}
+                       "subsets": full["config"]["subsets"],
+                       "call_us[p50,p99,max]": [(full.get("call_us") or {}).get(k) for k in ("p50", "p99", "max")], "families[avg_ms, frac(union), frac_per_launch]": fam}
         print(json.dumps(rec), flush=True)
         with open(out, "a") as f:
             f.write(json.dumps(rec) + "\n")
