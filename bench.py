@@ -883,6 +883,11 @@ def main():
     ap.add_argument("--watchdog", type=float, default=1500.0,
                     help="seconds after which a stuck run dumps every thread's stack and exits (0: off)")
     args = ap.parse_args()
+    wall0 = time.perf_counter()
+    wall = {}
+
+    def lap(name):                 # wall-clock seconds since the start of main() at the end of each phase (full record: `wall_s`)
+        wall[name] = round(time.perf_counter() - wall0, 1)
     if args.watchdog > 0:          # a hung collective or kernel must not hold the GPU box until the driver's limit
         import faulthandler
         faulthandler.dump_traceback_later(args.watchdog, exit=True)
@@ -995,6 +1000,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    lap("import_synth_init")
     # the plan this set runs against the one the steady-state parity tests cover (None = the same; literal config 5: no table entry)
     plan_diff = None if long_call else plan_as_tested(conv, wcfg)
     pre = ls.preroll()
@@ -1033,6 +1039,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    lap("timed_run")
     # ---- per-kernel durations, live, with HIP events on the streams the kernels run on ----
     kern = ls.kernel_times(KERNEL_NAMES)
     call_us = ls.call_latency() if (not long_call and world == 1) else None     # cost of each per-block call, stamped on the device
@@ -1151,14 +1158,17 @@ def main():
             bgl.close()
         if args.config == 2:
             side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
+    lap("side_legs")
     if world == 1 and args.cpu_seconds > 0 and lockstep_cfg:
         cores = os.cpu_count() or 1
         n_cpu_irs = min(len(irs), max(2, cores))
         xin = [np.ascontiguousarray(x[1 + c % (nch - 1)]) for c in range(n_cpu_irs)]          # (channel 0 carries the probe)
         cpu = cpu_baseline(irs[:n_cpu_irs], xin, host_block, tail, args.cpu_seconds, WORKLOADS[wcfg]["text"])
+    lap("cpu_baseline")
     regimes = None
     if args.config == 2 and world == 1 and args.side and args.regimes:
         regimes = small_regimes(torch, reevr_amd, synth, KERNEL_NAMES, local_rank, 4, irs4096=irs, x4096=x, instances=instances)
+    lap("regimes")
     if args.config == 2 and world == 1 and args.side:
         del irs, x
         for c in [int(v) for v in args.configs.split(",") if v.strip()]:
@@ -1166,6 +1176,7 @@ def main():
                 others["config%d" % c] = side_config(torch, reevr_amd, synth, KERNEL_NAMES, c, WORKLOADS[c]["channels"],
                                                      local_rank, args.config_steps, args.config_cpu_seconds)
 
+    lap("other_configs")
     # Compact scalar summary of everything the line holds elsewhere in nested form (the driver keeps the scalar entries of
     # `config` / `roofline`): per side configuration its rate, executed-bytes fraction of the HBM peak, SURVEY 8d fraction of
     # the reference-order run and 1-thread CPU rate; the small regimes; the one-queue run.
@@ -1252,7 +1263,7 @@ def main():
         "summary": summary,
         "cpu_baseline": cpu,
         **others,
-        "init_ms": round(init_ms, 2), "synth_s": round(synth_s, 2),
+        "init_ms": round(init_ms, 2), "synth_s": round(synth_s, 2), "wall_s": wall,
     }
     full["config"]["devices"] = devices
     full["config"]["shared_device"] = same_device

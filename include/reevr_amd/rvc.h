@@ -169,6 +169,14 @@ void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size
 void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len);
 void rvc_set_process_end(rvc_set *s, float *const *out);
 
+/* The set's own pinned staging rows, one per channel (valid after a successful init with non-empty impulses until the next init /
+ * reset / destroy; max_len floats each): a host that produces its audio straight into in[c] and consumes it from out[c] -- and
+ * passes exactly these pointers to rvc_set_process / _begin / _end -- skips the copy into and out of pinned memory that the
+ * host-pointer calls otherwise make (TwoStageFFTConvolver::process takes caller-owned buffers, TwoStageFFTConvolver.h:65-83: the
+ * reference has no such notion; for hosts with hundreds of channels the staging copy is most of a call). Either array may be
+ * NULL. out[c] holds the call's output from the return of rvc_set_process / _end until the next call. 1 = filled. */
+int rvc_set_host_buffers(rvc_set *s, float **in, float **out);
+
 /* Same, with DEVICE-resident buffers: channel c reads d_in + c*in_stride and writes
  * d_out + c*out_stride (strides in floats). Asynchronous on the set's stream
  * (rvc_set_stream, a non-blocking stream: it does not synchronise with the null stream): d_in must

@@ -40,6 +40,7 @@ SIGNATURES = {
     "rvc_set_process_device": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]),
     "rvc_set_process_device_blocks": (None, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
                                              C.c_size_t]),
+    "rvc_set_host_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "rvc_set_process_host_blocks_timed": (None, [C.c_void_p, F32PP, F32PP, C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]),
     "rvc_set_process_device_blocks_stamped": (C.c_long, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t,
                                                           C.POINTER(C.c_double)]),

@@ -120,6 +120,23 @@ class ConvolverSet:
         self._lib.rvc_set_process(self._h, ins, outs, n)
         return out
 
+    def host_buffers(self):
+        """(inputs, outputs): float32 views (n_channels rows of max_len) of the set's own pinned staging rows
+        (rvc_set_host_buffers). process_in_place(n) runs a call on the first n frames of `inputs` and leaves the result in the
+        first n frames of `outputs` -- no copy into or out of pinned memory."""
+        n, ml = self.n_channels, self.max_len
+        ins, outs = (C.c_void_p * n)(), (C.c_void_p * n)()
+        if not self._lib.rvc_set_host_buffers(self._h, ins, outs):
+            raise RvcError("rvc_set_host_buffers: the set is not initialised")
+        self._stage_ptrs = (ins, outs)
+        view = lambda p: np.ctypeslib.as_array(C.cast(p, L.F32P), shape=(ml,))
+        return [view(p) for p in ins], [view(p) for p in outs]
+
+    def process_in_place(self, n: int):
+        """One call of n <= max_len frames on the staging rows of host_buffers() (call that first)."""
+        ins, outs = self._stage_ptrs
+        self._lib.rvc_set_process(self._h, C.cast(ins, L.F32PP), C.cast(outs, L.F32PP), n)
+
     def process_host_blocks_timed(self, x: np.ndarray, block: int):
         """x: (n_channels, len) host array fed through process() in calls of `block` frames, all in C.
         Returns (output, per-call durations in microseconds)."""

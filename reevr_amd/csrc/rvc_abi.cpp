@@ -9,11 +9,93 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <thread>
 
 #include "rvc_set.h"
+
+// Staging of many channels: the caller's per-channel buffers are copied into / out of the pinned staging rows by a few host
+// threads (one thread moves ~15 GB/s: 0.55 ms each way for 4096 channels of 512 frames, more than the kernels of the call). One
+// process-wide crew, started on first use; a call that finds it busy (another handle on another thread) copies inline -- nobody
+// ever waits for it. Small sets (the plug-in's 2-4 channels) never touch it. (Callers that can write their audio into the staging
+// rows themselves -- rvc_set_host_buffers -- skip the copy altogether.)
+namespace {
+struct CopyCrew {
+  std::mutex busy;                       // one job at a time (try_lock: never waited for)
+  std::mutex m;
+  std::condition_variable wake, done;
+  std::vector<std::thread> workers;
+  const std::function<void(int)> *job = nullptr;
+  int next = 0, count = 0, active = 0;
+  unsigned long long epoch = 0;
+  bool stop = false;
+  void worker() {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      wake.wait(lk, [&] { return stop || epoch != seen; });
+      if (stop) return;
+      seen = epoch;
+      ++active;
+      while (next < count) {
+        const int i = next++;
+        lk.unlock();
+        (*job)(i);
+        lk.lock();
+      }
+      if (--active == 0) done.notify_all();
+    }
+  }
+  void start(int n) {
+    for (int i = 0; i < n; ++i) workers.emplace_back([this] { worker(); });
+  }
+  ~CopyCrew() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    wake.notify_all();
+    for (std::thread &t : workers) t.join();
+  }
+  // f(i) for i < n, the calling thread included
+  void run(int n, const std::function<void(int)> &f) {
+    if (n <= 1 || !busy.try_lock()) { for (int i = 0; i < n; ++i) f(i); return; }
+    if (workers.empty()) start(std::max(1, std::min(7, (int)std::thread::hardware_concurrency() / 2 - 1)));
+    std::unique_lock<std::mutex> lk(m);
+    job = &f; next = 0; count = n; ++epoch;
+    wake.notify_all();
+    while (next < count) {
+      const int i = next++;
+      lk.unlock();
+      f(i);
+      lk.lock();
+    }
+    done.wait(lk, [&] { return active == 0; });
+    job = nullptr;
+    lk.unlock();
+    busy.unlock();
+  }
+};
+CopyCrew &copy_crew() { static CopyCrew c; return c; }
+constexpr size_t kCrewMinBytes = (size_t)1 << 20;   // below this one thread is faster than waking the crew
+
+// rows [0, nch) of `len` floats between the caller's per-channel buffers and the staging rows (max_len apart); a caller's pointer
+// that IS the staging row (rvc_set_host_buffers) is skipped
+void stage_rows(rvc_set *s, const float *const *in, float *const *out, size_t len) {
+  const size_t bytes = len * sizeof(float);
+  auto one = [&](int c) {
+    float *row = (in ? s->h_in : s->h_out) + (size_t)c * s->max_len;
+    if (in) { if (in[c] != row) std::memcpy(row, in[c], bytes); }
+    else if (out[c] && out[c] != row) std::memcpy(out[c], row, bytes);
+  };
+  if ((size_t)s->nch * bytes < kCrewMinBytes) { for (int c = 0; c < s->nch; ++c) one(c); return; }
+  const int chunks = std::min(s->nch, 32);
+  copy_crew().run(chunks, [&](int i) {
+    for (int c = (int)((long long)s->nch * i / chunks), e = (int)((long long)s->nch * (i + 1) / chunks); c < e; ++c) one(c);
+  });
+}
+}  // namespace
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -242,19 +324,25 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
                                   // (rvc_set_process splits long calls itself)
   if (!use_device(s)) return;
   const TuneScope tune_scope(s);
-  for (int c = 0; c < s->nch; ++c) std::memcpy(s->h_in + (size_t)c * len, in[c], len * sizeof(float));
-  // Per-block calls (the latency path: one fused launch) skip both DMA copies: the pinned staging
+  stage_rows(s, in, nullptr, len);
+  // Per-block calls of SMALL sets (the latency path: one fused launch) skip both DMA copies: the pinned staging
   // buffers are device-visible, the kernel reads its 2 KB per channel over PCIe and writes the
-  // result straight back; the host waits for the event behind that kernel. Longer calls use DMA.
+  // result straight back; the host polls the flags its workgroups publish. Longer calls and many channels use DMA (a kernel
+  // that fetches megabytes over PCIe with its own loads holds its CUs for the whole transfer; the copy engines do not).
   const long long hb = (long long)s->A.B;
   // (a call across one block boundary is two such launches: step_device)
-  s->zero_copy = !s->block_general && rvc::fused_supported(s->A.logB, s->A.f64()) && ((s->n + (long long)len - 1) / hb - s->n / hb) <= 1;
+  const bool small = s->tune.host_zero_copy >= 0 ? s->tune.host_zero_copy != 0 : (size_t)s->nch * len * sizeof(float) <= kZeroCopyMaxBytes;
+  s->zero_copy = small && !s->block_general && rvc::fused_supported(s->A.logB, s->A.f64()) && ((s->n + (long long)len - 1) / hb - s->n / hb) <= 1;
   bool ok = true;
-  if (!s->zero_copy)
-    ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * len * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
+  const size_t ml = s->max_len;
+  if (!s->zero_copy) {
+    if (len == ml) ok = hipMemcpyAsync(s->d_in, s->h_in, sizeof(float) * len * s->nch, hipMemcpyHostToDevice, s->st_main) == hipSuccess;
+    else ok = hipMemcpy2DAsync(s->d_in, sizeof(float) * ml, s->h_in, sizeof(float) * ml, sizeof(float) * len, (size_t)s->nch,
+                               hipMemcpyHostToDevice, s->st_main) == hipSuccess;
+  }
   s->out_copy_len = len;                       // step_device emits the copy-back / event right behind the output kernel
-  ok = ok && (s->zero_copy ? step_device(s, s->h_in, len, s->h_out, len, len)
-                           : step_device(s, s->d_in, len, s->d_out, len, len));
+  ok = ok && (s->zero_copy ? step_device(s, s->h_in, ml, s->h_out, ml, len)
+                           : step_device(s, s->d_in, ml, s->d_out, ml, len));
   ok = ok && emit_output_copy(s);              // (paths whose last kernel is the output kernel)
   s->out_copy_len = 0;
   if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_begin");
@@ -296,12 +384,26 @@ void rvc_set_process_end(rvc_set *s, float *const *out) {
     ok = hipEventSynchronize(s->ev_out) == hipSuccess;   // output copied back; later stream work may still run
     if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_end");
   }
-  for (int c = 0; c < s->nch; ++c) {
-    if (!out[c]) continue;
-    if (ok) std::memcpy(out[c], s->h_out + (size_t)c * len, len * sizeof(float));
-    else std::memset(out[c], 0, len * sizeof(float));   // not initialised / empty IR / failed: zeros
-  }
+  if (ok) stage_rows(s, nullptr, out, len);
+  else
+    for (int c = 0; c < s->nch; ++c)
+      if (out[c]) std::memset(out[c], 0, len * sizeof(float));   // not initialised / empty IR / failed: zeros
   s->pending_ok = false;
+}
+
+int rvc_set_host_buffers(rvc_set *s, float **in, float **out) {
+  if (!s) return 0;
+  if (!s->kids.empty()) {
+    int ok = 1;
+    for (size_t k = 0; k < s->kids.size(); ++k)
+      ok &= rvc_set_host_buffers(s->kids[k], in ? in + s->kid_c0[k] : nullptr, out ? out + s->kid_c0[k] : nullptr);
+    return ok;
+  }
+  for (int c = 0; c < s->nch; ++c) {
+    if (in) in[c] = s->live ? s->h_in + (size_t)c * s->max_len : nullptr;
+    if (out) out[c] = s->live ? s->h_out + (size_t)c * s->max_len : nullptr;
+  }
+  return s->live ? 1 : 0;
 }
 
 void rvc_set_process(rvc_set *s, const float *const *in, float *const *out, size_t len) {

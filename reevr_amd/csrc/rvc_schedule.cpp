@@ -507,8 +507,11 @@ bool emit_output_copy(rvc_set *s) {
   if (s->out_copy_len == 0) return true;
   const size_t len = s->out_copy_len;
   s->out_copy_len = 0;
-  if (!s->zero_copy)
-    RVC_CK(hipMemcpyAsync(s->h_out, s->d_out, sizeof(float) * len * s->nch, hipMemcpyDeviceToHost, s->st_main));
+  if (!s->zero_copy) {             // staging rows are max_len apart (stable per-channel pointers: rvc_set_host_buffers)
+    if (len == s->max_len) RVC_CK(hipMemcpyAsync(s->h_out, s->d_out, sizeof(float) * len * s->nch, hipMemcpyDeviceToHost, s->st_main));
+    else RVC_CK(hipMemcpy2DAsync(s->h_out, sizeof(float) * s->max_len, s->d_out, sizeof(float) * s->max_len, sizeof(float) * len,
+                                 (size_t)s->nch, hipMemcpyDeviceToHost, s->st_main));
+  }
   RVC_CK(hipEventRecord(s->ev_out, s->st_main));
   return true;
 }

@@ -42,6 +42,10 @@ constexpr int kMix64Default = 2;
 // without a second stream issue the tail stage's sweeps a tail period early, in channel slices behind the per-block launches.
 // kSpreadDefault: bit 0 first-level sweeps, bit 1 second-level sweeps. Measured on MI355X: profiles/r6_spread.txt
 constexpr int kSpreadMinChannels = 256;
+// host-pointer per-block calls: up to this many bytes per direction the one-launch block kernel reads / writes the pinned staging rows
+// itself over PCIe (no DMA copies, completion flags instead of an event); beyond it the copy engines move the block
+// (measured on MI355X: profiles/r6_host_rate.txt)
+constexpr size_t kZeroCopyMaxBytes = (size_t)1 << 20;
 constexpr int kSpreadDefault = 0;
 constexpr bool kKidStaggerDefault = false;
 // Phase groups of the tail tiles of such sets (Tile::G). Measured on MI355X (profiles/r6_call_cost.txt), BASELINE config 2 at 4096
@@ -161,6 +165,8 @@ struct Tuning {
                           // launches (Tile::lag1 / lag2): -1 by size, else bit 0 the first-level sweeps, bit 1 the second-level ones
   int kid_stagger = -1;   // "kid_stagger": child k of n starts its tail tiles k * 8 / n blocks out of phase: -1 default / 0 off / 1 on
   int tail_phases = -1;   // "tail_phases": phase groups of the tail stage's tiles (Tile::G): -1 by size, else 1 (none) .. 8
+  int host_zero_copy = -1; // "host_zero_copy": host-pointer per-block calls let the kernel read / write the pinned staging rows itself
+                          // (no DMA copies): -1 by size (up to kZeroCopyMaxBytes per call), 0 never, 1 whenever legal
   rvc::LaunchTune launch; // kernel variants the launchers choose between (rvc_internal.h)
 };
 

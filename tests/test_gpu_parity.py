@@ -1642,3 +1642,42 @@ def test_reference_stereo_convolver_glue_on_the_drop_in(tmp_path, block, nblocks
 
 def _stream(o, x, block):
     return np.concatenate([o.process(x[a:a + block]) for a in range(0, len(x), block)]) if len(x) else np.zeros(0, np.float32)
+
+
+@pytest.mark.parametrize("nch,zc", [(2, -1), (6, 0), (600, -1), (600, 1)])
+def test_host_staging_rows_in_place(nch, zc):
+    """rvc_set_host_buffers: a host that writes its block into the set's own pinned staging rows and passes THOSE pointers to
+    rvc_set_process gets the same samples as through its own buffers -- no staging copy (600 channels: the many-thread staging
+    path for the ordinary call, DMA or in-kernel PCIe access by knob) -- per-block calls, a ragged call, and the ordinary
+    host-pointer call on the same handle in between; two channels against the oracle."""
+    head, tail, nblk = 128, 512, 40
+    irs = [synth.synth_ir(2 * tail + 3 * tail - 7 * (c % 13), 1, 40 + c % 9)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 5 + c % 7) for c in range(nch)])
+    s = reevr_amd.ConvolverSet(nch, tune=dict(host_zero_copy=zc))
+    assert s.init(head, tail, irs, max_len=head), s.last_error_string
+    ins, outs = s.host_buffers()
+    got = np.empty_like(x)
+    pos = 0
+    sched = [head] * 10 + [37, head - 37] + [head] * 8 + [-head] * 4 + [head] * (nblk - 23)      # (negative: through own buffers)
+    for n in sched:
+        if n < 0:
+            n = -n
+            got[:, pos:pos + n] = s.process(x[:, pos:pos + n])
+        else:
+            for c in range(nch):
+                ins[c][:n] = x[c, pos:pos + n]
+            s.process_in_place(n)
+            for c in range(nch):
+                got[c, pos:pos + n] = outs[c][:n]
+        pos += n
+    assert pos == head * nblk and s.last_error == 0, s.last_error_string
+    s.clear()
+    ref = np.concatenate([s.process(x[:, b * head:(b + 1) * head]) for b in range(nblk)], axis=1)
+    s.close()
+    assert np.array_equal(got[:, :10 * head], ref[:, :10 * head])           # same calls, other buffers: the same bits
+    for c in range(0, nch, max(1, nch // 16)):                              # (behind the ragged calls: the same samples)
+        assert rel_rms(got[c], ref[c]) <= 1e-6, c
+    for c in (0, nch - 1):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(got[c], o.process(x[c])) <= TOL, c
