@@ -635,6 +635,37 @@ def side_config(torch, reevr_amd, synth, KERNEL_NAMES, cfg: int, channels: int, 
     return out
 
 
+def literal_roofline(ls, rate: float, kern: dict) -> dict:
+    """Roofline of the literal config 5 leg (one long call per step through the whole-IR delay line at the largest block the
+    call allows -- rvc_plan::wide_block / long_call_block). Two readings: SURVEY.md 8d's flop model of the REFERENCE's structure
+    (656 flop per sample) x the measured rate against the fp32 vector peak -- a throughput equivalent like `alg_equiv`: the long
+    call runs fewer, larger partitions than the reference --, and per kernel family what the launch executes: the delay-line
+    kernel's multiply-adds (8 flop per partition x bin x output row) and the transforms' bytes over their live durations."""
+    p = ls.conv.plan()
+    nch, frames = ls.nch, ls.frames_step
+    B = int(p["wide_block"] or p["long_call_block"] or p["tail_block"] or p["head_block"])
+    P = ls.conv.partitions(2) if p["wide_block"] else (ls.conv.partitions(1) + 2 if p["long_call_block"] else ls.conv.partitions(0))
+    rows = -(-frames // B) + 1                                     # output rows of one call (the partly filled last block included)
+    fps = flops_per_sample(ls.head, ls.tail, ls.ir_len)
+    out = {"bound": "fp32_fma", "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "achieved": round(rate * fps / 1e12, 2), "frac": round(rate * fps / 1e12 / FP32_PEAK_TFLOPS, 4),
+           "flops_per_sample_model": round(fps, 1), "block": B, "partitions": P, "rows_per_call": rows, "families": {}}
+    fam_bytes = {"fft_fwd_tail": nch * rows * (4.0 * 2 * B + 8.0 * B), "fft_inv_tail": nch * rows * (8.0 * B + 4.0 * B),
+                 # the LDS-tiled delay line: every X row once per bin tile walk, the IR rows once per 64-row time tile, Y rows out
+                 "fir_tail": nch * 8.0 * B * (rows + P * -(-rows // 64) + rows)}
+    for k, v in kern.items():
+        ent = {"ms_per_call": round(v["avg_ms"] * v["launches_per_step"], 4)}
+        if k in fam_bytes:
+            ent["GBs"] = round(fam_bytes[k] / (v["avg_ms"] * v["launches_per_step"] * 1e-3) / 1e9, 1)
+            ent["frac_hbm"] = round(ent["GBs"] / HBM_PEAK_GBS, 4)
+        if k == "fir_tail":
+            tf = 8.0 * P * B * rows * nch / (v["avg_ms"] * v["launches_per_step"] * 1e-3) / 1e12
+            ent["executed_TFLOPs"] = round(tf, 2)
+            ent["frac_fp32"] = round(tf / FP32_PEAK_TFLOPS, 4)
+        out["families"][k] = ent
+    return out
+
+
 def small_regimes(torch, reevr_amd, synth, KERNEL_NAMES, local_rank: int, steps: int, irs4096=None, x4096=None, instances=None):
     """The regimes between one stereo pair and the headline's thousands of channels (where BASELINE configs 4 and 5 live on
     an 8-GPU node), each with the impulse probe; plus the literal config 5 and the headline set with double transforms."""
@@ -665,7 +696,8 @@ def small_regimes(torch, reevr_amd, synth, KERNEL_NAMES, local_rank: int, steps:
     out["config5_literal"] = {"value": round(rate5 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(ms5, 4), "channels": 64,
                               "frames_per_channel_per_step": l5.frames_step,
                               "workload": "64 mono channels, 5 s IR @ 48 kHz, block 4096, ONE process() of 20 s per step through "
-                                          "reevr_amd.render.BatchRenderer (the raw many-channel renderer, SURVEY 8f f-4)"}
+                                          "reevr_amd.render.BatchRenderer (the raw many-channel renderer, SURVEY 8f f-4)",
+                              "roofline": literal_roofline(l5, rate5, l5.kernel_times(KERNEL_NAMES))}
     l5.close()
     # the headline set with other transform precisions: float throughout (RVC_FLAG_FFT_F32: the default of rounds 1-4; the default
     # since round 5 runs the tail stage's INVERSE transform in double, which is what takes the reference's own known-answer rule,
@@ -812,8 +844,7 @@ def compact_line(full: dict, full_path=None) -> dict:
     side = {}
     cu = full.get("call_us")
     if cu:                                  # what each per-block call of the timed set costs the device (stamped loop)
-        line["call_us"] = _pick(cu, ("p50", "p99", "max", "block_period_us", "max_over_block_period", "tail_spread", "tail_phase_groups"))
-        optional.append("call_us")
+        line["call_us"] = _pick(cu, ("p50", "p99", "max", "block_period_us", "max_over_block_period", "tail_phase_groups"))
     if (full.get("bg_stream") or {}).get("call_us"):
         side["bg_stream_Msamples_s"] = full["bg_stream"]["value"]
         side["bg_stream_call_us_p99_max"] = [full["bg_stream"]["call_us"]["p99"], full["bg_stream"]["call_us"]["max"]]
@@ -825,6 +856,9 @@ def compact_line(full: dict, full_path=None) -> dict:
     if sb:
         side["stereo_pair_us_per_block"] = sb["us_per_block"]
         side["stereo_pair_host_call_us_median"] = sb["host_call_us_median"]
+    hb = full.get("host_boundary")
+    if hb:                                  # PCIe-inclusive rate of the host-pointer boundary at 1024 / 4096 channels: [own buffers, in place]
+        side["host_pcie_inclusive_Msamples_s"] = {k: [v["own_buffers_Msamples_s"], v["in_place_Msamples_s"]] for k, v in hb.items() if isinstance(v, dict)}
     reg = full.get("regimes")
     if reg:
         sw = reg.get("channel_sweep", {})
@@ -835,6 +869,10 @@ def compact_line(full: dict, full_path=None) -> dict:
         for k in ("config5_literal", "fft_f32", "fft_f64_long", "fft_f64"):
             if k in reg:
                 side[k + "_Msamples_s"] = reg[k]["value"]
+        r5 = (reg.get("config5_literal") or {}).get("roofline")
+        if r5:
+            side["config5_literal_roofline"] = dict(_pick(r5, ("bound", "achieved", "frac", "unit")),
+                                                    mac_frac_fp32=(r5["families"].get("fir_tail") or {}).get("frac_fp32"))
     if side:
         line["side"] = side
         optional.insert(0, "side")
@@ -868,8 +906,8 @@ def main():
                          "outputs of 8 stereo instances per GPU; 2: every channel; 0: off")
     ap.add_argument("--configs", type=str, default="1,3,5", help="other BASELINE configurations measured in the same run (N = 1, config 2)")
     ap.add_argument("--config-steps", type=int, default=8, help="timed steps of each of those")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the headline's CPU baseline leg (0 = skip)")
-    ap.add_argument("--config-cpu-seconds", type=float, default=8.0, help="budget of each other configuration's CPU leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the headline's CPU baseline leg (0 = skip)")
+    ap.add_argument("--config-cpu-seconds", type=float, default=4.0, help="budget of each other configuration's CPU leg")
     ap.add_argument("--side", type=int, default=1, help="0: skip the side measurements")
     ap.add_argument("--regimes", type=int, default=1, help="0: skip the small-regime entries (channel sweep, literal config 5, double transforms)")
     ap.add_argument("--distinct", type=int, default=0, help="synthesise only this many different stereo IRs and cycle them (0: all different; config 3: 128)")
@@ -1158,6 +1196,7 @@ def main():
             bgl.close()
         if args.config == 2:
             side.update(side_measurements(torch, reevr_amd, synth, irs[:2], local_rank, dev, host_block, tail))
+            side["host_boundary"] = host_boundary(torch, reevr_amd, irs, x, local_rank, host_block, tail)
     lap("side_legs")
     if world == 1 and args.cpu_seconds > 0 and lockstep_cfg:
         cores = os.cpu_count() or 1
@@ -1277,6 +1316,44 @@ def main():
         dist.destroy_process_group()
     if probe is not None and not probe["ok"]:
         raise SystemExit("correctness probe failed: %r" % (probe,))
+
+
+def host_boundary(torch, reevr_amd, irs, x, local_rank, host_block, tail, channels=(1024, 4096), blocks=192):
+    """The host-pointer boundary with MANY channels, PCIe-inclusive (never `value`), in steady state (the delay lines are filled
+    through the device entry first): rvc_set_process per block on the caller's own buffers (staging copy by the copy crew + DMA
+    both ways) and `in_place` -- the caller's audio lives in the set's pinned staging rows (rvc_set_host_buffers), both through
+    the same C loop with a stopwatch around every call (whole tail periods: every 16th call carries the tail job)."""
+    out = {}
+    for nch in channels:
+        if nch > len(irs):
+            continue
+        s = reevr_amd.ConvolverSet(nch, device=local_rank)
+        assert s.init(host_block, tail, irs[:nch], max_len=host_block), s.last_error_string
+        pre = -(-(s.partitions(1) + 4) * int(s.tail_block) // x.shape[1])
+        dx = torch.from_numpy(np.ascontiguousarray(x[:nch])).to(torch.device("cuda", local_rank))
+        dy = torch.empty_like(dx)
+        for _ in range(pre):
+            s.process_device_blocks(dx, host_block, dy, sync=True)
+        del dx, dy
+        torch.cuda.empty_cache()
+        xs = np.ascontiguousarray(x[:nch, :host_block * blocks])
+        _, us = s.process_host_blocks_timed(xs, host_block)
+        s.check()
+        ins, outs = s.host_buffers()
+        for c in range(nch):
+            ins[c][:host_block] = xs[c, :host_block]
+        us2 = s.process_in_place_timed(host_block, blocks)
+        s.check()
+        rate = lambda u: round(nch * host_block * len(u) / (float(np.sum(u)) * 1e-6) / 1e6, 1)
+        q = lambda u: [round(float(np.sort(u)[len(u) // 2]), 1), round(float(np.sort(u)[int(len(u) * 0.99)]), 1)]
+        out[str(nch)] = {"own_buffers_Msamples_s": rate(us), "in_place_Msamples_s": rate(us2),
+                         "own_buffers_call_us_p50_p99": q(us), "in_place_call_us_p50_p99": q(us2),
+                         "MB_per_call_each_way": round(nch * host_block * 4 / 1e6, 2), "subsets": s.subsets, "pre_roll_blocks": pre * (x.shape[1] // host_block)}
+        s.close()
+    out["note"] = ("rvc_set_process on HOST buffers, one call per block, PCIe-inclusive, delay lines full: own_buffers = the caller's "
+                   "per-channel buffers (staged into pinned rows by a few host threads, DMA both ways), in_place = the caller writes / "
+                   "reads the set's pinned staging rows (rvc_set_host_buffers); every 16th call carries the tail job")
+    return out
 
 
 def side_measurements(torch, reevr_amd, synth, irs2, local_rank, dev, host_block, tail):

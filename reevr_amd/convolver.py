@@ -137,6 +137,19 @@ class ConvolverSet:
         ins, outs = self._stage_ptrs
         self._lib.rvc_set_process(self._h, C.cast(ins, L.F32PP), C.cast(outs, L.F32PP), n)
 
+    def process_in_place_timed(self, n: int, calls: int) -> np.ndarray:
+        """`calls` back-to-back calls of n frames on the staging rows of host_buffers(), in C with a stopwatch around every call
+        (rvc_set_process_host_blocks_timed on the staging pointers themselves: block = len = n, no staging copy). Returns the
+        per-call durations in microseconds."""
+        ins, outs = self._stage_ptrs
+        us = np.zeros(calls, np.float64)
+        one = np.zeros(1, np.float64)
+        for i in range(calls):
+            self._lib.rvc_set_process_host_blocks_timed(self._h, C.cast(ins, L.F32PP), C.cast(outs, L.F32PP), n, n,
+                                                        one.ctypes.data_as(C.POINTER(C.c_double)))
+            us[i] = one[0]
+        return us
+
     def process_host_blocks_timed(self, x: np.ndarray, block: int):
         """x: (n_channels, len) host array fed through process() in calls of `block` frames, all in C.
         Returns (output, per-call durations in microseconds)."""
