@@ -189,6 +189,7 @@ struct LaunchTune {
   int sweep_nt = -1;     // sweeps of a stage stream (non-temporal accumulator-row stores, second-level IR loads): -1 by the stage's size / 0 / 1
   int inv_dif = -1;      // 8192-bin DOUBLE inverse as two 4096-point sub-transforms in two workgroups (k_fft8_inv_dif2): 0 off / else on
   int mac3 = -1;         // three-product complex multiply-accumulate in the LDS-fed 32-block sweeps: -1 default / 0 off / 1 on
+  int block_lanex = -1;  // per-block kernel of head 512: second exchange of its transforms lane-locally (v_permlane32/16_swap + DPP): -1 by size / 0 / 1
 };
 void set_launch_tune(const LaunchTune *t);   // thread-local; nullptr = the defaults above
 const LaunchTune &launch_tune();

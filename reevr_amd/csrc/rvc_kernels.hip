@@ -422,6 +422,47 @@ struct Tw8 {
   }
 };
 
+// The exchange behind radix-8 pass j = 1 of the single-wave 512-point plan, LANE-LOCALLY (north_star: "wavefront shuffles"). Thread
+// i = 8a + b writes leg r to index 64a + b + 8r and thread t reads t + 64r': new[lane (a, b)][register c] = old[lane (c, b)][register
+// a] -- an 8 x 8 transpose between the register index and the upper lane digit = three butterfly stages, one per bit: lanes 32 apart
+// with v_permlane32_swap_b32 (the upper half of one register against the lower half of the other: 8 instructions for the stage), lanes 16
+// apart with v_permlane16_swap_b32 (8), lanes 8 apart with bank-masked v_mov_b32_dpp row_ror:8 (a copy + two moves per pair and
+// component: 24) -- 40 VALU instructions instead of 8 ds_write_b64 + 8 ds_read_b64 and a wave fence. Measured on MI355X
+// (tools/ubench/wave_exchange.hip, profiles/r6_wave_exchange.txt): a wave ALONE on its SIMD is 12 % slower with it (296 against 264
+// cycles per exchange), 8 or 16 waves per CU -- which share the CU's one LDS pipe -- are 35 % FASTER (424 against 668 cycles). So
+// only the many-channel per-block kernel uses it (fft8_core LANEX; knob "block_lanex").
+// (The FIRST exchange of that plan rotates three digits -- the same transpose on the LOWER lane digit, whose two low bits have no swap
+//  instruction, followed by a lane permutation that is 16 ds_bpermute_b32 through the same LDS pipe: stays in LDS.)
+__device__ __forceinline__ void lanex_swap32(unsigned &x, unsigned &y) {   // x's upper half <-> y's lower half
+  const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+  x = r[0]; y = r[1];
+}
+__device__ __forceinline__ void lanex_swap16(unsigned &x, unsigned &y) {   // x's odd rows of 16 lanes <-> y's even rows
+  const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+  x = r[0]; y = r[1];
+}
+__device__ __forceinline__ void lanex_swap8(unsigned &x, unsigned &y) {    // x's lanes 8..15 of every row <-> y's lanes 0..7
+  const unsigned t = y;
+  y = (unsigned)__builtin_amdgcn_update_dpp((int)y, (int)x, 0x128, 0xF, 0x3, false);   // row_ror:8, banks 0-1 written
+  x = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)t, 0x128, 0xF, 0xC, false);   // row_ror:8, banks 2-3 written
+}
+__device__ __forceinline__ void lanex_transpose(cx<float> *v) {
+  unsigned re[8], im[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) { re[r] = __float_as_uint(v[r].x); im[r] = __float_as_uint(v[r].y); }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (!(r & 4)) { lanex_swap32(re[r], re[r | 4]); lanex_swap32(im[r], im[r | 4]); }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (!(r & 2)) { lanex_swap16(re[r], re[r | 2]); lanex_swap16(im[r], im[r | 2]); }
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+    if (!(r & 1)) { lanex_swap8(re[r], re[r | 1]); lanex_swap8(im[r], im[r | 1]); }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = mk<float>(__uint_as_float(re[r]), __uint_as_float(im[r]));
+}
+
 // v[e] = x[in_idx(e)] on entry, X[out_idx(e)] on exit (unscaled). `lds` holds LDS_ELEMS values.
 // Ends with all LDS reads done but NO trailing barrier.
 // SOLO: the transform lives in ONE wave that shares its workgroup with waves doing something else (k_fused_block2w): a
@@ -436,9 +477,11 @@ template <bool SOLO> __device__ __forceinline__ void core_sync() {
     __syncthreads();
   }
 }
-template <int LOGB, bool INV, typename R, bool SOLO = false, typename TW = Tw8<LOGB, R>>
+// LANEX: the exchange behind pass j = 1 of the single-wave 512-point plan runs lane-locally (lanex_transpose) instead of through LDS.
+template <int LOGB, bool INV, typename R, bool SOLO = false, typename TW = Tw8<LOGB, R>, bool LANEX = false>
 __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const TW &T, const int tid) {
   typedef Plan8<LOGB> P;
+  static_assert(!LANEX || (LOGB == 9 && sizeof(R) == 4 && P::NT == 64 && P::S == 1), "LANEX: the single-wave 512-point float plan");
   typedef cx<R> C;
   constexpr bool kLin = P::kLin;
   constexpr bool kEager = TW::EAGER;
@@ -547,7 +590,9 @@ __device__ __forceinline__ void fft8_core(cx<R> *v, cx<R> *lds, const TW &T, con
       dft8<R, INV>(a);
     }
     const bool last8 = (j == P::N8 - 1);
-    if (!(last8 && P::Q == 1)) {
+    if (LANEX && j == 1) {                          // (the pass index is a compile-time value in the unrolled loop)
+      if constexpr (LANEX) lanex_transpose(v);
+    } else if (!(last8 && P::Q == 1)) {
       if (j > 0) core_sync<SOLO>();               // previous exchange fully read before overwriting
 #pragma unroll
       for (int s = 0; s < P::S; ++s) {
@@ -1308,7 +1353,7 @@ __global__ void __launch_bounds__(Plan8<LOGB>::WG) k_fft8_inv_loop(const InvArgs
 // (SOLO: the many-channel form. Its general path -- ragged calls -- keeps the ring append between the sample loads: the
 //  requests then go out one at a time, but 16 fewer registers are live, and the whole-block path every lock-step launch
 //  takes sets the kernel's budget: three waves per SIMD.)
-template <int LOGB, bool FOLD, bool SOLO = false, bool LEAN = false>
+template <int LOGB, bool FOLD, bool SOLO = false, bool LEAN = false, bool LANEX = false>
 __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, const int wg, const float2 *hand = nullptr) {
   static_assert(!SOLO || Plan8<LOGB>::WG == 64, "SOLO: the workgroup's transform(s) live in one wave");
   static_assert(!LEAN || FOLD, "LEAN: the folded launch path only");
@@ -1456,7 +1501,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
   if constexpr (!LEAN) fold_in();
   // 2. forward transform, real split; X_k goes to the delay line and, times H0 plus the
   //    pre-multiplied accumulator, becomes Y_k
-  fft8_core<LOGB, false, float, SOLO, TW>(v, lds, T, tid);
+  fft8_core<LOGB, false, float, SOLO, TW, LANEX>(v, lds, T, tid);
   if constexpr (SOLO) {
     if (a.handover) {                            // (launch-uniform) the patch wave's row of this block: sweep row + recent partitions
       __syncthreads();                           // the one workgroup barrier of the launch: patch wave wrote, audio wave reads
@@ -1558,7 +1603,7 @@ __device__ __forceinline__ void fused_audio(const FusedArgs &a, char *smem_raw, 
     }
   }
   if constexpr (!kWS) core_sync<SOLO>();
-  fft8_core<LOGB, true, float, SOLO, TW>(v, lds, T, tid);
+  fft8_core<LOGB, true, float, SOLO, TW, LANEX>(v, lds, T, tid);
   if constexpr (LEAN) {
     __builtin_amdgcn_sched_barrier(0);
     load_addv();
@@ -2136,12 +2181,12 @@ template <int LOGB> __host__ __device__ constexpr size_t fused2w_hand_offset() {
   if (lds < sizeof(float2) * 4 * 64) lds = sizeof(float2) * 4 * 64;
   return (lds + 15) & ~(size_t)15;
 }
-template <int LOGB, bool NT, bool LEAN>
+template <int LOGB, bool NT, bool LEAN, bool LANEX = false>
 __global__ void __launch_bounds__(128, LEAN ? 4 : 2) k_fused_block2w(const FusedArgs a, const FirArgs f) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // (handover row: 512 entries behind the transform's exchange buffer, launch_fused2_t sizes the allocation)
   float2 *hand = reinterpret_cast<float2 *>(smem_raw + fused2w_hand_offset<LOGB>());
-  if (threadIdx.x < 64) fused_audio<LOGB, true, true, LEAN>(a, smem_raw, blockIdx.x, hand);
+  if (threadIdx.x < 64) fused_audio<LOGB, true, true, LEAN, LANEX>(a, smem_raw, blockIdx.x, hand);
   else if (f.P > 0) fdl_patch_wave<LOGB, NT, LEAN ? 2 : 3>(f, blockIdx.x, a.channels, a.handover ? hand : nullptr);
 }
 
@@ -2362,6 +2407,7 @@ static hipError_t launch_fused_t(const FusedArgs &a, int channels, hipStream_t s
 }
 
 // audio path of block k with H_1 X_{k-1} folded in + (f.P > 0) the partial accumulator of block k+1
+constexpr int kLanexMinWorkgroups = 1 << 30;   // per-block launches of at least this many workgroups exchange lane-locally (off: measured below)
 template <int LOGB>
 static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int channels, hipStream_t st) {
   typedef Plan8<LOGB> P;
@@ -2378,7 +2424,16 @@ static hipError_t launch_fused2_t(const FusedArgs &a, const FirArgs &f, int chan
       lds = fused2w_hand_offset<LOGB>() + sizeof(float2) * 512;
       if (launch_tune().patch_nt == 2 && (long long)channels * P::B >= (1ll << 19)) RVC_LAUNCH((k_fused_block2w<LOGB, true, false>), dim3(n_audio), dim3(128), lds, st, b, f);
       else if (launch_tune().block_occ == 4 && n_audio >= 1024) RVC_LAUNCH((k_fused_block2w<LOGB, false, true>), dim3(n_audio), dim3(128), lds, st, b, f);
-      else RVC_LAUNCH((k_fused_block2w<LOGB, false, false>), dim3(n_audio), dim3(128), lds, st, b, f);
+      else {
+        // many workgroups per CU share the CU's one LDS pipe: the second exchange of the 512-point transforms lane-locally
+        // (lanex_transpose; a handful of workgroups -- a wave alone on its SIMD -- is faster through LDS)
+        bool lanex = false;
+        if constexpr (LOGB == 9) lanex = launch_tune().block_lanex >= 0 ? launch_tune().block_lanex != 0 : n_audio >= kLanexMinWorkgroups;
+        if constexpr (LOGB == 9) {
+          if (lanex) RVC_LAUNCH((k_fused_block2w<LOGB, false, false, true>), dim3(n_audio), dim3(128), lds, st, b, f);
+          else RVC_LAUNCH((k_fused_block2w<LOGB, false, false>), dim3(n_audio), dim3(128), lds, st, b, f);
+        } else RVC_LAUNCH((k_fused_block2w<LOGB, false, false>), dim3(n_audio), dim3(128), lds, st, b, f);
+      }
       return hipGetLastError();
     }
   }

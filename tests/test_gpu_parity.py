@@ -1681,3 +1681,30 @@ def test_host_staging_rows_in_place(nch, zc):
         o = O.TwoStageFFTConvolver("orc")
         assert o.init(head, tail, irs[c])
         assert rel_rms(got[c], o.process(x[c])) <= TOL, c
+
+
+def test_per_block_kernel_lane_local_exchange_is_bit_identical():
+    """The per-block kernel of head 512 with the second exchange of its two transforms done LANE-LOCALLY (v_permlane32_swap /
+    v_permlane16_swap / DPP row_ror:8: knob block_lanex, rvc_kernels.hip lanex_transpose) instead of through LDS: a pure
+    permutation, so the same bits -- 64 lock-step channels (time-tiled zero-latency stage: the two-wave kernel), per-block calls
+    incl. ragged ones through the host entry; one channel against the oracle."""
+    import torch
+    nch, head, tail, ir_len, nblk = 64, 512, 8192, 70000, 120
+    irs = [synth.synth_ir(ir_len, 1, 500 + c)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 40 + c) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    outs = []
+    for lx in (0, 1):
+        s = reevr_amd.ConvolverSet(nch, tune=dict(block_lanex=lx))
+        assert s.init(head, tail, irs, max_len=head)
+        assert s.plan()["head_patch_in_launch"] == 1
+        y = s.process_device_blocks(dx[:, :head * 100].contiguous(), head).cpu().numpy()
+        z = np.concatenate([s.process(x[:, a:b]) for a, b in ((head * 100, head * 100 + 37), (head * 100 + 37, head * 101),
+                                                                (head * 101, head * 102))], axis=1)
+        assert s.last_error == 0
+        s.close()
+        outs.append(np.concatenate([y, z], axis=1))
+    assert np.array_equal(outs[0], outs[1])
+    o = O.TwoStageFFTConvolver("orc")
+    assert o.init(head, tail, irs[5])
+    assert rel_rms(outs[1][5], o.process(x[5, :head * 102])) <= TOL
