@@ -16,7 +16,11 @@ for seed in range(first, first + count):
             (T.test_fuzz_child_sets_call_patterns, (seed,)),
             # the delay-1 tail stage of many-channel sets, forced on these small ones: the tail at twice the block / half the zero-latency stage
             (T.test_fuzz_geometry_and_call_pattern, (seed, "widen")), (T.test_fuzz_geometry_and_call_pattern, (seed, "shrink")),
-            (T.test_fuzz_block_synchronous_time_tiling, (seed, "widen")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "shrink_force2"))]
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "widen")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "shrink_force2")),
+            # round 6: the tail tiles in channel groups out of phase (what sets of >= 256 channels run), and spread sweeps
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_force2_k32")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_shrink_force2")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_widen")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_force")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "spread3_force2")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "spread1_force2_k32"))]
     for fn, a in jobs:
         runs += 1
         if os.environ.get("STRESS_LOG"):

@@ -38,11 +38,14 @@ def case(seed):
 for seed in [226] + list(range(nseeds)):
     head, tail, nch, irs, sched, x = case(seed)
     # force2_k32: first-level tiles of 32 blocks = the LDS-fed sweeps; widen / shrink: the delay-1 tail stage of many-channel sets
-    for tiling in (False, True, "force", "force2", "force2_k32", "widen", "shrink"):
-        slack = {"widen": 1, "shrink": 2}.get(tiling, -1)
-        with reevr_amd.tuning(guard=2, k1=32 if tiling == "force2_k32" else 0, tail_slack=slack):
-            s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1) and slack < 0, fft_f32=slack > 0,
-                                       time_tiling={"force2_k32": "force2", "widen": "force", "shrink": "force2"}.get(tiling, tiling))
+    # round 6: phases = the tail tiles in channel groups out of phase (launches on channel sub-ranges); spread3 = sweeps in channel slices
+    for tiling in (False, True, "force", "force2", "force2_k32", "widen", "shrink", "phases", "phases_shrink", "spread3"):
+        slack = {"widen": 1, "shrink": 2, "phases_shrink": 2}.get(tiling, -1)
+        extra = dict(tail_phases=8) if str(tiling).startswith("phases") else (dict(tail_spread=3) if tiling == "spread3" else {})
+        with reevr_amd.tuning(guard=2, k1=32 if tiling == "force2_k32" else 0, tail_slack=slack, **extra):
+            s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1) and slack < 0 and not extra, fft_f32=slack > 0,
+                                       time_tiling={"force2_k32": "force2", "widen": "force", "shrink": "force2", "phases": "force2",
+                                                    "phases_shrink": "force2", "spread3": "force2"}.get(tiling, tiling))
             ok = s.init(head, tail, irs, max_len=max(sched))
         assert ok, s.last_error_string
         pos = 0
@@ -57,10 +60,13 @@ import torch
 for nch, head, tail, ir_len, nblk in ((64, 512, 8192, 480000, 16 * 20), (64, 256, 8192, 700000, 32 * 40), (40, 4096, 8192, 100000, 24)):
     irs = [synth.synth_ir(ir_len - 997 * (c % 5), 1, 600 + c)[0] for c in range(nch)]
     xx = torch.from_numpy(np.stack([synth.synth_input(head * nblk, 20 + c % 7) for c in range(nch)])).cuda()
-    for tiling in (True, "force", "force2", "force2_k32", "kids", "widen", "shrink"):      # kids: two child sets (forced), default tiling
-        with reevr_amd.tuning(guard=2, k1=32 if tiling == "force2_k32" else 0, subsets=2 if tiling == "kids" else -1,
-                              tail_slack={"widen": 1, "shrink": 2}.get(tiling, -1)):
-            s = reevr_amd.ConvolverSet(nch, time_tiling={"force2_k32": "force2", "kids": True, "widen": True, "shrink": True}.get(tiling, tiling))
+    # kids: two child sets (forced), default tiling; phases / kids_phases: 8 phase groups (of 8 / 4 channels) with the shrunk tail
+    for tiling in (True, "force", "force2", "force2_k32", "kids", "widen", "shrink", "phases", "kids_phases", "spread3"):
+        extra = dict(tail_phases=8) if "phases" in str(tiling) else (dict(tail_spread=3) if tiling == "spread3" else {})
+        with reevr_amd.tuning(guard=2, k1=32 if tiling == "force2_k32" else 0, subsets=2 if str(tiling).startswith("kids") else -1,
+                              tail_slack={"widen": 1, "shrink": 2, "phases": 2, "kids_phases": 2, "spread3": 2}.get(tiling, -1), **extra):
+            s = reevr_amd.ConvolverSet(nch, time_tiling={"force2_k32": "force2", "kids": True, "widen": True, "shrink": True, "phases": True,
+                                                         "kids_phases": True, "spread3": True}.get(tiling, tiling))
             ok = s.init(head, tail, irs, max_len=head)
         assert ok, s.last_error_string
         y = s.process_device_blocks(xx, head)
