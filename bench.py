@@ -81,7 +81,7 @@ SR = 48000
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3  # vector fp32 (same guide)
 K2 = 8                    # rvc::kSweepRows: the tile the per-block patches work on
-PROFILE_ROUND = "r5"      # the round whose committed rocprofv3 passes annotate the record (profiles/<round>_config<C>/, <round>_traffic.json)
+PROFILE_ROUND = "r6"      # the round whose committed rocprofv3 passes annotate the record (profiles/<round>_config<C>/, <round>_traffic.json)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_traffic.json")
 
 # BASELINE.json configurations as lock-step workloads: IR length, host block, single-stage?, default channels per GPU,

@@ -47,13 +47,13 @@ def test_algorithmic_byte_model_matches_survey():
 
 def test_bench_traffic_lookup_is_keyed_on_the_launch_size():
     """bench.py's counter-measured bytes per launch apply only to launches of exactly the channel count they were measured with
-    (round 3's line printed half-size figures for configs 1 / 3): the committed profiles/r5_traffic.json serves the default run
+    (round 3's line printed half-size figures for configs 1 / 3): the committed profiles/r6_traffic.json serves the default run
     (child sets: 2048 / 2048 / 1024 / 2048 channels per launch for configs 2 / 1 / 3 / 5) and the one-queue run (all the
     channels per launch), and any other launch size gets nothing."""
     b = _bench()
     for cfg, per_launch, one_queue in ((2, 2048, 4096), (1, 2048, 8192), (3, 1024, 2048), (5, 2048, 4096)):
         t, src = b.load_traffic(per_launch, cfg, True)
-        assert t and "r5_traffic.json" in src and str(per_launch) in src
+        assert t and "r6_traffic.json" in src and str(per_launch) in src
         t1, _ = b.load_traffic(one_queue, cfg, True)
         assert t1 and set(t1) == set(t)
         for k in t:                                   # twice the channels per launch: twice the bytes, within a few percent
@@ -97,11 +97,11 @@ def test_stage_plan_policy():
 class _SetGeometry:
     """what bench.executed_bytes asks a ConvolverSet for"""
 
-    def __init__(self, parts, tiles, tail_block, subsets=1, patch_in_launch=0):
-        self._p, self._t, self.tail_block, self.subsets, self._pil = parts, tiles, tail_block, subsets, patch_in_launch
+    def __init__(self, parts, tiles, tail_block, subsets=1, patch_in_launch=0, phases=1):
+        self._p, self._t, self.tail_block, self.subsets, self._pil, self._ph = parts, tiles, tail_block, subsets, patch_in_launch, phases
 
     def plan(self):
-        return {"head_patch_in_launch": self._pil}
+        return {"head_patch_in_launch": self._pil, "tail_phase_groups": self._ph, "tail_spread": 0, "tail_sweep_slices": 1}
 
     def partitions(self, stage):
         return self._p[stage]
@@ -114,13 +114,14 @@ def test_executed_bytes_model_against_the_committed_counter_passes():
     """bench.py's executed-bytes model of every kernel family -- with the structures the engine runs for sets of thousands of
     channels: the tail one block late over IR[T,..) and half the zero-latency stage (configs 2 / 5: 16 + 58 and 2 + 29 partitions),
     the tail at block 16384 (config 3: 64 + 175) -- against the PMC bytes per launch of the committed one-queue passes
-    (profiles/r5_traffic.json, rocprofv3 FETCH_SIZE / WRITE_SIZE): within 5 % for every family, none missing. Round 5: the per-block
+    (profiles/r6_traffic.json, rocprofv3 FETCH_SIZE / WRITE_SIZE): within 5 % for every family, none missing. Round 6: the tail tiles run
+    in 8 channel groups out of phase -- every sweep / patch launch of the tail stage covers an eighth of the channels. Round 5: the per-block
     launch of configs 1 / 2 / 3 (heads 512 / 512 / 256) patches its own block and hands the row over through LDS (no accumulator
     round trip through memory); config 5's head of 4096 keeps the general per-block path."""
     b = _bench()
-    cases = {2: (4096, 512, 8192, 480000, _SetGeometry((16, 58), (8, 32), 8192, patch_in_launch=1)),
-             3: (2048, 256, 8192, 2880000, _SetGeometry((64, 175), (32, 32), 16384, patch_in_launch=1)),
-             5: (4096, 4096, 8192, 240000, _SetGeometry((2, 29), (0, 16), 8192)),
+    cases = {2: (4096, 512, 8192, 480000, _SetGeometry((16, 58), (8, 32), 8192, patch_in_launch=1, phases=8)),
+             3: (2048, 256, 8192, 2880000, _SetGeometry((64, 175), (32, 32), 16384, patch_in_launch=1, phases=8)),
+             5: (4096, 4096, 8192, 240000, _SetGeometry((2, 29), (0, 16), 8192, phases=8)),
              1: (8192, 512, 0, 48000, _SetGeometry((94, 0), (32, 0), 0, patch_in_launch=1))}
     for cfg, (nch, head, tail, ir_len, conv) in cases.items():
         exe = b.executed_bytes(conv, nch, head, tail, ir_len, head, True)
@@ -221,7 +222,7 @@ def test_pmc_summary_kernel_families():
 
 
 def test_every_hot_kernel_of_the_committed_summaries_has_a_family():
-    """The rocprofv3 summaries kept under profiles/r5_config<C>/ list C++ kernel names; tools/pmc_summarize.py (and through it
+    """The rocprofv3 summaries kept under profiles/r6_config<C>/ list C++ kernel names; tools/pmc_summarize.py (and through it
     bench.py's `traffic`) sorts them into families by those names. Every kernel that takes more than 0.2 % of a kept run must map
     to a family -- a renamed or new kernel that silently drops out of the accounting fails here -- except the launches of init time
     (the IR spectra's double forward transforms, the runtime's fill / copy kernels)."""
@@ -235,7 +236,7 @@ def test_every_hot_kernel_of_the_committed_summaries_has_a_family():
     seen = set()
     for cfg, (hl, tl) in geometry.items():
         for name in ("kernel_stats.csv", "kernel_stats_one_queue.csv"):
-            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r5_config{cfg}", name))))
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r6_config{cfg}", name))))
             total = sum(float(r["TotalDurationNs"]) for r in rows)
             for r in rows:
                 if float(r["TotalDurationNs"]) / total <= 0.002 or any(t in r["Name"] for t in init_only):

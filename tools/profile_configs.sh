@@ -1,11 +1,11 @@
 #!/bin/bash
-# Rounds 4-5: the rocprofv3 evidence behind bench.py's `roofline*.traffic` and the per-kernel durations, for BASELINE configs
+# Rounds 4-6: the rocprofv3 evidence behind bench.py's `roofline*.traffic` and the per-kernel durations, for BASELINE configs
 # 2 (headline), 1, 3 and 5 in the lock-step regime AT THE BENCH'S OWN LAUNCH SIZES (the engine's default: child sets).
 #   per config:  --kernel-trace --stats   -> <out>/config<C>/kernel_stats.csv, kernel_union.txt (union of dispatch intervals)
 #                --pmc FETCH_SIZE         -> FETCH_SIZE_per_kernel.csv   (own pass, MI355X_MICROARCH.md HBM section)
 #                --pmc WRITE_SIZE         -> WRITE_SIZE_per_kernel.csv   (own pass)
 #   once:        the same two counters over a 1 GiB copy (tools/pmc_calib.py) -> calib_*_per_kernel.csv
-# then tools/pmc_summarize.py -> <out>/config<C>/traffic.json, merged into <out>/traffic.json (= profiles/r5_traffic.json).
+# then tools/pmc_summarize.py -> <out>/config<C>/traffic.json, merged into <out>/traffic.json (= profiles/r6_traffic.json).
 #   usage (GPU box, repo root): tools/profile_configs.sh <out dir> [configs, default "2 1 3 5"]
 set -u
 OUT=$(realpath -m "${1:-gpurun_out/prof}")
