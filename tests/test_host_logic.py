@@ -277,6 +277,17 @@ def test_compact_bench_line_fits_and_carries_the_contract():
     # the normal record keeps the optional groups too
     line = b.compact_line(full, "bench_full.json")
     assert set(line["other_configs"]) == {"1", "3", "5"} and "ch2_us_per_block" in line["side"]
+    # round 6's record: what one call costs, the plan check, the host boundary, the literal config 5's roofline ride along
+    r6 = json.load(open(os.path.join(ROOT, "profiles", "r6_bench.json")))
+    line = b.compact_line(r6, "bench_full.json")
+    assert len(json.dumps(line)) < 4096
+    assert line["config"]["plan_as_tested"] is True
+    cu = line["call_us"]
+    assert cu["max"] / cu["block_period_us"] <= 0.25 and cu["tail_phase_groups"] == 8          # (round 5, all channels in phase: 0.81)
+    side = line["side"]
+    assert set(side["host_pcie_inclusive_Msamples_s"]) == {"1024", "4096"} and side["config5_literal_roofline"]["bound"] == "fp32_fma"
+    assert "bg_stream_Msamples_s" in side and set(line["other_configs"]) == {"1", "3", "5"}
+    assert "rocprof_committed" in r6["roofline"] and "frac_rocprof" not in json.dumps(line)    # (full record only)
     # a multi-rank record without roofline / cpu legs still serialises
     bare = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                  "vs_baseline", "dtype", "data", "config")}
