@@ -138,8 +138,22 @@ def test_plan_and_per_set_knobs_without_gpu(lib):
     assert reevr_amd.TUNING_DEFAULTS["subsets"] == -1 and reevr_amd.TUNING_DEFAULTS["kid_fence"] == 1
     t = reevr_amd.ConvolverSet(4, tune={"k1": 32, "subsets": 2})
     t.close()
-    for bad in (b"no_such=1", b"k1", b"k1=", b"=3", b"k1=3x"):
+    for bad in (b"no_such=1", b"k1", b"k1=", b"=3", b"k1=3x",
+                #  only plain decimal ints inside int range: no sign prefix but '-', no blanks, no other bases, no overflow
+                b"k1=+5", b"k1= 7", b"k1=0x10", b"subsets=99999999999", b"subsets=-99999999999", b"k1=-", b"k1=--1"):
         assert not lib.rvc_set_create_tuned(2, 0, 0, bad), bad
+    for good in (b"k1=-1", b"subsets=2147483647", b"tail_phases=8,tail_spread=0,host_zero_copy=-1,block_lanex=1,kid_stagger=0"):
+        h = lib.rvc_set_create_tuned(2, 0, 0, good)
+        assert h, good
+        lib.rvc_set_destroy(h)
+    # the staging rows of a set without device state: nothing to hand out (rvc_set_host_buffers returns 0, the arrays hold NULL)
+    h = lib.rvc_set_create(3, 0, 0)
+    ins, outs = (ctypes.c_void_p * 3)(1, 1, 1), (ctypes.c_void_p * 3)(1, 1, 1)
+    assert lib.rvc_set_host_buffers(h, ins, outs) == 0 and not any(ins) and not any(outs)
+    assert lib.rvc_set_host_buffers(None, ins, outs) == 0
+    p = _lib.Plan()
+    assert lib.rvc_set_plan(h, ctypes.byref(p), ctypes.sizeof(p)) == 1 and p.tail_phase_groups == 0 and p.tail_spread == 0
+    lib.rvc_set_destroy(h)
     h = lib.rvc_set_create_tuned(2, 0, 0, None)
     assert h
     lib.rvc_set_destroy(h)
