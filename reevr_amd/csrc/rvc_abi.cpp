@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -24,76 +25,110 @@
 // ever waits for it. Small sets (the plug-in's 2-4 channels) never touch it. (Callers that can write their audio into the staging
 // rows themselves -- rvc_set_host_buffers -- skip the copy altogether.)
 namespace {
+// [copy-crew begin] (tests/test_host_logic.py compiles this block alone and stresses it on the CPU)
+constexpr int kCrewWorkers = 15;
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
 struct CopyCrew {
   std::mutex busy;                       // one job at a time (try_lock: never waited for)
-  std::mutex m;
-  std::condition_variable wake, done;
+  std::mutex m;                          // sleepers only
+  std::condition_variable wake;
   std::vector<std::thread> workers;
-  const std::function<void(int)> *job = nullptr;
-  int next = 0, count = 0, active = 0;
-  unsigned long long epoch = 0;
-  bool stop = false;
+  std::atomic<const std::function<void(int)> *> job{nullptr};
+  std::atomic<int> count{0}, finished{0};
+  std::atomic<unsigned long long> next{~0ull};     // (epoch << 32) | next chunk index of the job of that epoch; ~0: no job
+  std::atomic<unsigned long long> epoch{0};
+  std::atomic<bool> stop{false};
+  // claim chunks of job `ep` until none is left. A claim is a compare-exchange on (epoch, index): a straggler of an earlier job
+  // finds another epoch (or ~0) there and leaves without having consumed anything.
+  void drain(const unsigned long long ep) {
+    for (;;) {
+      unsigned long long v = next.load(std::memory_order_acquire);
+      if ((v >> 32) != (ep & 0xffffffffull)) return;
+      const int i = (int)(v & 0xffffffffull);
+      if (i >= count.load(std::memory_order_relaxed)) return;
+      if (!next.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel)) continue;
+      (*job.load(std::memory_order_relaxed))(i);
+      finished.fetch_add(1, std::memory_order_acq_rel);
+    }
+  }
   void worker() {
     unsigned long long seen = 0;
-    std::unique_lock<std::mutex> lk(m);
     for (;;) {
-      wake.wait(lk, [&] { return stop || epoch != seen; });
-      if (stop) return;
-      seen = epoch;
-      ++active;
-      while (next < count) {
-        const int i = next++;
-        lk.unlock();
-        (*job)(i);
-        lk.lock();
+      // a caller in a block loop comes back within tens of microseconds: spin that long before going to sleep (a condition
+      // variable costs the NEXT job ~50 us per sleeper to wake)
+      for (int i = 0; i < 20000 && epoch.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed); ++i) cpu_relax();
+      if (epoch.load(std::memory_order_acquire) == seen) {
+        std::unique_lock<std::mutex> lk(m);
+        wake.wait(lk, [&] { return stop.load() || epoch.load(std::memory_order_acquire) != seen; });
       }
-      if (--active == 0) done.notify_all();
+      if (stop.load()) return;
+      seen = epoch.load(std::memory_order_acquire);
+      drain(seen);
     }
   }
   void start(int n) {
     for (int i = 0; i < n; ++i) workers.emplace_back([this] { worker(); });
   }
   ~CopyCrew() {
-    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    { std::lock_guard<std::mutex> lk(m); stop.store(true); }
     wake.notify_all();
     for (std::thread &t : workers) t.join();
   }
   // f(i) for i < n, the calling thread included
   void run(int n, const std::function<void(int)> &f) {
     if (n <= 1 || !busy.try_lock()) { for (int i = 0; i < n; ++i) f(i); return; }
-    if (workers.empty()) start(std::max(1, std::min(7, (int)std::thread::hardware_concurrency() / 2 - 1)));
-    std::unique_lock<std::mutex> lk(m);
-    job = &f; next = 0; count = n; ++epoch;
-    wake.notify_all();
-    while (next < count) {
-      const int i = next++;
-      lk.unlock();
-      f(i);
-      lk.lock();
+    if (workers.empty()) {
+      // crew size: the caller + up to kCrewWorkers helpers, never more than half the host's hardware threads; RVC_COPY_THREADS (read
+      // once, at the first large call) overrides it for measurements
+      int w = std::min(kCrewWorkers, (int)std::thread::hardware_concurrency() / 2 - 1);
+      if (const char *e = std::getenv("RVC_COPY_THREADS")) w = std::atoi(e) - 1;
+      start(std::max(1, std::min(w, 63)));
     }
-    done.wait(lk, [&] { return active == 0; });
-    job = nullptr;
-    lk.unlock();
+    const unsigned long long ep = (epoch.load(std::memory_order_relaxed) + 1) & 0xffffffffull;
+    job.store(&f, std::memory_order_relaxed);
+    count.store(n, std::memory_order_relaxed);
+    finished.store(0, std::memory_order_relaxed);
+    next.store(ep << 32, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(m); epoch.store(ep, std::memory_order_release); }
+    wake.notify_all();
+    drain(ep);
+    while (finished.load(std::memory_order_acquire) < n) cpu_relax();     // (chunks are tens of microseconds long)
+    next.store(~0ull, std::memory_order_release);                          // no straggler claims anything of this job from here on
     busy.unlock();
   }
 };
+// [copy-crew end]
 CopyCrew &copy_crew() { static CopyCrew c; return c; }
 constexpr size_t kCrewMinBytes = (size_t)1 << 20;   // below this one thread is faster than waking the crew
 
-// rows [0, nch) of `len` floats between the caller's per-channel buffers and the staging rows (max_len apart); a caller's pointer
-// that IS the staging row (rvc_set_host_buffers) is skipped
-void stage_rows(rvc_set *s, const float *const *in, float *const *out, size_t len) {
+// rows of `len` floats between the caller's per-channel buffers and the staging rows (max_len apart) of the `n` sets in `sets` --
+// a set's child sets in ONE job --, set k serving the caller's channels c0[k] ..; a caller's pointer that IS the staging row
+// (rvc_set_host_buffers) is skipped. Exactly one of in / out is given.
+void stage_rows(rvc_set *const *sets, const int *c0, int n, const float *const *in, float *const *out, size_t len) {
   const size_t bytes = len * sizeof(float);
-  auto one = [&](int c) {
+  int total = 0;
+  for (int k = 0; k < n; ++k) total += sets[k]->nch;
+  auto one = [&](int k, int c) {
+    rvc_set *s = sets[k];
     float *row = (in ? s->h_in : s->h_out) + (size_t)c * s->max_len;
-    if (in) { if (in[c] != row) std::memcpy(row, in[c], bytes); }
-    else if (out[c] && out[c] != row) std::memcpy(out[c], row, bytes);
+    if (in) { if (in[c0[k] + c] != row) std::memcpy(row, in[c0[k] + c], bytes); }
+    else if (out[c0[k] + c] && out[c0[k] + c] != row) std::memcpy(out[c0[k] + c], row, bytes);
   };
-  if ((size_t)s->nch * bytes < kCrewMinBytes) { for (int c = 0; c < s->nch; ++c) one(c); return; }
-  const int chunks = std::min(s->nch, 32);
-  copy_crew().run(chunks, [&](int i) {
-    for (int c = (int)((long long)s->nch * i / chunks), e = (int)((long long)s->nch * (i + 1) / chunks); c < e; ++c) one(c);
-  });
+  auto range = [&](int lo, int hi) {               // global channel indices [lo, hi) over the concatenated sets
+    int base = 0;
+    for (int k = 0; k < n && lo < hi; ++k) {
+      const int e = base + sets[k]->nch;
+      for (; lo < hi && lo < e; ++lo) one(k, lo - base);
+      base = e;
+    }
+  };
+  if ((size_t)total * bytes < kCrewMinBytes) { range(0, total); return; }
+  const int chunks = std::min(total, 64);
+  copy_crew().run(chunks, [&](int i) { range((int)((long long)total * i / chunks), (int)((long long)total * (i + 1) / chunks)); });
 }
 }  // namespace
 
@@ -310,21 +345,9 @@ void rvc_set_process_host_blocks_timed(rvc_set *s, const float *const *in, float
   }
 }
 
-void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
-  if (!s) return;
-  if (!s->kids.empty()) {
-    for (size_t k = 0; k < s->kids.size(); ++k) rvc_set_process_begin(s->kids[k], in ? in + s->kid_c0[k] : nullptr, len);
-    return;
-  }
-  s->pending_len = len;
-  s->pending_ok = false;
-  s->flag_count = 0;
-  if (len == 0 || !s->live || s->err != RVC_OK || !in) return;
-  if (len > s->max_len) return;   // refused: process_end writes zeros for this call; the handle stays usable
-                                  // (rvc_set_process splits long calls itself)
-  if (!use_device(s)) return;
+// process_begin behind the staging (h_in holds the call's input): copy-in, kernels, copy-out enqueued; false = nothing is pending
+static bool begin_core(rvc_set *s, size_t len) {
   const TuneScope tune_scope(s);
-  stage_rows(s, in, nullptr, len);
   // Per-block calls of SMALL sets (the latency path: one fused launch) skip both DMA copies: the pinned staging
   // buffers are device-visible, the kernel reads its 2 KB per channel over PCIe and writes the
   // result straight back; the host polls the flags its workgroups publish. Longer calls and many channels use DMA (a kernel
@@ -347,17 +370,45 @@ void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
   s->out_copy_len = 0;
   if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_begin");
   s->pending_ok = ok;
+  return ok;
+}
+// whether this call of `len` frames will run on the set at all (else process_end delivers zeros)
+static bool begin_accepts(rvc_set *s, const float *const *in, size_t len) {
+  s->pending_len = len;
+  s->pending_ok = false;
+  s->flag_count = 0;
+  if (len == 0 || !s->live || s->err != RVC_OK || !in) return false;
+  if (len > s->max_len) return false;   // refused: process_end writes zeros for this call; the handle stays usable
+                                        // (rvc_set_process splits long calls itself)
+  return use_device(s);
 }
 
-void rvc_set_process_end(rvc_set *s, float *const *out) {
-  if (!s || !out) return;
+void rvc_set_process_begin(rvc_set *s, const float *const *in, size_t len) {
+  if (!s) return;
   if (!s->kids.empty()) {
-    for (size_t k = 0; k < s->kids.size(); ++k) rvc_set_process_end(s->kids[k], out + s->kid_c0[k]);
+    // the children's staging in ONE job of the copy crew (a job costs its wake-up whatever its size), then child by child: copy-in
+    // and kernels of child k are enqueued while child k + 1 ...
+    std::vector<rvc_set *> &run = s->stage_sets;
+    std::vector<int> &c0 = s->stage_c0;
+    run.clear(); c0.clear();
+    for (size_t k = 0; k < s->kids.size(); ++k)
+      if (begin_accepts(s->kids[k], in, len)) { run.push_back(s->kids[k]); c0.push_back(s->kid_c0[k]); }
+    if (run.empty()) return;
+    stage_rows(run.data(), c0.data(), (int)run.size(), in, nullptr, len);
+    for (rvc_set *k : run) begin_core(k, len);
     return;
   }
+  if (!begin_accepts(s, in, len)) return;
+  const int zero = 0;
+  rvc_set *one[1] = {s};
+  stage_rows(one, &zero, 1, in, nullptr, len);
+  begin_core(s, len);
+}
+
+// wait for the output of the pending call to be in h_out; false = deliver zeros
+static bool end_wait(rvc_set *s) {
   const size_t len = s->pending_len;
-  s->pending_len = 0;
-  if (len == 0) return;
+  if (len == 0) return false;
   bool ok = s->pending_ok;
   if (ok && s->flag_count > 0) {
     // poll the completion flags the audio workgroups write behind their output stores
@@ -384,11 +435,40 @@ void rvc_set_process_end(rvc_set *s, float *const *out) {
     ok = hipEventSynchronize(s->ev_out) == hipSuccess;   // output copied back; later stream work may still run
     if (!ok) fail(s, RVC_ERR_HIP, hipGetLastError(), "process_end");
   }
-  if (ok) stage_rows(s, nullptr, out, len);
-  else
-    for (int c = 0; c < s->nch; ++c)
-      if (out[c]) std::memset(out[c], 0, len * sizeof(float));   // not initialised / empty IR / failed: zeros
   s->pending_ok = false;
+  return ok;
+}
+static void end_zeros(rvc_set *s, float *const *out, size_t len) {
+  for (int c = 0; c < s->nch; ++c)
+    if (out[c]) std::memset(out[c], 0, len * sizeof(float));   // not initialised / empty IR / failed: zeros
+}
+
+void rvc_set_process_end(rvc_set *s, float *const *out) {
+  if (!s || !out) return;
+  if (!s->kids.empty()) {
+    std::vector<rvc_set *> &run = s->stage_sets;
+    std::vector<int> &c0 = s->stage_c0;
+    run.clear(); c0.clear();
+    size_t len = 0;
+    for (size_t k = 0; k < s->kids.size(); ++k) {
+      rvc_set *c = s->kids[k];
+      const size_t l = c->pending_len;
+      if (l == 0) continue;
+      if (end_wait(c)) { run.push_back(c); c0.push_back(s->kid_c0[k]); len = l; }
+      else end_zeros(c, out + s->kid_c0[k], l);
+      c->pending_len = 0;
+    }
+    if (!run.empty()) stage_rows(run.data(), c0.data(), (int)run.size(), nullptr, out, len);
+    return;
+  }
+  const size_t len = s->pending_len;
+  if (len == 0) return;
+  const bool ok = end_wait(s);
+  s->pending_len = 0;
+  const int zero = 0;
+  rvc_set *one[1] = {s};
+  if (ok) stage_rows(one, &zero, 1, nullptr, out, len);
+  else end_zeros(s, out, len);
 }
 
 int rvc_set_host_buffers(rvc_set *s, float **in, float **out) {

@@ -266,6 +266,8 @@ struct rvc_set {
   int ev_free = 0;
   std::vector<const float *> in_ptrs;    // scratch of rvc_set_process (sized at create)
   std::vector<float *> out_ptrs;
+  std::vector<rvc_set *> stage_sets;     // scratch of the host-pointer calls of a set with children (reserved when the children are made)
+  std::vector<int> stage_c0;
 
   size_t pending_len = 0;        // rvc_set_process_begin without its _end yet
   bool pending_ok = false;

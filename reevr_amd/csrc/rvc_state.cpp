@@ -568,6 +568,7 @@ bool make_kids(rvc_set *s, int n) {
     c->kid_index = k; c->kid_count = n;
     s->kids.push_back(c);
     s->kid_c0.push_back(c0);
+    s->stage_sets.reserve((size_t)n); s->stage_c0.reserve((size_t)n);      // (no allocation on the process path)
     c0 += mine;
   }
   return true;

@@ -1054,10 +1054,11 @@ def test_device_entry_with_misaligned_views_and_strides():
             assert rel_rms(got[c], want[c]) <= TOL
 
 
-@pytest.mark.parametrize("slack", [0, 1, 2])
+@pytest.mark.parametrize("slack", [0, 1, 2, "1_phases"])
 def test_two_level_tiling_at_config3_geometry(slack):
     """(slack: what the tail's period of slack buys -- 0 the reference's structure, 1 the tail at block 16384 with delay 1 = what
-    sets of >= 256 channels run at this geometry, 2 half the zero-latency stage.)
+    sets of >= 256 channels run at this geometry, 2 half the zero-latency stage; 1_phases: 1 with the tail tiles in 8 channel
+    groups out of phase -- bench.py's config-3 plan but for the channel count.)
     BASELINE configs[2]'s geometry with the time tiling FORCED on both stages and many channels: head 256 / tail 8192,
     a 30 s @ 96 kHz IR on channel 0 (P_A = 64 zero-latency partitions, P_T = 350 tail partitions -> two-level tiles on
     both stages), 64 lock-step channels with IRs of different lengths, one process() per 256-frame block through the
@@ -1069,10 +1070,13 @@ def test_two_level_tiling_at_config3_geometry(slack):
     irs = [base[c % 2][:lens[c]].copy() for c in range(nch)]
     nblk = (352 + 24) * (tail // head)                       # all 350 tail partitions in use, then a few tiles more
     x = np.stack([synth.synth_input(head * nblk, 200 + c % 5) for c in range(nch)])
-    with reevr_amd.tuning(tail_slack=slack):
+    phases = 8 if slack == "1_phases" else -1
+    slack = 1 if slack == "1_phases" else slack
+    with reevr_amd.tuning(tail_slack=slack, tail_phases=phases):
         s = reevr_amd.ConvolverSet(nch, time_tiling="force")
         assert s.init(head, tail, irs, max_len=head), s.last_error_string
     assert (s.partitions(0), s.partitions(1), s.tail_block) == [(64, 350, 8192), (64, 175, 16384), (32, 351, 8192)][slack]
+    assert s.plan()["tail_phase_groups"] == (8 if phases > 0 else 1)
     assert s.tile_rows(0) > 8 and s.tile_rows(1) > 8         # two levels on both stages
     got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
     assert s.last_error == 0, s.last_error_string

@@ -316,3 +316,42 @@ def test_bare_gpus_n_builds_a_launcher_command(monkeypatch):
     with pytest.raises(SystemExit):
         b.self_launch(4, 8)
     assert "REEVR_BENCH_SAME_DEVICE" not in seen["env"] or os.environ.get("REEVR_BENCH_SAME_DEVICE") == "1"
+
+
+def test_copy_crew_runs_every_chunk_exactly_once(tmp_path):
+    """The staging crew of the host-pointer calls (rvc_abi.cpp CopyCrew: a few host threads that copy the channels' blocks into /
+    out of the pinned staging rows; chunk claims are a compare-exchange on (job epoch, index), workers spin briefly before they
+    sleep) compiled ALONE with g++ and stressed on the CPU: 30 000 jobs of 2 .. 200 chunks back to back and across worker
+    sleeps -- every chunk of every job exactly once, no chunk of a finished job ever again."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = open(os.path.join(ROOT, "reevr_amd", "csrc", "rvc_abi.cpp")).read()
+    body = src[src.index("// [copy-crew begin]"):src.index("// [copy-crew end]")]
+    main = """
+int main() {
+  CopyCrew crew;
+  std::vector<std::atomic<int>> hits(512);
+  unsigned rng = 12345;
+  long bad = 0;
+  for (int job = 0; job < 30000; ++job) {
+    rng = rng * 1664525u + 1013904223u;
+    const int n = 2 + (int)((rng >> 8) % 200);
+    for (int i = 0; i < 512; ++i) hits[i].store(0);
+    crew.run(n, [&](int i) { hits[i].fetch_add(1); if ((i & 7) == 0) for (volatile int k = 0; k < 200; ++k) {} });
+    for (int i = 0; i < 512; ++i) bad += hits[i].load() != (i < n ? 1 : 0);
+    if ((job % 3000) == 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));   // the workers fall asleep
+  }
+  std::printf("bad %ld\\n", bad);
+  return bad != 0;
+}
+"""
+    inc = "\n".join("#include <%s>" % h for h in ("algorithm", "atomic", "chrono", "condition_variable", "cstdio", "cstdlib", "functional",
+                                                    "mutex", "thread", "vector"))
+    cpp = tmp_path / "crew.cpp"
+    cpp.write_text(inc + "\n" + body + main)
+    exe = tmp_path / "crew"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", str(cpp), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], env=dict(os.environ, RVC_COPY_THREADS="4"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
