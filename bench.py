@@ -283,7 +283,9 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
             # patch: the sweep row + the recent partitions (a group's first block needs none when its sweep is not spread), 1 row out
             depth = [j + (l1 if g == 0 else l2) for g in range(max(1, KT // K2)) for j in range(K2)]
             per = [2 * d + 2 for d in depth if d > 0]
-            exe["fir_tail"] = float(np.mean(per)) * row_t / G
+            exe["fir_tail"] = float(np.mean(per)) * row_t
+            if G > 1:      # phase groups: ONE patch launch per tail block over all channels, every group at its own depth (depth 0: the row is copied)
+                exe["fir_tail"] = float(np.mean([2 * d + 2 for d in depth])) * row_t
         else:
             exe["fir_tail"] = (2.0 * PT + 1) * row_t
         exe["fft_fwd_tail"] = float(n1 * (4 * 2 * tail_x + 8 * tail_x))
@@ -759,7 +761,7 @@ def write_full(full: dict, where: str = ""):
 
 
 # kernel family -> a substring of the rocprofv3 kernel name (the committed kernel-trace summaries list C++ names)
-FAMILY_KERNEL = {"fused_block": "k_fused_block", "fir_tail": "k_fdl_patch<1", "fir_head": "k_fdl_patch<0", "fft_fwd_tail": "k_fft8_fwd",
+FAMILY_KERNEL = {"fused_block": "k_fused_block", "fir_tail": "k_fdl_patch", "fir_head": "k_fdl_patch<0", "fft_fwd_tail": "k_fft8_fwd",
                  "fft_inv_tail": "k_fft8_inv"}
 
 

@@ -77,6 +77,16 @@ struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency
                             // them are in this launch): kernel form and cache policy are chosen for the whole stage, so slices agree
 };
 
+// Patches of the phase groups of a tail stage in ONE launch (launch_fdl_patch_groups): channels [c0, c0 + n) of group g add P
+// recent partitions to the row Yadd + c * yadd_chan_stride (c = the channel's index in the launch); P = 0 copies the row.
+struct PatchGroups {
+  static constexpr int kMax = 8;
+  int n_groups;
+  int c0[kMax], n[kMax], P[kMax];
+  const float2 *Yadd[kMax];
+  long long yadd_chan_stride[kMax];
+};
+
 struct InvArgs {            // spectrum row(s) -> last B samples of the inverse transform (overlap-save)
   const float2 *Y;          // [channel][M rows][B]
   long long y_chan_stride;
@@ -153,6 +163,9 @@ struct IngestArgs {
 hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int channels, hipStream_t st);
 hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int channels, hipStream_t st);
 hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st);
+// one single-row patch launch over all `channels`: a.H / a.X / a.Y / a.k0 / a.delay / a.B as for launch_fir, partitions and base row per
+// channel group from g (a.P / a.Yadd are ignored); every group's P <= the patch kernel's limit (kSweepRows - 1 + kSweepLagMax)
+hipError_t launch_fdl_patch_groups(const FirArgs &a, const PatchGroups &g, int channels, hipStream_t st);
 // whether launch_fft_fwd honours FwdArgs::ring_out for this block size / precision
 bool fwd_appends_ring(int logB);
 // fused single-block step; supported for 6 <= logB <= 13 (float transforms only)

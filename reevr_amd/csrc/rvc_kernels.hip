@@ -2037,10 +2037,19 @@ __device__ __forceinline__ void fdl_patch_n(const FirArgs &a, const int bx, cons
 }
 __device__ __forceinline__ void fdl_patch_body(const FirArgs &a, const int bx, const int c) { fdl_patch_n<kPatchMax>(a, bx, c); }
 // dispatch on the (launch-uniform) partition count
+// P = 0: the base row as it is (a phase group whose sweep row is complete: the row moves to where the inverse transform reads)
+template <bool NT>
+__device__ __forceinline__ void fdl_patch_copy(const FirArgs &a, const int bx, const int c) {
+  const int bin = bx * 512 + (int)threadIdx.x * 2;
+  if (bin >= a.B) return;
+  const float4 y = patch_ld<NT>(a.Yadd + (long long)c * a.yadd_chan_stride + bin);
+  *reinterpret_cast<float4 *>(a.Y + (long long)c * a.y_chan_stride + bin) = y;
+}
 template <bool NT>
 __device__ __forceinline__ void fdl_patch_any(const FirArgs &a, const int bx, const int c) {
   static_assert(kPatchMax == 10, "cases below");
   switch (a.P) {
+    case 0: fdl_patch_copy<NT>(a, bx, c); break;
     case 1: fdl_patch_n<1, NT>(a, bx, c); break;
     case 2: fdl_patch_n<2, NT>(a, bx, c); break;
     case 3: fdl_patch_n<3, NT>(a, bx, c); break;
@@ -2059,6 +2068,20 @@ template <int STAGE, bool NT>
 __global__ void __launch_bounds__(256) k_fdl_patch(const FirArgs a, const int rot) {
   // rot: channel c takes its 512-bin tiles in the order rotated by c (every XCD sees every part of the rows: rvc_sweep.hip)
   fdl_patch_any<NT>(a, rot ? (int)((blockIdx.x + blockIdx.y) % gridDim.x) : (int)blockIdx.x, blockIdx.y);
+}
+
+// The patches of all phase groups of a tail stage in one launch: the channel picks its group (a scalar walk over <= 8 entries,
+// uniform per workgroup), the group its partition count and base row.
+template <int STAGE, bool NT>
+__global__ void __launch_bounds__(256) k_fdl_patch_groups(const FirArgs a0, const PatchGroups g, const int rot) {
+  const int c = blockIdx.y;
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < PatchGroups::kMax; ++i)
+    if (i < g.n_groups && c >= g.c0[i]) k = i;
+  FirArgs a = a0;
+  a.P = g.P[k]; a.Yadd = g.Yadd[k]; a.yadd_chan_stride = g.yadd_chan_stride[k];
+  fdl_patch_any<NT>(a, rot ? (int)((blockIdx.x + blockIdx.y) % gridDim.x) : (int)blockIdx.x, c);
 }
 
 // One launch per block of the streaming path: workgroups [0, n_audio) run block k's audio path
@@ -2530,6 +2553,18 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
       break;
   }
 #undef RVC_FIR_CASE
+  return hipGetLastError();
+}
+
+hipError_t launch_fdl_patch_groups(const FirArgs &a, const PatchGroups &g, int channels, hipStream_t st) {
+  if (channels <= 0 || g.n_groups <= 0 || (a.B % 2) != 0) return hipErrorInvalidValue;
+  for (int i = 0; i < g.n_groups; ++i)
+    if (g.P[i] < 0 || g.P[i] > kPatchMax || !g.Yadd[i]) return hipErrorInvalidValue;
+  const dim3 grid((a.B + 511) / 512, channels), block(256);
+  const bool nt = launch_tune().patch_nt != 0 && (long long)channels * a.B >= (1ll << 20);
+  const int rot = (grid.x >= 8 && launch_tune().tile_rot) ? 1 : 0;
+  if (a.tag == 0) { if (nt) RVC_LAUNCH((k_fdl_patch_groups<0, true>), grid, block, 0, st, a, g, rot); else RVC_LAUNCH((k_fdl_patch_groups<0, false>), grid, block, 0, st, a, g, rot); }
+  else { if (nt) RVC_LAUNCH((k_fdl_patch_groups<1, true>), grid, block, 0, st, a, g, rot); else RVC_LAUNCH((k_fdl_patch_groups<1, false>), grid, block, 0, st, a, g, rot); }
   return hipGetLastError();
 }
 

@@ -247,6 +247,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
     // of a second-level group or of a tile in any tail period, and sweeps over ITS channels only; every group patches at its own
     // depth (a group whose sweep row is complete copies it) into T.Y, which ONE inverse launch then reads for all channels.
     Tile &t = s->tT;
+    rvc::PatchGroups pg{};
     for (int p = 0; p < t.G; ++p) {
       const Tile::Phase &q = t.ph[p];
       if (q.n <= 0) continue;
@@ -273,22 +274,18 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
         RVC_CK(rvc::launch_fdl_sweep(w, q.n, st));
         t.s0 = g0;
       }
+      // the group's entry of the one patch launch below: its sweep row + the partitions whose input arrived since (none: a copy)
       long long stride = 0;
       const float2 *row = tile_row(s, true, m_lo, &stride);
-      const long long recent = m_lo - g0;
-      if (recent > 0) {
-        rvc::FirArgs f = r;
-        f.P = (int)std::min<long long>(recent, T.P);
-        f.Yadd = row; f.yadd_chan_stride = stride;
-        f = ranged(f);
-        Timer tm(s, 5, st);
-        RVC_CK(rvc::launch_fir(f, q.n, st));
-      } else {                                       // the group's first block: its sweep row is complete
-        RVC_CK(hipMemcpy2DAsync(T.Y + (long long)q.c0 * r.y_chan_stride, sizeof(float2) * (size_t)r.y_chan_stride,
-                                row + (long long)q.c0 * stride, sizeof(float2) * (size_t)stride, sizeof(float2) * (size_t)tb,
-                                (size_t)q.n, hipMemcpyDeviceToDevice, st));
-      }
+      const int gi = pg.n_groups++;
+      pg.c0[gi] = q.c0; pg.n[gi] = q.n;
+      pg.P[gi] = (int)std::min<long long>(m_lo - g0, T.P);
+      pg.Yadd[gi] = row; pg.yadd_chan_stride[gi] = stride;
       t.store_phase(p);
+    }
+    {
+      Timer tm(s, 5, st);
+      RVC_CK(rvc::launch_fdl_patch_groups(r, pg, s->nch, st));
     }
   } else if (tiled_row) {
     // block-synchronous streaming, time-tiled: output block m_lo lies in the current tile -- whose sweeps have run, were spread over

@@ -46,7 +46,7 @@ def family(name: str, head_log: int, tail_log: int):
     m = re.search(r"k_fir_row<(\d)>", name)
     if m:
         return "premultiply" if m.group(1) == "0" else "fir_tail"
-    m = re.search(r"k_fdl_patch<(\d)", name)
+    m = re.search(r"k_fdl_patch(?:_groups)?<(\d)", name)     # (_groups, round 6: the patches of all phase groups of a tail stage in one launch)
     if m:
         return PATCH0_FAMILY if m.group(1) == "0" else "fir_tail"
     m = re.search(r"k_fir(?:_lds)?<(?:\d+, )?(\d)>", name)
