@@ -244,8 +244,9 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
   const bool tiled_row = s->tT.on && r.M == 1;
   if (tiled_row && s->tT.G > 1) {
     // Phase groups (Tile::G): every group of channels runs the schedule below on its own clock -- exactly one group is at the start
-    // of a second-level group or of a tile in any tail period, and sweeps over ITS channels only; every group patches at its own
-    // depth (a group whose sweep row is complete copies it) into T.Y, which ONE inverse launch then reads for all channels.
+    // of a second-level group or of a tile in any tail period, and sweeps over ITS channels only; then ONE patch launch for all
+    // channels, every group at its own depth (rvc::PatchGroups; a group whose sweep row is complete has depth 0: the row is
+    // copied), into T.Y, which ONE inverse launch reads.
     Tile &t = s->tT;
     rvc::PatchGroups pg{};
     for (int p = 0; p < t.G; ++p) {
