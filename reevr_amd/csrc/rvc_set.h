@@ -38,6 +38,8 @@ constexpr int kWidenMinPShort = 48;
 // noise that breaks the rule is the inverse transform's (its small outputs share a transform with outputs of 1.5e7) --; BASELINE
 // config 2 at 4096 channels: 17.06 (float) / 16.64 / 16.65 (inverse: -2.4 %) / 16.15 (both) Gsamples/s.
 constexpr int kMix64Default = 2;
+// a stage's zero-padded time-domain IR partitions stay allocated between inits only below this size (upload_ir_stage)
+constexpr size_t kKeepIrBytesMax = (size_t)256 << 20;
 // Spread tail sweeps (Tile::lag1 / lag2; rvc_schedule.cpp "uniform call cost"): lock-step sets of at least kSpreadMinChannels channels
 // without a second stream issue the tail stage's sweeps a tail period early, in channel slices behind the per-block launches.
 // kSpreadDefault: bit 0 first-level sweeps, bit 1 second-level sweeps. Measured on MI355X: profiles/r6_spread.txt

@@ -293,6 +293,10 @@ bool upload_ir_stage(rvc_set *s, Stage &g, const float *const *irs, const std::v
   hipError_t e = rvc::launch_fft_fwd(g.logB, ir64, a, g.hrows(), s->nch, s->st_main);
   if (e == hipSuccess) e = hipStreamSynchronize(s->st_main);
   if (e != hipSuccess) return fail(s, RVC_ERR_HIP, e, "IR spectra");
+  // The time-domain partitions are kept so that an IR swap with unchanged geometry -- the plug-in's hot-swap -- allocates nothing.
+  // For sets of thousands of channels they are gigabytes (BASELINE config 3 at 2048 channels: 24 GB beside 126 GB of spectra and
+  // delay lines) and an allocation of a few milliseconds at the next swap is nothing beside the upload: given back.
+  if (sizeof(float) * (size_t)s->nch * padded >= kKeepIrBytesMax) { dev_free(s, g.d_ir); g.d_ir = nullptr; }
   return true;
 }
 
