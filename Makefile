@@ -1,7 +1,7 @@
 # Top-level convenience targets (plain make; no cmake needed).
 #   make            libreevr_amd.so (hipcc, gfx950) + the oracle's C restatement
 #   make ref        the untouched reference built where it lies (needs /root/reference)
-#   make example    examples/host_block_loop (g++, links the C ABI)
+#   make example    examples/host_block_loop + host_many_channels (g++, link the C ABI)
 #   make test       CPU test-suite;   make test-gpu   on an MI355X
 HIPCC ?= /opt/rocm/bin/hipcc
 CSRC  := reevr_amd/csrc
@@ -21,6 +21,8 @@ ref:
 example: $(LIB)
 	g++ -O2 -std=c++17 -I include examples/host_block_loop.cpp -L $(CSRC) -lreevr_amd \
 	  -Wl,-rpath,'$$ORIGIN/../$(CSRC)' -o examples/host_block_loop
+	g++ -O2 -std=c++17 -I include examples/host_many_channels.cpp -L $(CSRC) -lreevr_amd \
+	  -Wl,-rpath,'$$ORIGIN/../$(CSRC)' -o examples/host_many_channels
 
 test: all
 	python -m pytest tests -q -m "not gpu"
@@ -29,7 +31,7 @@ test-gpu: all
 	python -m pytest tests -q -m gpu
 
 clean:
-	rm -f $(LIB) examples/host_block_loop
+	rm -f $(LIB) examples/host_block_loop examples/host_many_channels
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle ref example test test-gpu clean
