@@ -185,6 +185,12 @@ def test_cpp_shim_headers_compile():
                         "-L", libdir, "-lreevr_amd", f"-Wl,-rpath,{libdir}"], check=True)
         r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stdout + r.stderr
+        # the plain-C++ host examples build against the same headers and library (host_many_channels: rvc_set_host_buffers, rvc_set_plan)
+        for ex in ("host_block_loop", "host_many_channels"):
+            subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", ex + ".cpp"),
+                            "-o", os.path.join(d, ex), "-L", libdir, "-lreevr_amd", f"-Wl,-rpath,{libdir}"], check=True)
+        r = subprocess.run([os.path.join(d, "host_many_channels"), "4", "2", "1"], capture_output=True, text=True, timeout=120)
+        assert r.returncode in (0, 2), r.stdout + r.stderr          # (2: no GPU here -- "this engine has no CPU fallback")
 
 
 from oracle.ref_glue import GLUE_EXE, REF_SC, build_reference_glue  # noqa: E402  (the recipe lives with the checker, not with the tests)
