@@ -6,6 +6,7 @@
 // (:129-137), and the object lifetime of Convolver (src/dsp/Convolver.cpp:56-75).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "rvc_set.h"
@@ -23,6 +24,10 @@ bool fail(rvc_set *s, int code, hipError_t e, const char *what) {
 }
 
 bool use_device(rvc_set *s) {
+  // (hipGetDevice is a thread-local read; hipSetDevice takes a runtime lock: skipped when the thread is on the set's device already)
+  static const bool always = std::getenv("RVC_SETDEVICE_ALWAYS") != nullptr;     // (measurement: the pre-round-6 behaviour)
+  int cur = -1;
+  if (!always && hipGetDevice(&cur) == hipSuccess && cur == s->device) return true;
   hipError_t e = hipSetDevice(s->device);
   if (e != hipSuccess) return fail(s, RVC_ERR_NO_DEVICE, e, "hipSetDevice");
   return true;
