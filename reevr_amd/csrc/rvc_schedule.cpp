@@ -169,10 +169,9 @@ bool ensure_tail_spectra(rvc_set *s, long long lo, hipStream_t st) {
 // it reads exists ONE TAIL PERIOD earlier: it is planned right behind the tail job of the block before (plan_next_tail_sweep) and
 // issued in channel slices behind the per-block launches of the period in between (issue_tail_slices, one slice per call, spaced
 // over the period); whatever is left when its first block is due is issued then (flush_tail_sweep: ragged call patterns).
-bool launch_sweep_slice(rvc_set *s, Tile &t, int count, hipStream_t st) {
-  Tile::Pending &q = t.pend;
+bool launch_sweep_slice(rvc_set *s, Tile::Pending &q, int count, hipStream_t st) {
   while (q.on && count-- > 0) {
-    const int c0 = q.next, n = std::min(q.per, s->nch - c0);
+    const int c0 = q.base + q.next, n = std::min(q.per, q.span - q.next);
     rvc::FirArgs a = q.a;
     a.H += (long long)c0 * a.h_chan_stride; a.X += (long long)c0 * a.x_chan_stride; a.Y += (long long)c0 * a.y_chan_stride;
     if (a.Ybase) a.Ybase += (long long)c0 * a.ybase_chan_stride;
@@ -182,46 +181,70 @@ bool launch_sweep_slice(rvc_set *s, Tile &t, int count, hipStream_t st) {
       RVC_CK(rvc::launch_fdl_sweep(a, n, st));
     }
     q.next += n; ++q.issued;
-    if (q.next >= s->nch) q.on = false;
+    if (q.next >= q.span) q.on = false;
   }
   return true;
 }
-bool flush_tail_sweep(rvc_set *s, hipStream_t st) { return launch_sweep_slice(s, s->tT, 1 << 30, st); }
+bool flush_tail_sweep(rvc_set *s, hipStream_t st) { return launch_sweep_slice(s, s->tT.pend, 1 << 30, st); }
 // one per-block call has been enqueued: the slices that are due by now (evenly over the calls of a tail period but the last)
-bool issue_tail_slices(rvc_set *s) {
-  Tile::Pending &q = s->tT.pend;
+static bool issue_due(rvc_set *s, Tile::Pending &q) {
   if (!q.on) return true;
   ++q.calls;
   const long long due = ((long long)q.calls * q.slices + q.budget - 1) / q.budget;
-  return launch_sweep_slice(s, s->tT, (int)std::min<long long>(due, q.slices) - q.issued, s->st_main);
+  return launch_sweep_slice(s, q, (int)std::min<long long>(due, q.slices) - q.issued, s->st_main);
+}
+bool issue_tail_slices(rvc_set *s) {
+  Tile &t = s->tT;
+  if (!issue_due(s, t.pend)) return false;
+  for (int p = 0; p < t.G && t.G > 1; ++p)
+    if (!issue_due(s, t.ph[p].pend)) return false;
+  return true;
 }
 // calls of a tail period that can carry a slice: all but the one that completes the tail block (it carries the tail job)
 static int slice_budget(const rvc_set *s) {
   return std::max(1, (int)std::max<long long>(1, (long long)s->T.B / (long long)s->A.B) - 1);
 }
-static int slice_channels(const rvc_set *s) {
-  const int want = std::max(1, std::min({slice_budget(s), 16, s->nch}));
-  return (s->nch + want - 1) / want;
+static int slice_channels(const rvc_set *s, int span) {
+  const int want = std::max(1, std::min({slice_budget(s), 16, span}));
+  return (span + want - 1) / want;
 }
-int sweep_slices(const rvc_set *s) { const int per = slice_channels(s); return (s->nch + per - 1) / per; }
-void plan_sweep(rvc_set *s, Tile &t, const rvc::FirArgs &a, int timer_id) {
-  Tile::Pending &q = t.pend;
+int sweep_slices(const rvc_set *s) {
+  const int span = s->tT.G > 1 ? std::max(1, s->tT.ph[0].n) : s->nch;
+  const int per = slice_channels(s, span);
+  return (span + per - 1) / per;
+}
+// a sweep over channels [base, base + span) to be issued in slices by the calls to come
+void plan_sweep(rvc_set *s, Tile::Pending &q, const rvc::FirArgs &a, int timer_id, int base, int span) {
   q = Tile::Pending();
-  q.on = true; q.a = a; q.timer_id = timer_id;
+  q.on = true; q.a = a; q.timer_id = timer_id; q.base = base; q.span = span;
   q.budget = slice_budget(s);
-  q.per = slice_channels(s);
-  q.slices = sweep_slices(s);
+  q.per = slice_channels(s, span);
+  q.slices = (span + q.per - 1) / q.per;
 }
 // behind the tail job of block m: the sweep block m + 1 will need, if it is a spread one
 void plan_next_tail_sweep(rvc_set *s, long long m) {
   Tile &t = s->tT;
   const long long next = m + 1, td = s->T.delay;
+  if (t.G > 1) {                   // phase groups: a group whose tile ends with block m (first-level sweeps only)
+    if (!t.lag1) return;
+    for (int p = 0; p < t.G; ++p) {
+      Tile::Phase &q = t.ph[p];
+      if (q.n <= 0) continue;
+      t.load_phase(p);
+      if (!t.holds(next)) {
+        t.start(next, t.K1);
+        plan_sweep(s, q.pend, sweep1_args(s, true, next, next - td - t.lag1), 10, q.c0, q.n);
+        t.store_phase(p);
+      }
+    }
+    return;
+  }
   if (!t.holds(next)) {
     if (!t.lag1) return;
     t.start(next, t.K1);
-    plan_sweep(s, t, sweep1_args(s, true, next, next - td - t.lag1), 10);
+    plan_sweep(s, t.pend, sweep1_args(s, true, next, next - td - t.lag1), 10, 0, s->nch);
   } else if (t.K1 > rvc::kSweepRows && t.group(next) == next && t.s0 != next && t.lag2) {
-    plan_sweep(s, t, sweep2_args(s, true, next), 12);
+    plan_sweep(s, t.pend, sweep2_args(s, true, next), 12, 0, s->nch);
     t.s0 = next;
   }
 }
@@ -261,10 +284,11 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
         return a;
       };
       t.load_phase(p);
+      if (!launch_sweep_slice(s, t.ph[p].pend, 1 << 30, st)) return false;     // (what the calls in between did not carry of a spread sweep)
       if (!t.holds(m_lo)) {
         const int len = t.fresh ? std::max(1, t.K1 - q.phi) : t.K1;
         t.start(m_lo, len);
-        const rvc::FirArgs w = ranged(sweep1_args(s, true, m_lo, m_lo - td));
+        const rvc::FirArgs w = ranged(sweep1_args(s, true, m_lo, m_lo - td - t.lag1));
         Timer tm(s, 10, st);
         RVC_CK(rvc::launch_fdl_sweep(w, q.n, st));
       }
@@ -280,7 +304,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
       const float2 *row = tile_row(s, true, m_lo, &stride);
       const int gi = pg.n_groups++;
       pg.c0[gi] = q.c0; pg.n[gi] = q.n;
-      pg.P[gi] = (int)std::min<long long>(m_lo - g0, T.P);
+      pg.P[gi] = (int)std::min<long long>(m_lo - g0 + (g0 == t.t0 ? t.lag1 : 0), T.P);   // (a spread first-level sweep left its newest row out)
       pg.Yadd[gi] = row; pg.yadd_chan_stride[gi] = stride;
       t.store_phase(p);
     }

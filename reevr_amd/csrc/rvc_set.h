@@ -54,6 +54,11 @@ constexpr bool kKidStaggerDefault = false;
 // channels, cost of the worst per-block call / rate: in phase 8.6 ms / 18.26 Gsamples/s; 2 groups 4.6 / 18.20; 4: 3.0 / 18.40;
 // 8: 1.8 ms / 18.21 -- against spread sweeps: first level 3.8 / 17.88, both levels 1.3 ms / 17.10 (a partition more per patch)
 constexpr int kPhasesDefault = 8;
+// ... and where a tail period is at least this many calls long, each group's first-level sweep would ALSO be spread over the calls of
+// the period before (Tile::lag1 with phase groups; knob tail_spread = 1 on top of the phase groups). Measured on MI355X
+// (profiles/r6_call_cost.txt): BASELINE config 3 (64 calls per tail period, block period 2.67 ms) worst call 2.13 -> 1.18 ms, p99 1.06 ->
+// 0.64 ms, rate 11.95 -> 11.79 Gsamples/s (-1.4 %); config 2 (16 calls) 1.46 -> 1.17 ms at -3 %. Off by default (no geometry is that long).
+constexpr int kSpreadPhasesMinCalls = 1 << 30;
 
 inline size_t next_pow2(size_t v) {   // Utilities.h:280-289
   size_t p = 1;
@@ -115,10 +120,11 @@ struct Tile {
   int first_len = 0;             // length of the first tile after init / clear() (0 = K1): the children of a set start their tiles
                                  // out of phase, so that their un-spread sweeps fall into different calls
   bool fresh = true;             // no tile since init / clear() yet
-  struct Pending {               // a spread sweep, partly issued: channels [next, nch) are still to be launched
+  struct Pending {               // a spread sweep over channels [base, base + span), partly issued: [base + next, base + span) are still to be launched
     bool on = false;
     rvc::FirArgs a{};
     int timer_id = 0;
+    int base = 0, span = 0;
     int next = 0, per = 0, calls = 0, slices = 0, issued = 0, budget = 0;
   } pend;
   // Phase groups (tail stage of many-channel sets, rvc_schedule.cpp "uniform call cost"): the channels of the set are dealt to G
@@ -130,13 +136,13 @@ struct Tile {
   // works on it (load_phase / store_phase); the zero-latency stage has one group and uses them directly.
   static constexpr int kMaxPhases = 8;
   int G = 1;
-  struct Phase { long long t0 = -1, end = -1, s0 = -1; bool fresh = true; int phi = 0; int c0 = 0, n = 0; } ph[kMaxPhases];
+  struct Phase { long long t0 = -1, end = -1, s0 = -1; bool fresh = true; int phi = 0; int c0 = 0, n = 0; Pending pend; } ph[kMaxPhases];
   void load_phase(int p) { t0 = ph[p].t0; end = ph[p].end; s0 = ph[p].s0; fresh = ph[p].fresh; }
   void store_phase(int p) { ph[p].t0 = t0; ph[p].end = end; ph[p].s0 = s0; ph[p].fresh = fresh; }
   void start(long long b, int len) { t0 = b; end = b + len; s0 = -1; fresh = false; }
   void drop() {
     t0 = s0 = end = -1; pend.on = false;
-    for (Phase &q : ph) q.t0 = q.s0 = q.end = -1;
+    for (Phase &q : ph) { q.t0 = q.s0 = q.end = -1; q.pend.on = false; }
   }
   void restart() {                              // init / clear(): the next tile is a first tile again
     drop(); fresh = true;

@@ -503,7 +503,14 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     // 8: one group per patch depth; spread over the K1 blocks of a tile: one first-level sweep every K1 / G periods)
     int G = s->tune.tail_phases >= 0 ? s->tune.tail_phases : (nch_all >= kSpreadMinChannels ? kPhasesDefault : 1);
     G = std::max(1, std::min({G, Tile::kMaxPhases, s->nch}));
-    if (!tT.on || tT.lag1 || tT.lag2) G = 1;               // (spread sweeps and phase groups are alternatives)
+    if (!tT.on) G = 1;
+    if (G > 1) {
+      // with phase groups only the FIRST-level sweeps are ever spread (a group's second-level sweep is an eighth of a small launch):
+      // by knob, or by default where a tail period is many calls long
+      const long long cpp = A.B ? (long long)tb / (long long)A.B : 1;
+      tT.lag2 = 0;
+      if (s->tune.tail_spread < 0) tT.lag1 = (can && cpp >= kSpreadPhasesMinCalls) ? 1 : 0;
+    }
     tT.G = G;
     for (int p = 0; p < G; ++p) {
       Tile::Phase &q = tT.ph[p];

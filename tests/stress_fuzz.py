@@ -20,7 +20,8 @@ for seed in range(first, first + count):
             # round 6: the tail tiles in channel groups out of phase (what sets of >= 256 channels run), and spread sweeps
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_force2_k32")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_shrink_force2")),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_widen")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_force")),
-            (T.test_fuzz_block_synchronous_time_tiling, (seed, "spread3_force2")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "spread1_force2_k32"))]
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "spread3_force2")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "spread1_force2_k32")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "phspread_force2_k32")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "phspread_shrink_force2"))]
     for fn, a in jobs:
         runs += 1
         if os.environ.get("STRESS_LOG"):

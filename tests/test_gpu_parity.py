@@ -688,7 +688,8 @@ def test_fuzz_geometry_and_call_pattern(seed, tiling):
 
 @pytest.mark.parametrize("tiling", [True, False, "force", "force2", "force2_k32", "widen", "shrink_force2",
                                     "spread1_force2_k32", "spread3_force2", "spread3_shrink_force2", "spread3_widen", "spread2_force2_k32",
-                                    "phases_force2_k32", "phases_force2", "phases_shrink_force2", "phases_widen", "phases_force"])
+                                    "phases_force2_k32", "phases_force2", "phases_shrink_force2", "phases_widen", "phases_force",
+                                    "phspread_force2_k32", "phspread_shrink_force2", "phspread_widen"])
 @pytest.mark.parametrize("seed", list(range(24)) + [226])   # 226: 3 tail partitions on 4 sweep waves (a wave without work)
 def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     """The plug-in's calling pattern -- one call per host block, now and then a ragged one, several calls inside one
@@ -702,6 +703,8 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
         spread, tiling = int(tiling[6]), tiling[8:]
     elif str(tiling).startswith("phases_"):      # the tail tiles in channel groups out of phase (tail_phases; one group per channel here)
         phases, tiling = 8, tiling[7:]
+    elif str(tiling).startswith("phspread_"):    # ... with every group's first-level sweep spread over the calls of the period before
+        phases, spread, tiling = 8, 1, tiling[9:]
     rng = np.random.RandomState(4200 + seed)
     head = int(rng.choice([64, 128, 256, 512]))
     tail = int(rng.choice([2 * head, 4 * head, 16 * head]))
@@ -739,7 +742,7 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
         s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling="force2" if tiling == "force2_k32" else tiling, fft_f32=slack > 0)
         assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
     if spread and s.tile_rows(1):
-        assert s.plan()["tail_spread"] == (spread if s.tile_rows(1) > 8 else spread & 1)
+        assert s.plan()["tail_spread"] == ((spread if s.tile_rows(1) > 8 else spread & 1) if not phases else spread & 1)
     if phases and s.tile_rows(1):
         assert s.plan()["tail_phase_groups"] == min(nch, 8)
     if slack == 1:

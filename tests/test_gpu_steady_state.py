@@ -105,7 +105,7 @@ def test_config2_plan_steady_state_vs_oracle():
         assert rel_rms(got[c][lo:], want[lo:]) <= TOL, c
 
 
-@pytest.mark.parametrize("spread,stagger,phases", [(1, 0, 1), (3, 1, 1), (2, 1, 1), (0, 0, 8), (0, 0, 4)])
+@pytest.mark.parametrize("spread,stagger,phases", [(1, 0, 1), (3, 1, 1), (2, 1, 1), (0, 0, 8), (0, 0, 4), (1, 0, 8)])
 def test_config2_geometry_spread_tail_sweeps_vs_oracle(spread, stagger, phases):
     """The same set with the tail stage's sweeps SPREAD (knob tail_spread: bit 0 the 32-block first-level sweeps, bit 1 the
     second-level ones: issued a tail period early in 15 channel slices behind the per-block launches, their newest row left to

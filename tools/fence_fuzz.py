@@ -39,13 +39,14 @@ for seed in [226] + list(range(nseeds)):
     head, tail, nch, irs, sched, x = case(seed)
     # force2_k32: first-level tiles of 32 blocks = the LDS-fed sweeps; widen / shrink: the delay-1 tail stage of many-channel sets
     # round 6: phases = the tail tiles in channel groups out of phase (launches on channel sub-ranges); spread3 = sweeps in channel slices
-    for tiling in (False, True, "force", "force2", "force2_k32", "widen", "shrink", "phases", "phases_shrink", "spread3"):
-        slack = {"widen": 1, "shrink": 2, "phases_shrink": 2}.get(tiling, -1)
-        extra = dict(tail_phases=8) if str(tiling).startswith("phases") else (dict(tail_spread=3) if tiling == "spread3" else {})
+    for tiling in (False, True, "force", "force2", "force2_k32", "widen", "shrink", "phases", "phases_shrink", "spread3", "phases_spread"):
+        slack = {"widen": 1, "shrink": 2, "phases_shrink": 2, "phases_spread": 2}.get(tiling, -1)
+        extra = (dict(tail_phases=8, tail_spread=1) if tiling == "phases_spread" else dict(tail_phases=8) if str(tiling).startswith("phases")
+                 else (dict(tail_spread=3) if tiling == "spread3" else {}))
         with reevr_amd.tuning(guard=2, k1=32 if tiling == "force2_k32" else 0, tail_slack=slack, **extra):
             s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1) and slack < 0 and not extra, fft_f32=slack > 0,
                                        time_tiling={"force2_k32": "force2", "widen": "force", "shrink": "force2", "phases": "force2",
-                                                    "phases_shrink": "force2", "spread3": "force2"}.get(tiling, tiling))
+                                                    "phases_shrink": "force2", "spread3": "force2", "phases_spread": "force2"}.get(tiling, tiling))
             ok = s.init(head, tail, irs, max_len=max(sched))
         assert ok, s.last_error_string
         pos = 0
