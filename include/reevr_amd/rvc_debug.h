@@ -73,7 +73,12 @@ const char *rvc_debug_tuning_keys(void);
  * slack buys (rvc.h, RVC_MAX_BLOCK): -1 by size / 0 nothing (the reference's structure, delay 2) / 1 a tail at twice the block /
  * 2 half the zero-latency stage, wherever supported (tests force both on small sets); "sweep_lds", "fft_many", "kid_fence",
  * "sweep_lw", "sweep_d", "patch_nt", "block_occ", "mac3", "inv_dif", "sweep_nt": kernel / schedule variants (rvc_internal.h LaunchTune, rvc_set.h
- * Tuning). */
+ * Tuning). Round 6: "tail_phases" -1 by size / 1 .. 8 channel groups whose tail tiles run out of phase (rvc_plan::tail_phase_groups: no
+ * call carries a sweep over the whole set); "tail_spread" -1 by size / bit 0 first-level, bit 1 second-level sweeps of the tail stage issued
+ * a tail period early in channel slices (one more partition per patch; with phase groups only bit 0 applies); "kid_stagger" 1 = the children
+ * of a set start their tail tiles out of phase (only without phase groups); "host_zero_copy" -1 by size / 0 / 1 host-pointer per-block calls
+ * let the block kernel read and write the pinned staging rows itself instead of DMA copies; "block_lanex" -1 by size / 0 / 1 the per-block
+ * kernel of head 512 exchanges lane-locally between its last two radix-8 passes (v_permlane32_swap / v_permlane16_swap / DPP). */
 int rvc_debug_set_tuning(const char *key, int value);
 /* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set
  * is initialised, every device allocation of the set lies between two 256 KiB guard bands filled with 0xFF and starts out
