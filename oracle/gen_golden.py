@@ -77,7 +77,7 @@ def main():
     # AudioFFT known-answer vectors: forward spectrum of seeded noise at a few sizes.
     fft = {}
     from reevr_amd import synth
-    for n in (2, 4, 8, 16, 64, 1024, 16384):
+    for n in (2, 4, 8, 16, 64, 1024, 16384, 32768):       # (32768: round 6, the 16384-bin transforms of a widened tail)
         x = synth.white_noise(n, 0xF00D + n)
         re, im = O.rfft(x, "ref")
         fft[f"n{n}/re"] = re

@@ -721,7 +721,7 @@ static int debug_fft(int device, size_t n, int f64, bool inverse, const float *i
     }
     ok = hipMemcpy(d_f, Y.data(), sizeof(float2) * 2 * B, hipMemcpyHostToDevice) == hipSuccess;
     rvc::InvArgs v{};
-    v.Y = d_f; v.y_chan_stride = (long long)(2 * B); v.tw = g.twp(g.f64i); v.wsplit = g.wsp(g.f64i); v.tw8 = g.t8p(g.f64i); v.tw8_half = g.t8h(g.f64i);
+    v.Y = d_f; v.y_chan_stride = (long long)(2 * B); v.tw = g.twp(g.f64i); v.wsplit = g.wsp(g.f64i); v.tw8 = g.t8p(g.f64i); v.tw8_half = g.t8h(g.f64i); v.tw_half = g.twh(g.f64i);
     v.blk0 = 0; v.dst = d_t; v.dst_chan_stride = (long long)n; v.dst_origin = 0; v.dst_mask = ~0ull;
     v.lo = 0; v.hi = (long long)n; v.add = nullptr;
     ok = ok && rvc::launch_fft_inv(logB, g.f64i, v, 2, 1, s->st_main) == hipSuccess &&

@@ -105,6 +105,8 @@ struct InvArgs {            // spectrum row(s) -> last B samples of the inverse 
   long long add_from;       // add applies for n >= add_from
   const void *tw8_half;     // optional: the per-pass tables (double2, fft8_table_entries(logB - 1)) of the HALF-size transform: the
                             // 8192-bin double inverse then runs as two 4096-point sub-transforms (k_fft8_inv_dif2)
+  const void *tw_half;      // optional (float2, B / 2 entries e^{-2 pi i j / (B/2)}): the final radix-2 pass of a half-size plan that has one
+                            // (the 16384-bin float inverse as two 8192-point sub-transforms)
   int rows;                 // set by the launcher
 };
 
@@ -202,6 +204,7 @@ struct LaunchTune {
   int sweep_nt = -1;     // sweeps of a stage stream (non-temporal accumulator-row stores, second-level IR loads): -1 by the stage's size / 0 / 1
   int inv_dif = -1;      // 8192-bin DOUBLE inverse as two 4096-point sub-transforms in two workgroups (k_fft8_inv_dif2): 0 off / else on
   int mac3 = -1;         // three-product complex multiply-accumulate in the LDS-fed 32-block sweeps: -1 default / 0 off / 1 on
+  int inv_dif14 = -1;    // 16384-bin FLOAT inverse as two 8192-point sub-transforms in two workgroups (k_fft8_inv_dif2<13, float>): 0 off / else on
   int block_lanex = -1;  // per-block kernel of head 512: second exchange of its transforms lane-locally (v_permlane32/16_swap + DPP): -1 by size / 0 / 1
 };
 void set_launch_tune(const LaunchTune *t);   // thread-local; nullptr = the defaults above

@@ -1028,7 +1028,9 @@ __global__ void __launch_bounds__(Plan8<LOGBH>::WG, 2) k_fft8_inv_dif2(const Inv
   typedef Plan8<LOGBH> P;
   typedef cx<R> C;
   typedef Tw8<LOGBH, R, false, false, false, false, true> TW;    // (w^2k, w^4k of a pass squared from w^k: a third of the fetches)
-  static_assert(P::TPW == 1 && P::S == 1 && P::Q == 1 && P::kLin && !TW::EAGER, "a big single-transform plan without a final pass");
+  // (round 6: also half-size plans WITH a final radix-2 pass -- the 16384-bin float inverse as two 8192-point sub-transforms: the
+  //  pass's twiddles come from a.tw_half, the outputs a thread holds follow Plan8::out_idx)
+  static_assert(P::TPW == 1 && P::S == 1 && (P::Q == 1 || P::Q == 2) && P::kLin && !TW::EAGER, "a big single-transform plan, at most a radix-2 final pass");
   static_assert(2 * P::B == 16 * P::NT, "the constant turns between a thread's four bins below");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int BH = P::B, B = 2 * BH, NT = P::NT;
@@ -1042,7 +1044,7 @@ __global__ void __launch_bounds__(Plan8<LOGBH>::WG, 2) k_fft8_inv_dif2(const Inv
   const long long nblk = (a.blk0 + r_) * (long long)B;
   const float2 *Y = a.Y + (long long)c * a.y_chan_stride + (long long)r_ * B;
   TW T;
-  T.load(reinterpret_cast<const C *>(a.tw8_half), nullptr, tid);   // (no final radix-2 / 4 pass: the second table is never read)
+  T.load(reinterpret_cast<const C *>(a.tw8_half), reinterpret_cast<const C *>(a.tw_half), tid);   // (tw_half: the final radix-2 pass's, Q == 2 only)
   const R sc = (R)0.5 / (R)B;
   const int lt = lpad(tid), ln = lpad_neg(tid);
   C v[P::E];
@@ -1116,8 +1118,9 @@ __global__ void __launch_bounds__(Plan8<LOGBH>::WG, 2) k_fft8_inv_dif2(const Inv
   // sub-transform output m = z[2m + par]; the block's samples are z[B/2 .. B) = sample pairs: m >= BH/2, pair index 2 (m - BH/2) + par
   float2 *ob = reinterpret_cast<float2 *>(a.dst + (long long)c * a.dst_chan_stride + ((unsigned long long)(nblk - a.dst_origin) & a.dst_mask));
 #pragma unroll
-  for (int e = 4; e < P::E; ++e) {
-    const int m = tid + e * NT;
+  for (int e = 0; e < P::E; ++e) {
+    if (P::out_is_low(e)) continue;                          // (compile time: the first half of the sub-transform's outputs is not the block's)
+    const int m = P::out_idx(tid, e);
     ob[2 * (m - BH / 2) + par] = make_float2((float)v[e].x, (float)v[e].y);
   }
 }
@@ -2345,8 +2348,8 @@ static bool inv_rows_loopable(const InvArgs &a, int rows) {
 }
 
 // whole blocks to an aligned run of the destination that does not wrap inside a block (a ring of whole blocks, or linear memory)
-static bool inv_rows_flat(const InvArgs &a, int rows) {
-  constexpr long long B = 1ll << kLoopLogB;
+static bool inv_rows_flat(const InvArgs &a, int rows, int logB = kLoopLogB) {
+  const long long B = 1ll << logB;
   const long long n0 = a.blk0 * B;
   const bool linear = a.dst_mask == ~0ull;
   return a.add == nullptr && a.lo <= n0 && n0 + rows * B <= a.hi && (linear || (long long)(a.dst_mask + 1ull) % B == 0) &&
@@ -2403,6 +2406,17 @@ hipError_t launch_fft_inv(int logB, bool f64, const InvArgs &a, int rows, int ch
     b.rows = rows;
     RVC_LAUNCH((k_fft8_inv_dif2<kLoopLogB - 1, double>), dim3((unsigned)(16 * ((items + 7) / 8))), dim3(PH::WG),
                sizeof(cx<double>) * PH::LDS_ELEMS, st, b, (int)items);
+    return hipGetLastError();
+  }
+  // round 6: the 16384-bin FLOAT inverse the same way (the widened tail of BASELINE config 3): two 8192-point workgroups of 1024
+  // threads, 68 KiB and 60 VGPRs each -- two per CU -- instead of one whole-CU workgroup of 136 KiB. Measured on MI355X
+  // (profiles/r6_inv_dif14.txt): 146 -> 114 us per 2048 rows on one queue (0.34 -> 0.44 of the HBM peak), config 3 +1.2 %; knob inv_dif14
+  if (logB == 14 && !f64 && a.tw8_half && a.tw_half && launch_tune().inv_dif14 != 0 && inv_rows_flat(a, rows, 14) && items < (1ll << 26)) {
+    typedef Plan8<13> PH;
+    InvArgs b = a;
+    b.rows = rows;
+    RVC_LAUNCH((k_fft8_inv_dif2<13, float>), dim3((unsigned)(16 * ((items + 7) / 8))), dim3(PH::WG), sizeof(cx<float>) * PH::LDS_ELEMS, st, b,
+               (int)items);
     return hipGetLastError();
   }
   if (f64) {
@@ -2586,6 +2600,7 @@ hipError_t prepare_kernels() {
   }
   const void *big[] = {reinterpret_cast<const void *>(k_fft8_fwd_loop<kLoopLogB>), reinterpret_cast<const void *>(k_fft8_inv_loop<kLoopLogB>),
                        reinterpret_cast<const void *>(k_fft8_inv_dif2<kLoopLogB - 1, double>),
+                       reinterpret_cast<const void *>(k_fft8_inv_dif2<13, float>),
                        reinterpret_cast<const void *>(k_fft8_fwd<13, float>), reinterpret_cast<const void *>(k_fft8_inv<13, float, true>),
                        reinterpret_cast<const void *>(k_fft8_inv<13, float, false>),
                        reinterpret_cast<const void *>(k_fft8_fwd<14, float>), reinterpret_cast<const void *>(k_fft8_inv<14, float, true>),

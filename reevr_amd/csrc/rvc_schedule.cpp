@@ -350,7 +350,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
     RVC_CK(rvc::launch_fir(r, s->nch, st));
   }
   rvc::InvArgs v{};
-  v.Y = yrows; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(T.f64i); v.wsplit = T.wsp(T.f64i); v.tw8 = T.t8p(T.f64i); v.tw8_half = T.t8h(T.f64i);
+  v.Y = yrows; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(T.f64i); v.wsplit = T.wsp(T.f64i); v.tw8 = T.t8p(T.f64i); v.tw8_half = T.t8h(T.f64i); v.tw_half = T.twh(T.f64i);
   v.blk0 = m_lo;
   v.dst = s->tailring; v.dst_chan_stride = (long long)s->ring_cap; v.dst_origin = 0; v.dst_mask = s->ring_cap - 1;
   v.lo = 0; v.hi = (long long)1 << 62;
@@ -455,7 +455,7 @@ bool head_stage(rvc_set *s, long long n0, long long na, long long nb, const floa
     else if (!tail_rows(s, (nb - 1) / (long long)T.B + 1, s->st_main)) return false;   // lazily, if skipped
   }
   rvc::InvArgs v{};
-  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(A.f64i); v.wsplit = A.wsp(A.f64i); v.tw8 = A.t8p(A.f64i); v.tw8_half = A.t8h(A.f64i);
+  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(A.f64i); v.wsplit = A.wsp(A.f64i); v.tw8 = A.t8p(A.f64i); v.tw8_half = A.t8h(A.f64i); v.tw_half = A.twh(A.f64i);
   v.blk0 = ka;
   v.dst = d_out + (na - n0); v.dst_chan_stride = (long long)out_stride; v.dst_origin = na; v.dst_mask = ~0ull;
   v.lo = na; v.hi = nb;
@@ -776,7 +776,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
     }
     rvc::InvArgs v{};
-    v.Y = W.Y; v.y_chan_stride = r.y_chan_stride; v.tw = W.twp(W.f64i); v.wsplit = W.wsp(W.f64i); v.tw8 = W.t8p(W.f64i); v.tw8_half = W.t8h(W.f64i);
+    v.Y = W.Y; v.y_chan_stride = r.y_chan_stride; v.tw = W.twp(W.f64i); v.wsplit = W.wsp(W.f64i); v.tw8 = W.t8p(W.f64i); v.tw8_half = W.t8h(W.f64i); v.tw_half = W.twh(W.f64i);
     v.blk0 = m_first;
     v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
     v.lo = n0; v.hi = n1;
@@ -842,7 +842,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
           RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
         }
         rvc::InvArgs v{};
-        v.Y = r.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(T.f64i); v.wsplit = T.wsp(T.f64i); v.tw8 = T.t8p(T.f64i); v.tw8_half = T.t8h(T.f64i);
+        v.Y = r.Y; v.y_chan_stride = r.y_chan_stride; v.tw = T.twp(T.f64i); v.wsplit = T.wsp(T.f64i); v.tw8 = T.t8p(T.f64i); v.tw8_half = T.t8h(T.f64i); v.tw_half = T.twh(T.f64i);
         v.blk0 = r0;
         v.dst = d_out; v.dst_chan_stride = (long long)out_stride; v.dst_origin = n0; v.dst_mask = ~0ull;
         v.lo = n0; v.hi = n1;

@@ -87,13 +87,15 @@ struct Stage {
   float2 *tw = nullptr, *wsplit = nullptr, *tw8 = nullptr;       // float twiddles
   double2 *twd = nullptr, *wsplitd = nullptr, *tw8d = nullptr;   // double twiddles (B <= 8192): IR spectra, f64 mode
   double2 *tw8dh = nullptr;                                       // B = 8192: the per-pass tables of the 4096-point transform (k_fft8_inv_dif2)
+  float2 *tw8fh = nullptr, *twfh = nullptr;                       // B = 16384: per-pass tables and base twiddles of the 8192-point transform (float)
   bool f64f = false, f64i = false;               // run this stage's forward / inverse transforms in double
   bool f64() const { return f64f || f64i; }      // (any of them: the float-only one-launch block kernel is out then)
   void set64(int mode) { f64f = (mode & 1) != 0; f64i = (mode & 2) != 0; }
   const void *twp(bool d) const { return d ? (const void *)twd : (const void *)tw; }
   const void *wsp(bool d) const { return d ? (const void *)wsplitd : (const void *)wsplit; }
   const void *t8p(bool d) const { return d ? (const void *)tw8d : (const void *)tw8; }
-  const void *t8h(bool d) const { return d ? (const void *)tw8dh : nullptr; }
+  const void *t8h(bool d) const { return d ? (const void *)tw8dh : (const void *)tw8fh; }
+  const void *twh(bool d) const { return d ? nullptr : (const void *)twfh; }
 };
 
 struct TimedLaunch {

@@ -125,7 +125,7 @@ bool ensure_streams(rvc_set *s) {
 }
 
 void free_stage(rvc_set *s, Stage &g) {
-  void *all[] = {g.H, g.X, g.Y, g.d_ir, g.tw, g.wsplit, g.twd, g.wsplitd, g.tw8, g.tw8d, g.tw8dh};
+  void *all[] = {g.H, g.X, g.Y, g.d_ir, g.tw, g.wsplit, g.twd, g.wsplitd, g.tw8, g.tw8d, g.tw8dh, g.tw8fh, g.twfh};
   for (void *q : all) dev_free(s, q);
   g = Stage();
 }
@@ -269,6 +269,21 @@ bool make_twiddles(rvc_set *s, Stage &g) {
     if (th.size() != (size_t)rvc::fft8_table_entries(12)) return fail(s, RVC_ERR_HIP, hipSuccess, "twiddle table layout");
     RVC_CK(dev_alloc(s, &g.tw8dh, sizeof(double2) * th.size()));
     RVC_CK(hipMemcpy(g.tw8dh, th.data(), sizeof(double2) * th.size(), hipMemcpyHostToDevice));
+  }
+  if (g.logB == 14) {                         // the float inverse as two half-size (8192-point) sub-transforms: pass tables + base twiddles
+    std::vector<double2> th;
+    pass_tables(13, th);
+    if (th.size() != (size_t)rvc::fft8_table_entries(13)) return fail(s, RVC_ERR_HIP, hipSuccess, "twiddle table layout");
+    std::vector<float2> tf(th.size()), tb(B / 2);
+    for (size_t i = 0; i < th.size(); ++i) tf[i] = make_float2((float)th[i].x, (float)th[i].y);
+    for (size_t j = 0; j < B / 2; ++j) {
+      const double ang = -2.0 * kPi * (double)j / (double)(B / 2);
+      tb[j] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    RVC_CK(dev_alloc(s, &g.tw8fh, sizeof(float2) * tf.size()));
+    RVC_CK(hipMemcpy(g.tw8fh, tf.data(), sizeof(float2) * tf.size(), hipMemcpyHostToDevice));
+    RVC_CK(dev_alloc(s, &g.twfh, sizeof(float2) * tb.size()));
+    RVC_CK(hipMemcpy(g.twfh, tb.data(), sizeof(float2) * tb.size(), hipMemcpyHostToDevice));
   }
   return true;
 }

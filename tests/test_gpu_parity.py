@@ -262,8 +262,7 @@ def test_full_size_properties_other_configs(cfg):
 AUDIOFFT_SIZES = (2, 4, 8, 16, 64, 1024, 16384)
 
 
-@pytest.mark.parametrize("f64", [0, 1])
-@pytest.mark.parametrize("n", AUDIOFFT_SIZES)
+@pytest.mark.parametrize("n,f64", [(n, f) for n in AUDIOFFT_SIZES for f in (0, 1)] + [(32768, 0)])    # (32768: float only, 16384-bin rows)
 def test_bare_transforms_vs_audiofft_golden(golden, n, f64):
     """The HIP forward / inverse transform kernels ALONE (rvc_debug_rfft / rvc_debug_irfft: one launch of the
     stage kernels with the stage twiddle tables) against the reference's AudioFFT known answers
@@ -1715,3 +1714,50 @@ def test_per_block_kernel_lane_local_exchange_is_bit_identical():
     o = O.TwoStageFFTConvolver("orc")
     assert o.init(head, tail, irs[5])
     assert rel_rms(outs[1][5], o.process(x[5, :head * 102])) <= TOL
+
+
+def test_float_inverse_16384_as_two_half_transforms(golden):
+    """k_fft8_inv_dif2<13, float> (knob inv_dif14; round 6, review item 3b) -- the 16384-bin float inverse as two 8192-point
+    sub-transforms in two workgroups of 1024 threads (a half-size plan WITH a final radix-2 pass) -- against the whole-CU one-row
+    kernel and the known answers: (1) the bare transform on the reference's AudioFFT spectrum (n = 32768), both forms within the
+    float tolerance of the golden round trip and within 1e-6 of each other; (2) a 301-channel set whose tail runs at block 16384
+    (head 256 / tail 8192, widened: config 3's structure; an odd job count), both forms against each other and the oracle."""
+    import torch
+    from reevr_amd import _lib
+    L = _lib.lib()
+    g = golden["audiofft"]
+    n = 32768
+    fp = lambda a: a.ctypes.data_as(_lib.F32P)
+    wre = np.ascontiguousarray(g[f"n{n}/re"], np.float32)
+    wim = np.ascontiguousarray(g[f"n{n}/im"], np.float32)
+    wrt = g[f"n{n}/rt"].astype(np.float64)
+    rts = {}
+    for mode in (0, 1):
+        reevr_amd.set_tuning("inv_dif14", mode)
+        try:
+            rt = np.full(n, np.nan, np.float32)
+            assert L.rvc_debug_irfft(0, n, 0, fp(rt), fp(wre), fp(wim)) == 1
+            rts[mode] = rt.astype(np.float64)
+        finally:
+            reevr_amd.set_tuning("inv_dif14", -1)
+        assert np.sqrt(np.mean((rts[mode] - wrt) ** 2)) / np.sqrt(np.mean(wrt ** 2)) <= 2e-6, mode
+    assert np.sqrt(np.mean((rts[1] - rts[0]) ** 2)) / np.sqrt(np.mean(wrt ** 2)) <= 1e-6     # (two float forms: measured 2.6e-7)
+    nch, head, tail, nblk = 301, 256, 8192, 64 * 6
+    irs = [synth.synth_ir(2 * tail + 5 * tail - 101 * (c % 7), 1, 40 + c % 11)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 300 + c % 9) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    outs = {}
+    for mode in (0, 1):
+        s = reevr_amd.ConvolverSet(nch, tune={"inv_dif14": mode, "tail_slack": 1})
+        assert s.init(head, tail, irs, max_len=head), s.last_error_string
+        assert s.tail_block == 2 * tail and s.plan()["tail_f64"] == 0
+        outs[mode] = s.process_device_blocks(dx, head).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        s.close()
+    assert np.isfinite(outs[1]).all()
+    for c in range(nch):
+        assert rel_rms(outs[1][c], outs[0][c]) <= 1e-6, c
+    for c in (0, 150, 300):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(outs[1][c], o.process(x[c])) <= TOL, c

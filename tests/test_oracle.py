@@ -42,7 +42,7 @@ def test_synth_oracle_vs_golden(golden, name):
         cases.compare_to_fixture(out[c], fixture_of(golden["synth"], f"{name}/ch{c}"), ORACLE_TOL)
 
 
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 1024, 16384])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 1024, 16384, 32768])
 def test_audiofft_oracle_vs_golden(golden, n):
     from reevr_amd import synth
     x = synth.white_noise(n, 0xF00D + n)
