@@ -695,7 +695,7 @@ static int debug_fft(int device, size_t n, int f64, bool inverse, const float *i
     rvc::FwdArgs a{};
     a.src = d_t; a.src_chan_stride = (long long)n; a.src_mask = ~0ull;
     a.seg0 = 0; a.valid_len = (int)n; a.lo = 0; a.hi = (long long)n;
-    a.tw = g.twp(g.f64f); a.wsplit = g.wsp(g.f64f); a.tw8 = g.t8p(g.f64f);
+    a.tw = g.twp(g.f64f); a.wsplit = g.wsp(g.f64f); a.tw8 = g.t8p(g.f64f); a.tw8_half = g.t8h(g.f64f); a.tw_half = g.twh(g.f64f);
     a.dst = d_f; a.dst_chan_stride = (long long)B; a.row0 = 0; a.row_mask = ~0ull;
     ok = ok && rvc::launch_fft_fwd(logB, g.f64f, a, 1, 1, s->st_main) == hipSuccess &&
          hipStreamSynchronize(s->st_main) == hipSuccess;

@@ -40,6 +40,8 @@ struct FwdArgs {            // real time-domain segment(s) -> spectrum row(s)
   long long dst_chan_stride;
   long long row0;           // absolute row index of row 0
   unsigned long long row_mask;   // row slot = (row0 + r) & row_mask
+  const void *tw8_half;     // optional (float2): per-pass tables and base twiddles of the HALF-size transform -- the 16384-bin float forward
+  const void *tw_half;      // then runs as two 8192-point sub-transforms in two workgroups (k_fft8_fwd_dif2)
   int rows;                 // set by the launcher (several small transforms share a workgroup)
 };
 
@@ -204,6 +206,7 @@ struct LaunchTune {
   int sweep_nt = -1;     // sweeps of a stage stream (non-temporal accumulator-row stores, second-level IR loads): -1 by the stage's size / 0 / 1
   int inv_dif = -1;      // 8192-bin DOUBLE inverse as two 4096-point sub-transforms in two workgroups (k_fft8_inv_dif2): 0 off / else on
   int mac3 = -1;         // three-product complex multiply-accumulate in the LDS-fed 32-block sweeps: -1 default / 0 off / 1 on
+  int fwd_dif14 = -1;    // 16384-bin FLOAT forward as two 8192-point sub-transforms in two workgroups (k_fft8_fwd_dif2<13>): 0 off / else on
   int inv_dif14 = -1;    // 16384-bin FLOAT inverse as two 8192-point sub-transforms in two workgroups (k_fft8_inv_dif2<13, float>): 0 off / else on
   int block_lanex = -1;  // per-block kernel of head 512: second exchange of its transforms lane-locally (v_permlane32/16_swap + DPP): -1 by size / 0 / 1
 };

@@ -1125,6 +1125,108 @@ __global__ void __launch_bounds__(Plan8<LOGBH>::WG, 2) k_fft8_inv_dif2(const Inv
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// Round 6: the 16384-bin FLOAT forward transform -- the tail forward of BASELINE config 3's widened tail -- as TWO 8192-point
+// sub-transforms in two workgroups, the counterpart of k_fft8_inv_dif2<13, float>. Decimation in frequency of the B-point complex
+// transform of z[n] = x[2n] + i x[2n+1]:
+//   Z[2j]     = DFT_{B/2}( z[n] + z[n + B/2] )[j],      Z[2j + 1] = DFT_{B/2}( (z[n] - z[n + B/2]) w^n )[j],   w = e^{-2 pi i / B}:
+// workgroup `par` of a row reads the whole 2B-sample segment (the second read comes from the XCD's L2) and produces the bins of
+// parity par. The real split pairs bin k with B - k -- the SAME parity --, i.e. sub-transform output j with B/2 - j (even) or
+// B/2 - 1 - j (odd): each workgroup finishes its own bins through one LDS mirror exchange and stores every other bin of the row.
+// Only whole rows read from the time ring alone (launch_fft_fwd checks: no second source, no ring append, no window cut).
+// ----------------------------------------------------------------------------------------
+template <int LOGBH>
+__global__ void __launch_bounds__(Plan8<LOGBH>::WG, 8) k_fft8_fwd_dif2(const FwdArgs a, const int items) {   // (8 waves per SIMD = two workgroups per CU: <= 64 VGPRs)
+  typedef Plan8<LOGBH> P;
+  typedef float R;
+  typedef cx<R> C;
+  typedef Tw8<LOGBH, R, false, false, false, false, true> TW;
+  static_assert(P::TPW == 1 && P::S == 1 && P::kLin && !TW::EAGER, "a big single-transform plan");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int BH = P::B, B = 2 * BH, NT = P::NT;
+  const int tid = threadIdx.x;
+  C *lds = reinterpret_cast<C *>(smem_raw);
+  const int chunk = blockIdx.x >> 4, j16 = blockIdx.x & 15;       // (job placement as k_fft8_inv_dif2: the halves of a row 8 apart)
+  const int w = chunk * 8 + (j16 & 7), par = j16 >> 3;
+  if (w >= items) return;
+  const int r_ = w % a.rows, c = w / a.rows;
+  const float *src = a.src + (long long)c * a.src_chan_stride;
+  const long long seg = a.seg0 + (long long)r_ * B;
+  // z[i] lies in the first half of the segment, z[i + B/2] at the same offset of the second half (i < B/2)
+  const float2 *b0 = reinterpret_cast<const float2 *>(src + ((unsigned long long)seg & a.src_mask));
+  const float2 *b1 = reinterpret_cast<const float2 *>(src + ((unsigned long long)(seg + B) & a.src_mask));
+  TW T;
+  T.load(reinterpret_cast<const C *>(a.tw8_half), reinterpret_cast<const C *>(a.tw_half), tid);
+  float2 za[P::E], zb[P::E];
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) { za[e] = b0[tid + e * NT]; zb[e] = b1[tid + e * NT]; }
+  const C *tw = reinterpret_cast<const C *>(a.tw);
+  const C *wsplit = reinterpret_cast<const C *>(a.wsplit);
+  C v[P::E];
+  if (par == 0) {                                                  // (uniform)
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) v[e] = mk<R>(za[e].x + zb[e].x, za[e].y + zb[e].y);
+  } else {
+    C wn[P::E];
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) wn[e] = tw[tid + e * NT];      // w^n, n = in_idx(tid, e) < B/2
+#pragma unroll
+    for (int e = 0; e < P::E; ++e) v[e] = cmul(mk<R>(za[e].x - zb[e].x, za[e].y - zb[e].y), wn[e]);
+  }
+  // split twiddles e^{-i pi k / B} of the bins k = 2 j + par this thread completes (the low half of its outputs)
+  C ws[P::E / 2];
+  {
+    int q = 0;
+#pragma unroll
+    for (int e = 0; e < P::E; ++e)
+      if (P::out_is_low(e)) ws[q++] = wsplit[2u * (unsigned)P::out_idx(tid, e) + (unsigned)par];
+  }
+  fft8_core<LOGBH, false, R, false, TW>(v, lds, T, tid);
+  // mirror exchange inside the workgroup: output j pairs with BH - j - par
+  const int lt = lpad(tid), lnp = lpad_neg(tid + par);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < P::E; ++e)
+    if (!P::out_is_low(e)) lds[lt + lpad_c(P::out_c(e))] = v[e];
+  __syncthreads();
+  C Zp[P::E / 2];
+  {
+    int q = 0;
+#pragma unroll
+    for (int e = 0; e < P::E; ++e)
+      if (P::out_is_low(e)) {
+        int idx = lnp + lpad_c(BH - P::out_c(e));                  // lpad(BH - j - par), j = tid + out_c(e)
+        if (e == 0 && par == 0) idx = tid == 0 ? lpad(BH / 2) : idx;   // (j = 0 of the even half: no partner, replaced below)
+        Zp[q++] = lds[idx];
+      }
+  }
+  float2 *dst = a.dst + (long long)c * a.dst_chan_stride + (long long)(((unsigned long long)(a.row0 + r_)) & a.row_mask) * B;
+  const R half = (R)0.5;
+  int q = 0;
+#pragma unroll
+  for (int e = 0; e < P::E; ++e) {
+    const unsigned j = (unsigned)P::out_idx(tid, e);
+    const unsigned k = 2u * j + (unsigned)par;
+    const C A = v[e];
+    if (P::out_is_low(e)) {
+      const C wk = ws[q];
+      const C Bc = cconj(Zp[q]);                                   // conj Z[B - k]
+      ++q;
+      const C Ev = mk<R>(half * (A.x + Bc.x), half * (A.y + Bc.y));
+      const C D = mk<R>(half * (A.x - Bc.x), half * (A.y - Bc.y));
+      const C wO = cmul(wk, mk<R>(D.y, -D.x));                     // w^k * (-i D)
+      float2 x0 = make_float2(Ev.x + wO.x, Ev.y + wO.y);
+      const float2 x1 = make_float2(Ev.x - wO.x, wO.y - Ev.y);     // conj(E - w^k O)
+      const bool dc = (e == 0) && tid == 0 && par == 0;
+      if (dc) x0 = make_float2(A.x + A.y, A.x - A.y);              // packed (DC, Nyquist)
+      dst[k] = x0;
+      if (!dc) dst[(unsigned)B - k] = x1;
+    } else if (par == 0 && j == (unsigned)BH / 2) {
+      dst[k] = make_float2(A.x, -A.y);                             // X[B/2] = conj(Z[B/2]) (its own partner)
+    }
+  }
+}
+
 // e^{-i pi q / 8}, q = 0 .. 3 (compile-time after unrolling)
 template <typename R> __device__ __forceinline__ cx<R> eighth_turn(const int q) {
   return q == 0 ? mk<R>((R)1, (R)0)
@@ -2356,8 +2458,29 @@ static bool inv_rows_flat(const InvArgs &a, int rows, int logB = kLoopLogB) {
          (n0 - a.dst_origin) % B == 0 && (reinterpret_cast<uintptr_t>(a.dst) & 7u) == 0 && (a.dst_chan_stride & 1) == 0;
 }
 
+// whole rows read from the time ring alone, every half segment contiguous: what k_fft8_fwd_dif2 handles
+static bool fwd_rows_flat(const FwdArgs &a, int rows, int logB) {
+  const long long B = 1ll << logB;
+  const bool linear = a.src_mask == ~0ull;
+  return a.src2 == nullptr && a.ring_out == nullptr && a.valid_len == 2 * B && a.seg0 >= a.lo && a.seg0 + (rows + 1) * B <= a.hi &&
+         (linear || ((long long)(a.src_mask + 1ull) % B == 0 && a.seg0 % B == 0)) && (linear ? (a.seg0 & 1) == 0 : true) &&
+         (reinterpret_cast<uintptr_t>(a.src) & 7u) == 0 && (a.src_chan_stride & 1) == 0;
+}
+
 hipError_t launch_fft_fwd(int logB, bool f64, const FwdArgs &a, int rows, int channels, hipStream_t st) {
   if (rows <= 0 || channels <= 0) return hipSuccess;
+  // round 6: the 16384-bin float forward as two 8192-point sub-transforms in two workgroups of 1024 threads (68 KiB, 64 VGPRs: two per
+  // CU) instead of one whole-CU workgroup. Measured on MI355X (profiles/r6_inv_dif14.txt): 160 -> 138 us per 2048 rows on one queue
+  // (0.42 -> 0.49 of the HBM peak), config 3 +0.9-1.5 %; knob fwd_dif14
+  if (logB == 14 && !f64 && a.tw8_half && a.tw_half && launch_tune().fwd_dif14 != 0 && fwd_rows_flat(a, rows, 14) &&
+      (long long)rows * channels < (1ll << 26)) {
+    typedef Plan8<13> PH;
+    const long long items = (long long)rows * channels;
+    FwdArgs b = a;
+    b.rows = rows;
+    RVC_LAUNCH((k_fft8_fwd_dif2<13>), dim3((unsigned)(16 * ((items + 7) / 8))), dim3(PH::WG), sizeof(cx<float>) * PH::LDS_ELEMS, st, b, (int)items);
+    return hipGetLastError();
+  }
   if (logB == kLoopLogB && !f64 && launch_tune().fft_loop != 0 && fwd_rows_loopable(a, rows)) {
     const int nwg = fft_loop_workgroups(false);
     const long long items = (long long)rows * channels;
@@ -2600,7 +2723,7 @@ hipError_t prepare_kernels() {
   }
   const void *big[] = {reinterpret_cast<const void *>(k_fft8_fwd_loop<kLoopLogB>), reinterpret_cast<const void *>(k_fft8_inv_loop<kLoopLogB>),
                        reinterpret_cast<const void *>(k_fft8_inv_dif2<kLoopLogB - 1, double>),
-                       reinterpret_cast<const void *>(k_fft8_inv_dif2<13, float>),
+                       reinterpret_cast<const void *>(k_fft8_inv_dif2<13, float>), reinterpret_cast<const void *>(k_fft8_fwd_dif2<13>),
                        reinterpret_cast<const void *>(k_fft8_fwd<13, float>), reinterpret_cast<const void *>(k_fft8_inv<13, float, true>),
                        reinterpret_cast<const void *>(k_fft8_inv<13, float, false>),
                        reinterpret_cast<const void *>(k_fft8_fwd<14, float>), reinterpret_cast<const void *>(k_fft8_inv<14, float, true>),

@@ -25,7 +25,7 @@ static const TuneKey kTuneKeys[] = {
     {"patch_nt", nullptr, &rvc::LaunchTune::patch_nt}, {"sweep_split", nullptr, &rvc::LaunchTune::sweep_split},
     {"sweep_lw", nullptr, &rvc::LaunchTune::sweep_lw}, {"sweep_d", nullptr, &rvc::LaunchTune::sweep_d},
     {"sweep_lds", nullptr, &rvc::LaunchTune::sweep_lds}, {"mac3", nullptr, &rvc::LaunchTune::mac3},
-    {"inv_dif", nullptr, &rvc::LaunchTune::inv_dif}, {"block_lanex", nullptr, &rvc::LaunchTune::block_lanex}, {"inv_dif14", nullptr, &rvc::LaunchTune::inv_dif14}, {"sweep_nt", nullptr, &rvc::LaunchTune::sweep_nt},
+    {"inv_dif", nullptr, &rvc::LaunchTune::inv_dif}, {"block_lanex", nullptr, &rvc::LaunchTune::block_lanex}, {"inv_dif14", nullptr, &rvc::LaunchTune::inv_dif14}, {"fwd_dif14", nullptr, &rvc::LaunchTune::fwd_dif14}, {"sweep_nt", nullptr, &rvc::LaunchTune::sweep_nt},
 };
 int *tune_slot(Tuning &t, const std::string &key) {
   for (const TuneKey &k : kTuneKeys)

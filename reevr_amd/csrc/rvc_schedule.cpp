@@ -133,7 +133,7 @@ bool tail_spectra(rvc_set *s, long long n0, long long n1, const float *src2, siz
   f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
   f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
   f.seg0 = (mb0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
-  f.tw = T.twp(T.f64f); f.wsplit = T.wsp(T.f64f); f.tw8 = T.t8p(T.f64f);
+  f.tw = T.twp(T.f64f); f.wsplit = T.wsp(T.f64f); f.tw8 = T.t8p(T.f64f); f.tw8_half = T.t8h(T.f64f); f.tw_half = T.twh(T.f64f);
   f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = mb0; f.row_mask = T.rows - 1;
   Timer t(s, 4, st);
   RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64f, f, (int)(mb1 - mb0), s->nch, st));
@@ -152,7 +152,7 @@ bool ensure_tail_spectra(rvc_set *s, long long lo, hipStream_t st) {
   rvc::FwdArgs f{};
   f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
   f.seg0 = (lo - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = s->xt_valid_lo * tb;
-  f.tw = T.twp(T.f64f); f.wsplit = T.wsp(T.f64f); f.tw8 = T.t8p(T.f64f);
+  f.tw = T.twp(T.f64f); f.wsplit = T.wsp(T.f64f); f.tw8 = T.t8p(T.f64f); f.tw8_half = T.t8h(T.f64f); f.tw_half = T.twh(T.f64f);
   f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = lo; f.row_mask = T.rows - 1;
   Timer t(s, 4, st);
   RVC_CK(rvc::launch_fft_fwd(T.logB, T.f64f, f, (int)(s->xt_valid_lo - lo), s->nch, st));
@@ -411,7 +411,7 @@ bool head_spectra(rvc_set *s, long long k_lo, long long k_hi, long long n_hi, co
   f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
   f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = src2_from;
   f.seg0 = (k_lo - 1) * hb; f.valid_len = (int)(2 * hb); f.lo = 0; f.hi = n_hi;
-  f.tw = A.twp(A.f64f); f.wsplit = A.wsp(A.f64f); f.tw8 = A.t8p(A.f64f);
+  f.tw = A.twp(A.f64f); f.wsplit = A.wsp(A.f64f); f.tw8 = A.t8p(A.f64f); f.tw8_half = A.t8h(A.f64f); f.tw_half = A.twh(A.f64f);
   f.dst = A.X; f.dst_chan_stride = (long long)A.rows * hb; f.row0 = k_lo; f.row_mask = A.rows - 1;
   if (ring_from >= 0) {   // the transform kernel also appends the call's recent samples to the time ring
     f.ring_out = s->xring; f.ring_out_chan_stride = (long long)s->ring_cap; f.ring_out_mask = s->ring_cap - 1;
@@ -756,7 +756,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
       f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
       f.seg0 = (fft_lo - 1) * wb; f.valid_len = (int)(2 * wb); f.lo = 0; f.hi = n1;
-      f.tw = W.twp(W.f64f); f.wsplit = W.wsp(W.f64f); f.tw8 = W.t8p(W.f64f);
+      f.tw = W.twp(W.f64f); f.wsplit = W.wsp(W.f64f); f.tw8 = W.t8p(W.f64f); f.tw8_half = W.t8h(W.f64f); f.tw_half = W.twh(W.f64f);
       f.dst = W.X; f.dst_chan_stride = (long long)W.rows * wb; f.row0 = fft_lo; f.row_mask = W.rows - 1;
       if (fft_ingests) {
         f.ring_out = s->xring; f.ring_out_chan_stride = (long long)s->ring_cap; f.ring_out_mask = s->ring_cap - 1;
@@ -821,7 +821,7 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
         f.src = s->xring; f.src_chan_stride = (long long)s->ring_cap; f.src_mask = s->ring_cap - 1;
         f.src2 = src2; f.src2_chan_stride = (long long)in_stride; f.src2_from = n0;
         f.seg0 = (r0 - 1) * tb; f.valid_len = (int)(2 * tb); f.lo = 0; f.hi = n1;
-        f.tw = T.twp(T.f64f); f.wsplit = T.wsp(T.f64f); f.tw8 = T.t8p(T.f64f);
+        f.tw = T.twp(T.f64f); f.wsplit = T.wsp(T.f64f); f.tw8 = T.t8p(T.f64f); f.tw8_half = T.t8h(T.f64f); f.tw_half = T.twh(T.f64f);
         f.dst = T.X; f.dst_chan_stride = (long long)T.rows * tb; f.row0 = r0; f.row_mask = T.rows - 1;
         if (ring_from >= 0) {
           f.ring_out = s->xring; f.ring_out_chan_stride = (long long)s->ring_cap; f.ring_out_mask = s->ring_cap - 1;

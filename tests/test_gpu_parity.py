@@ -1717,9 +1717,9 @@ def test_per_block_kernel_lane_local_exchange_is_bit_identical():
 
 
 def test_float_inverse_16384_as_two_half_transforms(golden):
-    """k_fft8_inv_dif2<13, float> (knob inv_dif14; round 6, review item 3b) -- the 16384-bin float inverse as two 8192-point
-    sub-transforms in two workgroups of 1024 threads (a half-size plan WITH a final radix-2 pass) -- against the whole-CU one-row
-    kernel and the known answers: (1) the bare transform on the reference's AudioFFT spectrum (n = 32768), both forms within the
+    """k_fft8_inv_dif2<13, float> and k_fft8_fwd_dif2<13> (knobs inv_dif14 / fwd_dif14; round 6, review item 3b) -- the 16384-bin
+    float inverse and forward as two 8192-point sub-transforms in two workgroups of 1024 threads (a half-size plan WITH a final
+    radix-2 pass) -- against the whole-CU one-row kernels and the known answers: (1) the bare transform on the reference's AudioFFT spectrum (n = 32768), both forms within the
     float tolerance of the golden round trip and within 1e-6 of each other; (2) a 301-channel set whose tail runs at block 16384
     (head 256 / tail 8192, widened: config 3's structure; an odd job count), both forms against each other and the oracle."""
     import torch
@@ -1742,13 +1742,28 @@ def test_float_inverse_16384_as_two_half_transforms(golden):
             reevr_amd.set_tuning("inv_dif14", -1)
         assert np.sqrt(np.mean((rts[mode] - wrt) ** 2)) / np.sqrt(np.mean(wrt ** 2)) <= 2e-6, mode
     assert np.sqrt(np.mean((rts[1] - rts[0]) ** 2)) / np.sqrt(np.mean(wrt ** 2)) <= 1e-6     # (two float forms: measured 2.6e-7)
+    # ... and the FORWARD transform the same way (k_fft8_fwd_dif2<13>, knob fwd_dif14): the reference's spectrum of seeded noise
+    x = synth.white_noise(n, 0xF00D + n)
+    want = np.concatenate([g[f"n{n}/re"], g[f"n{n}/im"]]).astype(np.float64)
+    specs = {}
+    for mode in (0, 1):
+        reevr_amd.set_tuning("fwd_dif14", mode)
+        try:
+            re, im = np.full(n // 2 + 1, np.nan, np.float32), np.full(n // 2 + 1, np.nan, np.float32)
+            assert L.rvc_debug_rfft(0, n, 0, fp(x), fp(re), fp(im)) == 1
+            specs[mode] = np.concatenate([re, im]).astype(np.float64)
+        finally:
+            reevr_amd.set_tuning("fwd_dif14", -1)
+        assert np.sqrt(np.mean((specs[mode] - want) ** 2)) / np.sqrt(np.mean(want ** 2)) <= 2e-6, mode
+        assert specs[mode][n // 2 + 1] == 0.0 and specs[mode][-1] == 0.0                        # im[0] = im[n/2] = 0 (AudioFFT.cpp:134-135)
+    assert np.sqrt(np.mean((specs[1] - specs[0]) ** 2)) / np.sqrt(np.mean(want ** 2)) <= 1e-6
     nch, head, tail, nblk = 301, 256, 8192, 64 * 6
     irs = [synth.synth_ir(2 * tail + 5 * tail - 101 * (c % 7), 1, 40 + c % 11)[0] for c in range(nch)]
     x = np.stack([synth.synth_input(head * nblk, 300 + c % 9) for c in range(nch)])
     dx = torch.from_numpy(x).cuda()
     outs = {}
     for mode in (0, 1):
-        s = reevr_amd.ConvolverSet(nch, tune={"inv_dif14": mode, "tail_slack": 1})
+        s = reevr_amd.ConvolverSet(nch, tune={"inv_dif14": mode, "fwd_dif14": mode, "tail_slack": 1})
         assert s.init(head, tail, irs, max_len=head), s.last_error_string
         assert s.tail_block == 2 * tail and s.plan()["tail_f64"] == 0
         outs[mode] = s.process_device_blocks(dx, head).cpu().numpy()
