@@ -41,8 +41,10 @@ def family(name: str, head_log: int, tail_log: int):
     m = re.search(r"k_fft8_(fwd|inv)_loop<(\d+)>", name)
     if m:
         return f"fft_{m.group(1)}_tail"
-    if "k_fft8_inv_dif2<" in name:           # the 8192-bin double inverse as two half-size sub-transforms (lock-step sets' tail)
+    if "k_fft8_inv_dif2<" in name:           # the 8192-bin double / 16384-bin float inverse as two half-size sub-transforms (lock-step sets' tail)
         return "fft_inv_tail"
+    if "k_fft8_fwd_dif2<" in name:           # the 16384-bin float forward the same way (round 6)
+        return "fft_fwd_tail"
     m = re.search(r"k_fir_row<(\d)>", name)
     if m:
         return "premultiply" if m.group(1) == "0" else "fir_tail"
