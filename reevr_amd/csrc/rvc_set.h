@@ -142,14 +142,13 @@ struct Tile {
   void load_phase(int p) { t0 = ph[p].t0; end = ph[p].end; s0 = ph[p].s0; fresh = ph[p].fresh; }
   void store_phase(int p) { ph[p].t0 = t0; ph[p].end = end; ph[p].s0 = s0; ph[p].fresh = fresh; }
   void start(long long b, int len) { t0 = b; end = b + len; s0 = -1; fresh = false; }
+  // anything that is not a block-synchronous single-block call (a multi-block call, the adaptive long-call path, clear(), init)
+  // drops the tiles; the next tile is a FIRST tile again -- shortened per group, so that the groups fall out of phase again
   void drop() {
-    t0 = s0 = end = -1; pend.on = false;
-    for (Phase &q : ph) { q.t0 = q.s0 = q.end = -1; q.pend.on = false; }
+    t0 = s0 = end = -1; pend.on = false; fresh = true;
+    for (Phase &q : ph) { q.t0 = q.s0 = q.end = -1; q.pend.on = false; q.fresh = true; }
   }
-  void restart() {                              // init / clear(): the next tile is a first tile again
-    drop(); fresh = true;
-    for (Phase &q : ph) q.fresh = true;
-  }
+  void restart() { drop(); }                    // init / clear()
   bool holds(long long b) const { return t0 >= 0 && b >= t0 && b < end; }
   // start of the kSweepRows-block group of the current tile that block b (t0 <= b < end) lies in
   long long group(long long b) const { return t0 + (b - t0) / rvc::kSweepRows * rvc::kSweepRows; }
