@@ -103,16 +103,16 @@ WORKLOADS = {
 HEADLINE_PLANS = {
     1: dict(subsets=4, two_stage=0, tail_on_second_stream=0, head_block=512, tail_block=0, zero_latency_samples=0,
             head_partitions=94, tail_partitions=0, tail_delay=0, head_f64=0, tail_f64=0, head_tile_blocks=32, tail_tile_blocks=0,
-            block_path=0, head_patch_in_launch=1),
+            block_path=0, head_patch_in_launch=1, head_third_level=1),
     2: dict(subsets=2, two_stage=1, tail_on_second_stream=0, head_block=512, tail_block=8192, zero_latency_samples=8192,
             head_partitions=16, tail_partitions=58, tail_delay=1, head_f64=0, tail_f64=2, head_tile_blocks=8, tail_tile_blocks=32,
-            block_path=0, head_patch_in_launch=1, reference_structure=0, tail_spread=0, tail_phase_groups=8),
+            block_path=0, head_patch_in_launch=1, reference_structure=0, tail_spread=0, tail_phase_groups=8, tail_third_level=1, head_third_level=1),
     3: dict(subsets=2, two_stage=1, tail_on_second_stream=0, head_block=256, tail_block=16384, zero_latency_samples=16384,
             head_partitions=64, tail_partitions=175, tail_delay=1, head_f64=0, tail_f64=0, head_tile_blocks=32, tail_tile_blocks=32,
-            block_path=0, head_patch_in_launch=1, reference_structure=0, tail_spread=0, tail_phase_groups=8),
+            block_path=0, head_patch_in_launch=1, reference_structure=0, tail_spread=0, tail_phase_groups=8, tail_third_level=1, head_third_level=0),
     5: dict(subsets=2, two_stage=1, tail_on_second_stream=0, head_block=4096, tail_block=8192, zero_latency_samples=8192,
             head_partitions=2, tail_partitions=29, tail_delay=1, head_f64=2, tail_f64=2, head_tile_blocks=0, tail_tile_blocks=16,
-            block_path=1, head_patch_in_launch=0, reference_structure=0, tail_spread=0, tail_phase_groups=8),
+            block_path=1, head_patch_in_launch=0, reference_structure=0, tail_spread=0, tail_phase_groups=8, tail_third_level=1, head_third_level=0),
 }
 
 
@@ -254,13 +254,20 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
         if conv.plan()["head_patch_in_launch"]:
             # round 5: the launch patches its OWN block and hands the row over through LDS -- audio part (H0, H1, X_{k-1} read; X_k
             # written; samples) + the block's sweep row + on average (K2-1)/2 recent partitions (an IR row and a delay-line row each)
-            exe["fused_block"] = 4 * row_h + io_blk + ((K2 - 1) / 2.0 * 2 + 1) * row_h
+            # round 6: the stage's sweeps take the newest row too (a patch is one partition shorter), and with head_third_level a
+            # third-level sweep half way through every group of 8 lets the last four blocks' patches start over
+            third_h = bool(conv.plan().get("head_third_level", 0))
+            mean_p = float(np.mean([max(0, (j % (K2 // 2) if third_h else j) - 1) for j in range(K2)]))
+            exe["fused_block"] = 4 * row_h + io_blk + (2 * mean_p + 1) * row_h
+            if third_h:          # 6 IR rows, 4 delay-line rows, the group's 4 rows read, 4 written
+                exe["sweep3_head"] = 18.0 * row_h
         else:
             # audio part (H0, H1, X_{k-1}, accumulator read; X_k written; samples) + on average (K2-1)/2 recent partitions patched
             exe["fused_block"] = 5 * row_h + io_blk + ((K2 - 1) / 2.0 * 2 + 2) * row_h * (K2 - 1) / K2
         # IR rows 2.. + arrived delay-line rows read once, KA partial rows written (the two newest partitions are the per-block launch's)
         exe["sweep_head"] = ((PA - 2) + (PA - 2) + KA) * row_h
-        exe["sweep2_head"] = sweep2_rows(KA, PA - 2, 2) * row_h
+        # (same-block sets: the stage's sweeps take the newest row -- lag 1 -- so a second-level walk is one partition shorter)
+        exe["sweep2_head"] = sweep2_rows(KA, PA - 2, 3 if conv.plan()["head_patch_in_launch"] else 2) * row_h
     else:                                                    # zero-latency stage not tiled: every block reads all of it
         exe["fused_block"] = 5 * row_h + io_blk + (2.0 * max(PA - 2, 0) + 1) * row_h
         # (many channels with a large head block: the per-block call is transform / delay line / inverse launches)
@@ -281,7 +288,12 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
             exe["sweep_tail"] = (2 * PT + KT) * row_t / (slices if l1 else 1) / G
             exe["sweep2_tail"] = (sweep2_rows(KT, PT, 2) + 2 * l1) * row_t / (slices if l2 else 1) / G
             # patch: the sweep row + the recent partitions (a group's first block needs none when its sweep is not spread), 1 row out
-            depth = [j + (l1 if g == 0 else l2) for g in range(max(1, KT // K2)) for j in range(K2)]
+            # third level (rvc_plan::tail_third_level): half way through a group a sweep over the 4 rows that arrived since (7 IR rows, 4
+            # delay-line rows, the group's 4 rows read, 4 written) gives the last four blocks rows of their own: their patches start over
+            third = bool(pl.get("tail_third_level", 0))
+            if third:
+                exe["sweep3_tail"] = 19.0 * row_t / G
+            depth = [(j - K2 // 2) if (third and j >= K2 // 2) else j + (l1 if g == 0 else l2) for g in range(max(1, KT // K2)) for j in range(K2)]
             per = [2 * d + 2 for d in depth if d > 0]
             exe["fir_tail"] = float(np.mean(per)) * row_t
             if G > 1:      # phase groups: ONE patch launch per tail block over all channels, every group at its own depth (depth 0: the row is copied)

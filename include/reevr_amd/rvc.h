@@ -279,6 +279,10 @@ typedef struct rvc_plan {
   int tail_phase_groups;        /* the tail stage's time tiles run in this many channel groups whose tiles are out of phase: in every tail
                                    period ONE group sweeps (its channels only) and every group patches at its own depth, so no call
                                    carries a sweep over the whole set; 1 = all channels in phase */
+  int tail_third_level;         /* 1: half way through every group of 8 tail blocks a third-level sweep over the four input rows that
+                                   arrived since gives the group's last four blocks rows of their own: a patch adds three partitions at
+                                   most (fewer bytes per tail block) */
+  int head_third_level;         /* 1: the same for the zero-latency stage (sets with head_patch_in_launch whose rows are large enough) */
 } rvc_plan;
 /* plan_size = sizeof(rvc_plan) as the caller compiled it: the struct only ever grows at its end, a caller compiled against a
  * shorter one gets the fields it knows (bytes beyond the library's own struct are zeroed). 1 = filled. */
@@ -287,7 +291,8 @@ int rvc_set_plan(const rvc_set *s, rvc_plan *plan, size_t plan_size);
 /* With RVC_FLAG_TIMING: accumulated HIP-event time of one kernel family since the last
  * rvc_set_kernel_time_reset. kernel: 0 ingest, 1 fft_fwd(head) 2 fir(head) 3 fft_inv(head),
  * 4 fft_fwd(tail) 5 fir(tail; time-tiled streaming: the patch launches) 6 fft_inv(tail), 7 fused single-block step,
- * 8 pre-multiply, 9 sweep(head) 10 sweep(tail) of the time-tiled delay lines.
+ * 8 pre-multiply, 9 sweep(head) 10 sweep(tail) of the time-tiled delay lines, 11 / 12 their second-level sweeps (head / tail),
+ * 13 / 14 the third-level sweeps (tail / head).
  * Synchronises the set. Returns launches. */
 long rvc_set_kernel_time(rvc_set *s, int kernel, double *total_ms);
 void rvc_set_kernel_time_reset(rvc_set *s);

@@ -80,7 +80,8 @@ const char *rvc_debug_tuning_keys(void);
  * let the block kernel read and write the pinned staging rows itself instead of DMA copies; "block_lanex" -1 by size / 0 / 1 the per-block
  * kernel of head 512 exchanges lane-locally between its last two radix-8 passes (v_permlane32_swap / v_permlane16_swap / DPP);
  * "inv_dif14" / "fwd_dif14" 0 = the 16384-bin float inverse / forward transform as ONE whole-CU workgroup per row (rounds 1-5) instead of
- * two 8192-point workgroups. */
+ * two 8192-point workgroups; "tail_third" -1 by size / 0 / 1 third-level sweeps of the tail stage's tiles (rvc_plan::tail_third_level);
+ * "head_third" the same for the zero-latency stage (rvc_plan::head_third_level). */
 int rvc_debug_set_tuning(const char *key, int value);
 /* Development net against out-of-bounds accesses of the kernels: with rvc_debug_set_tuning("guard", 1) in force when a set
  * is initialised, every device allocation of the set lies between two 256 KiB guard bands filled with 0xFF and starts out

@@ -120,7 +120,7 @@ class Plan(C.Structure):                # struct rvc_plan
                 ("head_tile_blocks", C.c_int), ("tail_tile_blocks", C.c_int), ("block_path", C.c_int),
                 ("reference_structure", C.c_int), ("long_call_block", C.c_size_t), ("wide_block", C.c_size_t),
                 ("head_patch_in_launch", C.c_int), ("tail_spread", C.c_int), ("tail_sweep_slices", C.c_int),
-                ("tail_phase_groups", C.c_int)]
+                ("tail_phase_groups", C.c_int), ("tail_third_level", C.c_int), ("head_third_level", C.c_int)]
 
 
 class ImpulseParams(C.Structure):       # struct rvc_impulse_params

@@ -358,7 +358,7 @@ class ConvolverSet:
 
 
 KERNEL_NAMES = ["ingest", "fft_fwd_head", "fir_head", "fft_inv_head", "fft_fwd_tail", "fir_tail", "fft_inv_tail",
-                "fused_block", "premultiply", "sweep_head", "sweep_tail", "sweep2_head", "sweep2_tail"]
+                "fused_block", "premultiply", "sweep_head", "sweep_tail", "sweep2_head", "sweep2_tail", "sweep3_tail", "sweep3_head"]
 
 
 def set_tuning(key: str, value: int) -> bool:

@@ -876,6 +876,8 @@ int rvc_set_plan(const rvc_set *s, rvc_plan *out, size_t out_size) {
     p.tail_spread = k->tT.on ? (k->tT.lag1 | (k->tT.lag2 << 1)) : 0;
     p.tail_sweep_slices = p.tail_spread ? sweep_slices(k) : 1;
     p.tail_phase_groups = k->tT.on ? k->tT.G : 1;
+    p.tail_third_level = (k->tT.on && k->tT.s3) ? 1 : 0;
+    p.head_third_level = (k->tA.on && k->tA.s3) ? 1 : 0;
     // the reference's structure at these sizes: head + tail0 cover IR[0, 2T) at the head block, the tail runs 2 blocks late
     p.reference_structure = (k->T.P == 0 || (k->T.delay == 2)) ? 1 : 0;
   }

@@ -235,6 +235,7 @@ int fir_time_tile(int M);
 // and the per-block patches still add at most 7 (+ 2 + lag) partitions: 2 P / K1 + K1 / 8 + 12 rows per block.
 constexpr int kSweepRows = 8;     // tile of the level the patches work on (second level, or the only one)
 constexpr int kSweepRowsMax = 32; // largest first-level tile
+constexpr int kThirdRows = 4;     // blocks a third-level sweep (half way through a group of kSweepRows) prepares
 constexpr int kTwoLevelMinP = 24; // up to this many partitions one level of 8 blocks is as good (P / 4 + 10 rows per block against
                                   // P / 8 + 12); measured at 32 partitions (config 2's zero-latency stage): 375 -> 365 B/sample, +2-4 %
 constexpr int kLongLineMinP = 48; // from this many partitions on the first level covers 32 blocks. Round 3: 80 (the one-wave 32-block sweep ran at

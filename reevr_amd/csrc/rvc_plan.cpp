@@ -19,7 +19,7 @@ struct TuneKey { const char *key; int Tuning::*m; int rvc::LaunchTune::*lm; };
 static const TuneKey kTuneKeys[] = {
     {"k1", &Tuning::k1, nullptr}, {"two_level_min_p", &Tuning::two_min_p, nullptr}, {"subsets", &Tuning::subsets, nullptr},
     {"tail_slack", &Tuning::tail_slack, nullptr}, {"kid_fence", &Tuning::kid_fence, nullptr}, {"guard", &Tuning::guard, nullptr}, {"mix64", &Tuning::mix64, nullptr},
-    {"same_block", &Tuning::same_block, nullptr}, {"tail_spread", &Tuning::tail_spread, nullptr}, {"kid_stagger", &Tuning::kid_stagger, nullptr}, {"tail_phases", &Tuning::tail_phases, nullptr}, {"host_zero_copy", &Tuning::host_zero_copy, nullptr},
+    {"same_block", &Tuning::same_block, nullptr}, {"tail_spread", &Tuning::tail_spread, nullptr}, {"kid_stagger", &Tuning::kid_stagger, nullptr}, {"tail_phases", &Tuning::tail_phases, nullptr}, {"tail_third", &Tuning::tail_third, nullptr}, {"head_third", &Tuning::head_third, nullptr}, {"host_zero_copy", &Tuning::host_zero_copy, nullptr},
     {"fft_loop", nullptr, &rvc::LaunchTune::fft_loop}, {"fft_many", nullptr, &rvc::LaunchTune::fft_many},
     {"tile_rot", nullptr, &rvc::LaunchTune::tile_rot}, {"block_occ", nullptr, &rvc::LaunchTune::block_occ},
     {"patch_nt", nullptr, &rvc::LaunchTune::patch_nt}, {"sweep_split", nullptr, &rvc::LaunchTune::sweep_split},

@@ -75,7 +75,10 @@ struct Timer {   // brackets one launch with events when timing is on
 // sweep would only fetch their IR rows to multiply them with rows that have not arrived (2 of 38 rows of config 2's sweep).
 // stage_lag: how far behind the block being prepared the newest input row lies that a sweep may use -- the zero-latency
 // stage's two newest partitions belong to the per-block launch, the tail's newest row is `delay` blocks back.
-int stage_lag(const rvc_set *s, bool tail) { return tail ? s->T.delay : 2; }
+// (Round 6: a zero-latency stage whose per-block launch patches its OWN block -- same_block -- runs every sweep for blocks kb..
+//  when row kb - 1 exists: behind the launch that completed block kb - 1, or in front of block kb's. Its sweeps take that row too --
+//  it meets block kb + 1 in partition 2 -- and every patch is one partition shorter: lag 1.)
+int stage_lag(const rvc_set *s, bool tail) { return tail ? s->T.delay : (s->same_block ? 1 : 2); }
 rvc::FirArgs stage_line(rvc_set *s, bool tail) {
   Stage &g = tail ? s->T : s->A;
   const long long B = (long long)g.B;
@@ -108,11 +111,31 @@ rvc::FirArgs sweep2_args(rvc_set *s, bool tail, long long g0) {
   r.P = (int)std::min<long long>(r.P, g0 - t.t0 + K - 1 + L + t.lag1 - r.delay);
   return r;
 }
+// third level: blocks [h, h + 4), h = g0 + 4 half way through the group that starts at g0: the group's rows (first-level ones for the
+// tile's first group, else second-level ones) + the input rows that group's sweep left out, up to h - L
+rvc::FirArgs sweep3_args(rvc_set *s, bool tail, long long g0, long long h) {
+  const Tile &t = tail ? s->tT : s->tA;
+  const long long K = rvc::kSweepRows, K3 = rvc::kThirdRows;
+  rvc::FirArgs r = stage_line(s, tail);
+  r.Y = t.s3; r.y_chan_stride = K3 * r.B; r.y_row_mask = (unsigned)(K3 - 1);
+  const bool first = g0 == t.t0 || t.K1 <= K;
+  if (first) { r.Ybase = t.s1; r.ybase_chan_stride = (long long)t.rows1 * r.B; r.ybase_row_mask = (unsigned)(t.rows1 - 1); }
+  else { r.Ybase = t.s2; r.ybase_chan_stride = K * r.B; r.ybase_row_mask = (unsigned)(K - 1); }
+  const long long L = stage_lag(s, tail), lagp = first ? t.lag1 : t.lag2;
+  r.k0 = h; r.M = (int)K3; r.x_from = g0 - L - lagp + 1; r.x_hi = h - L;
+  // the oldest row that counts (x_from) meets block h + 3 in partition h + 3 - delay - x_from
+  r.P = (int)std::min<long long>(r.P, h - g0 + K3 - 1 + L + lagp - r.delay);
+  return r;
+}
 // where the partial sums of block b live -- b inside the current first-level tile, and past its first group only once
 // that group's second-level sweep has run -- and the per-channel stride of those rows
 const float2 *tile_row(const rvc_set *s, bool tail, long long b, long long *stride) {
   const Tile &t = tail ? s->tT : s->tA;
   const size_t B = tail ? s->T.B : s->A.B;
+  if (t.third(b)) {
+    *stride = (long long)rvc::kThirdRows * (long long)B;
+    return t.s3 + (size_t)((unsigned long long)b & (unsigned long long)(rvc::kThirdRows - 1)) * B;
+  }
   if (t.K1 > rvc::kSweepRows && t.group(b) != t.t0) {
     *stride = (long long)rvc::kSweepRows * (long long)B;
     return t.s2 + (size_t)((unsigned long long)b & (unsigned long long)(rvc::kSweepRows - 1)) * B;
@@ -299,12 +322,18 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
         RVC_CK(rvc::launch_fdl_sweep(w, q.n, st));
         t.s0 = g0;
       }
+      if (t.s3 && m_lo == g0 + rvc::kThirdRows && t.h0 != m_lo) {     // half way through the group: third-level sweep
+        const rvc::FirArgs w = ranged(sweep3_args(s, true, g0, m_lo));
+        Timer tm(s, 13, st);
+        RVC_CK(rvc::launch_fdl_sweep(w, q.n, st));
+        t.h0 = m_lo;
+      }
       // the group's entry of the one patch launch below: its sweep row + the partitions whose input arrived since (none: a copy)
       long long stride = 0;
       const float2 *row = tile_row(s, true, m_lo, &stride);
       const int gi = pg.n_groups++;
       pg.c0[gi] = q.c0; pg.n[gi] = q.n;
-      pg.P[gi] = (int)std::min<long long>(m_lo - g0 + (g0 == t.t0 ? t.lag1 : 0), T.P);   // (a spread first-level sweep left its newest row out)
+      pg.P[gi] = (int)std::min<long long>(t.third(m_lo) ? m_lo - t.h0 : m_lo - g0 + (g0 == t.t0 ? t.lag1 : 0), T.P);   // (a spread first-level sweep left its newest row out)
       pg.Yadd[gi] = row; pg.yadd_chan_stride[gi] = stride;
       t.store_phase(p);
     }
@@ -332,10 +361,16 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
       RVC_CK(rvc::launch_fdl_sweep(w, s->nch, st));
       t.s0 = g0;
     }
+    if (t.s3 && m_lo == g0 + rvc::kThirdRows && t.h0 != m_lo) {       // half way through the group: third-level sweep
+      const rvc::FirArgs w = sweep3_args(s, true, g0, m_lo);
+      Timer tm(s, 13, st);
+      RVC_CK(rvc::launch_fdl_sweep(w, s->nch, st));
+      t.h0 = m_lo;
+    }
     long long stride = 0;
     const float2 *row = tile_row(s, true, m_lo, &stride);
-    // input rows that came after the sweep: g0 - td - lag + 1 .. m_lo - td (lag: that of the sweep the row is from)
-    const long long recent = m_lo - g0 + (g0 == t.t0 ? t.lag1 : t.lag2);
+    // input rows that came after the sweep: g0 - td - lag + 1 .. m_lo - td (lag: that of the sweep the row is from; third level: none)
+    const long long recent = t.third(m_lo) ? m_lo - t.h0 : m_lo - g0 + (g0 == t.t0 ? t.lag1 : t.lag2);
     if (recent > 0) {
       r.P = (int)std::min<long long>(recent, T.P);
       r.Yadd = row; r.yadd_chan_stride = stride;
@@ -483,9 +518,9 @@ rvc::FirArgs premultiply_args(rvc_set *s, long long kb) {
 }
 
 // A first-level sweep of the zero-latency stage for the tile of blocks starting at kb: partial sums of blocks
-// kb .. kb+K1-1 over the input rows that exist (<= kb - 2); row kb is complete (= sum_{i>=2} H_i X_{kb-i}).
+// kb .. kb+K1-1 over the input rows the sweep may use (<= kb - stage_lag); row kb is complete (= sum_{i>=2} H_i X_{kb-i}).
 bool run_head_sweep1(rvc_set *s, long long kb) {
-  const rvc::FirArgs r = sweep1_args(s, false, kb, kb - 2);
+  const rvc::FirArgs r = sweep1_args(s, false, kb, kb - stage_lag(s, false));
   {
     Timer t(s, 9, s->st_main);
     RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
@@ -505,6 +540,17 @@ bool run_head_sweep2(rvc_set *s, long long g0) {
   s->tA.s0 = g0;
   s->ypre_block = g0;
   s->ypre_cur = tile_row(s, false, g0, &s->ypre_cur_stride);
+  return true;
+}
+
+// The third-level sweep for blocks [h, h + 4), h = g0 + 4 half way through the group that starts at g0 (whose rows exist).
+bool run_head_sweep3(rvc_set *s, long long g0, long long h) {
+  const rvc::FirArgs r = sweep3_args(s, false, g0, h);
+  {
+    Timer t(s, 14, s->st_main);
+    RVC_CK(rvc::launch_fdl_sweep(r, s->nch, s->st_main));
+  }
+  s->tA.h0 = h;
   return true;
 }
 
@@ -628,7 +674,8 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
       Tile &ta = s->tA;
       const long long g0 = ta.group(k0);
       rvc::FirArgs f = premultiply_args(s, k0);                        // partitions 2.., delay 2, one row
-      f.P = (int)std::min<long long>(k0 - g0, (long long)A.P - 2);
+      // (the group's sweep took the rows <= g0 - stage_lag; the patch's newest row is k0 - 2)
+      f.P = (int)std::min<long long>((ta.third(k0) ? k0 - ta.h0 : k0 - g0) - (2 - stage_lag(s, false)), (long long)A.P - 2);
       f.Yadd = tile_row(s, false, k0, &f.yadd_chan_stride);
       f.Y = nullptr;
       if (f.P < 0) f.P = 0;
@@ -642,6 +689,9 @@ bool step_device(rvc_set *s, const float *d_in, size_t in_stride, float *d_out, 
         const long long kn = k0 + 1;
         if (!(kn > ta.t0 && kn < ta.t0 + ta.K1)) { if (!run_head_sweep1(s, kn)) return false; }
         else if (ta.group(kn) == kn && ta.s0 != kn) { if (!run_head_sweep2(s, kn)) return false; }
+        else if (ta.s3 && kn == ta.group(kn) + rvc::kThirdRows && ta.h0 != kn && (ta.group(kn) == ta.t0 || ta.s0 == ta.group(kn))) {
+          if (!run_head_sweep3(s, ta.group(kn), kn)) return false;        // half way through the group
+        }
       }
       s->ypre_block = -1;
     } else if (s->fold) {

@@ -23,7 +23,7 @@
 namespace rvc_eng {
 
 constexpr double kPi = 3.14159265358979323846264338327950288;
-constexpr int kNumKernelIds = 13;
+constexpr int kNumKernelIds = 15;
 // delay-1 tail stage (do_init): sets of at least this many lock-step channels; widened when the tail would have at least
 // kWidenMinP partitions at the requested block -- kWidenMinPShort when the widened block is below 16384, whose transforms run
 // two to four workgroups per CU instead of one (measured on MI355X, profiles/r4_tail_slack.txt: head 512 / tail 8192: 117
@@ -54,6 +54,12 @@ constexpr bool kKidStaggerDefault = false;
 // channels, cost of the worst per-block call / rate: in phase 8.6 ms / 18.26 Gsamples/s; 2 groups 4.6 / 18.20; 4: 3.0 / 18.40;
 // 8: 1.8 ms / 18.21 -- against spread sweeps: first level 3.8 / 17.88, both levels 1.3 ms / 17.10 (a partition more per patch)
 constexpr int kPhasesDefault = 8;
+// Third-level sweeps of the tail tiles of such sets (Tile::s3): measured on MI355X, profiles/r6_third_level.txt
+constexpr bool kThirdDefault = true;
+// ... and of the zero-latency stage (same-block sets): where a row of all channels is at least this many bytes (below it the extra
+// launch's ramp costs what the shorter patches save: measured on MI355X, profiles/r6_third_level.txt -- BASELINE config 3's 2048 x
+// 256-bin rows, 4 MiB: -1.4 %; config 2's 16 MiB +1.3 %, config 1's 32 MiB +5.5 %)
+constexpr size_t kHeadThirdMinRowBytes = (size_t)8 << 20;
 // ... and where a tail period is at least this many calls long, each group's first-level sweep would ALSO be spread over the calls of
 // the period before (Tile::lag1 with phase groups; knob tail_spread = 1 on top of the phase groups). Measured on MI355X
 // (profiles/r6_call_cost.txt): BASELINE config 3 (64 calls per tail period, block period 2.67 ms) worst call 2.13 -> 1.18 ms, p99 1.06 ->
@@ -114,6 +120,12 @@ struct Tile {
   long long t0 = -1;             // blocks [t0, end) have first-level rows; -1: none
   long long end = -1;            // t0 + K1 -- less for the FIRST tile after the clock (re)starts of a child set (first_len)
   long long s0 = -1;             // blocks [s0, s0 + kSweepRows), s0 > t0, have second-level rows; -1: none
+  // Third level (tail stage of many-channel sets; round 6): half way through every group of 8 -- block h = g0 + 4 -- a sweep over the
+  // FOUR input rows that arrived since the group's own sweep gives blocks [h, h + 4) rows of their own (s3 = the group's row + those
+  // rows' partitions), so a patch never adds more than three partitions: per tail block and channel 5 + 19 / 8 rows instead of 9
+  // (rvc_schedule.cpp sweep3_args).
+  float2 *s3 = nullptr;          // [nch][kThirdRows][B]; nullptr: no third level
+  long long h0 = -1;             // blocks [h0, h0 + kThirdRows) have third-level rows; -1: none
   // Spread sweeps (tail stage of many-channel sets, rvc_schedule.cpp "Uniform call cost"): a sweep with lag 1 leaves out the newest
   // row that exists when its first block is due (x_hi one older; the patches add one more partition), so it can be issued ONE
   // TAIL PERIOD EARLIER -- in channel slices behind the per-block launches of that period instead of inside the one call that
@@ -138,18 +150,19 @@ struct Tile {
   // works on it (load_phase / store_phase); the zero-latency stage has one group and uses them directly.
   static constexpr int kMaxPhases = 8;
   int G = 1;
-  struct Phase { long long t0 = -1, end = -1, s0 = -1; bool fresh = true; int phi = 0; int c0 = 0, n = 0; Pending pend; } ph[kMaxPhases];
-  void load_phase(int p) { t0 = ph[p].t0; end = ph[p].end; s0 = ph[p].s0; fresh = ph[p].fresh; }
-  void store_phase(int p) { ph[p].t0 = t0; ph[p].end = end; ph[p].s0 = s0; ph[p].fresh = fresh; }
-  void start(long long b, int len) { t0 = b; end = b + len; s0 = -1; fresh = false; }
+  struct Phase { long long t0 = -1, end = -1, s0 = -1, h0 = -1; bool fresh = true; int phi = 0; int c0 = 0, n = 0; Pending pend; } ph[kMaxPhases];
+  void load_phase(int p) { t0 = ph[p].t0; end = ph[p].end; s0 = ph[p].s0; h0 = ph[p].h0; fresh = ph[p].fresh; }
+  void store_phase(int p) { ph[p].t0 = t0; ph[p].end = end; ph[p].s0 = s0; ph[p].h0 = h0; ph[p].fresh = fresh; }
+  void start(long long b, int len) { t0 = b; end = b + len; s0 = -1; h0 = -1; fresh = false; }
   // anything that is not a block-synchronous single-block call (a multi-block call, the adaptive long-call path, clear(), init)
   // drops the tiles; the next tile is a FIRST tile again -- shortened per group, so that the groups fall out of phase again
   void drop() {
-    t0 = s0 = end = -1; pend.on = false; fresh = true;
-    for (Phase &q : ph) { q.t0 = q.s0 = q.end = -1; q.pend.on = false; q.fresh = true; }
+    t0 = s0 = h0 = end = -1; pend.on = false; fresh = true;
+    for (Phase &q : ph) { q.t0 = q.s0 = q.h0 = q.end = -1; q.pend.on = false; q.fresh = true; }
   }
   void restart() { drop(); }                    // init / clear()
   bool holds(long long b) const { return t0 >= 0 && b >= t0 && b < end; }
+  bool third(long long b) const { return s3 && h0 >= 0 && b >= h0 && b < h0 + rvc::kThirdRows; }   // block b has third-level rows
   // start of the kSweepRows-block group of the current tile that block b (t0 <= b < end) lies in
   long long group(long long b) const { return t0 + (b - t0) / rvc::kSweepRows * rvc::kSweepRows; }
 };
@@ -173,6 +186,8 @@ struct Tuning {
   int tail_spread = -1;   // "tail_spread": sweeps of the tail stage issued a tail period early in channel slices behind the per-block
                           // launches (Tile::lag1 / lag2): -1 by size, else bit 0 the first-level sweeps, bit 1 the second-level ones
   int kid_stagger = -1;   // "kid_stagger": child k of n starts its tail tiles k * 8 / n blocks out of phase: -1 default / 0 off / 1 on
+  int head_third = -1;    // "head_third": the same for the zero-latency stage of sets whose per-block launch patches its own block: -1 by size, 0, 1
+  int tail_third = -1;    // "tail_third": third-level sweeps of the tail stage's tiles (Tile::s3): -1 by size, 0 off, 1 on
   int tail_phases = -1;   // "tail_phases": phase groups of the tail stage's tiles (Tile::G): -1 by size, else 1 (none) .. 8
   int host_zero_copy = -1; // "host_zero_copy": host-pointer per-block calls let the kernel read / write the pinned staging rows itself
                           // (no DMA copies): -1 by size (up to kZeroCopyMaxBytes per call), 0 never, 1 whenever legal

@@ -179,7 +179,7 @@ void free_device_state(rvc_set *s) {
   free_stage(s, s->T);
   free_stage(s, s->W);
   dev_free(s, s->xring); dev_free(s, s->tailring); dev_free(s, s->d_in); dev_free(s, s->d_out); dev_free(s, s->ypre);
-  dev_free(s, s->tA.s1); dev_free(s, s->tA.s2); dev_free(s, s->tT.s1); dev_free(s, s->tT.s2);
+  dev_free(s, s->tA.s1); dev_free(s, s->tA.s2); dev_free(s, s->tA.s3); dev_free(s, s->tT.s1); dev_free(s, s->tT.s2); dev_free(s, s->tT.s3);
   s->ypre = nullptr;
   s->tA = Tile(); s->tT = Tile();
   s->ypre_cur = nullptr;
@@ -527,6 +527,9 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
       if (s->tune.tail_spread < 0) tT.lag1 = (can && cpp >= kSpreadPhasesMinCalls) ? 1 : 0;
     }
     tT.G = G;
+    // third-level sweeps (Tile::s3): many-channel sets -- where a patch's rows are bandwidth, not latency; knob "tail_third"
+    const bool third = tT.on && (s->tune.tail_third >= 0 ? s->tune.tail_third != 0 : (nch_all >= kSpreadMinChannels && kThirdDefault));
+    if (third) RVC_CK(dev_alloc(s, &tT.s3, sizeof(float2) * (size_t)s->nch * (size_t)rvc::kThirdRows * T.B));
     for (int p = 0; p < G; ++p) {
       Tile::Phase &q = tT.ph[p];
       q = Tile::Phase();
@@ -537,6 +540,13 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     }
   }
   s->same_block = s->tA.on && rvc::fused_same_block(A.logB) && s->tune.same_block != 0;
+  {
+    // third-level sweeps of the zero-latency stage (Tile::s3; same-block sets only: their sweeps run when the newest row exists)
+    const int nch_all = s->plan_nch ? s->plan_nch : s->nch;
+    const bool third = s->same_block && (s->tune.head_third >= 0 ? s->tune.head_third != 0
+                                                                 : (kThirdDefault && (size_t)nch_all * A.B * sizeof(float2) >= kHeadThirdMinRowBytes));
+    if (third) RVC_CK(dev_alloc(s, &s->tA.s3, sizeof(float2) * (size_t)s->nch * (size_t)rvc::kThirdRows * A.B));
+  }
   RVC_CK(dev_alloc(s, &s->d_in, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(dev_alloc(s, &s->d_out, sizeof(float) * (size_t)s->nch * s->max_len));
   RVC_CK(hipHostMalloc(&s->h_in, sizeof(float) * (size_t)s->nch * s->max_len, hipHostMallocDefault));

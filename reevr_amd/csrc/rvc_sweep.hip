@@ -208,7 +208,7 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
 // 0.73 / 0.65 / 0.49 of the HBM peak at 4 / 16 / 32 KiB bodies); this body is 8 KiB at K = 32.
 template <int K, int D, int LW, bool NT, bool NTH = NT>   // NTH: the IR rows' loads non-temporal (also where the delay line's are ordinary)
 __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_tile, const int c) {
-  constexpr int U = 8, WN = K + U - 1;
+  constexpr int U = K < 8 ? K : 8, WN = K + U - 1;
   static_assert(U % D == 0 && K % U == 0, "queue / window indexing");
   typedef typename SweepVec<LW>::T V;
   constexpr int BPL = LW / 2;
@@ -620,7 +620,11 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
   // K = 16 / 32 (first level of long delay lines): 8 B per lane -- 2 K registers of accumulators, 2 K of window.
   const bool deep = launch_tune().sweep_d == 8;           // (measurement: 8 row pairs requested ahead instead of 4)
   const bool lds_ok = a.B >= 128 && a.Ybase == nullptr && launch_tune().sweep_lds != 0;
-  if (a.M == 32 && lds_ok) {
+  if (a.M == kThirdRows) {
+    // third-level sweeps (four blocks, four input rows, seven partitions): the second-level form with four accumulators
+    if (a.stream) launch_variant<kThirdRows, 1, STAGE, 4, 4, 4, false, true>(a, channels, st);
+    else launch_variant<kThirdRows, 1, STAGE, 4, 4, 4, false>(a, channels, st);
+  } else if (a.M == 32 && lds_ok) {
     // Measured on MI355X (profiles/r4_sweep_lds.txt): rings ONE chunk ahead (32 KiB: five workgroups = 20 waves per CU) beat
     // three chunks ahead (48 KiB, three workgroups) on 512-bin rows -- config 1's 94-partition line 1.50 (one-wave form) / 1.47 /
     // 1.35 ms per 8192-channel launch -- and tie on 8192-bin rows (config 3's 350 partitions: 23.6 / 23.3 / 23.2 ms), where every
@@ -667,7 +671,7 @@ static void launch_stage(const FirArgs &a, int channels, hipStream_t st) {
 
 hipError_t launch_fdl_sweep(const FirArgs &a0, int channels, hipStream_t st) {
   if (channels <= 0 || a0.P <= 0) return hipSuccess;
-  if (a0.M != 8 && a0.M != 16 && a0.M != 32) return hipErrorInvalidValue;
+  if (a0.M != 8 && a0.M != 16 && a0.M != 32 && !(a0.M == kThirdRows && a0.Ybase)) return hipErrorInvalidValue;
   // Does anything of this stage survive in a cache between two visits? Its IR spectra alone (h_chan_stride = all partitions of a
   // channel) against twice the 256 MiB last-level cache: config 2's tail 7.8 GB and config 1's 8192-channel head 790 MB per child
   // set stream (non-temporal row stores / second-level IR loads: +2-4 % / +4-10 %), config 2's and 3's heads (134 MB per child,

@@ -688,7 +688,9 @@ def test_fuzz_geometry_and_call_pattern(seed, tiling):
 @pytest.mark.parametrize("tiling", [True, False, "force", "force2", "force2_k32", "widen", "shrink_force2",
                                     "spread1_force2_k32", "spread3_force2", "spread3_shrink_force2", "spread3_widen", "spread2_force2_k32",
                                     "phases_force2_k32", "phases_force2", "phases_shrink_force2", "phases_widen", "phases_force",
-                                    "phspread_force2_k32", "phspread_shrink_force2", "phspread_widen"])
+                                    "phspread_force2_k32", "phspread_shrink_force2", "phspread_widen",
+                                    "third_force", "third_force2_k32", "third_phases_force2_k32", "third_phases_shrink_force2", "third_phases_widen",
+                                    "third_phases_force", "third_spread3_force2", "third_phspread_force2_k32"])
 @pytest.mark.parametrize("seed", list(range(24)) + [226])   # 226: 3 tail partitions on 4 sweep waves (a wave without work)
 def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     """The plug-in's calling pattern -- one call per host block, now and then a ragged one, several calls inside one
@@ -696,8 +698,13 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     time tiling off, on by size (default) and forced: every output sample against the oracle.
     spreadN_*: the tail stage's sweeps issued a tail period early in channel slices behind the per-block calls (knob
     tail_spread = N: bit 0 first-level, bit 1 second-level sweeps; what sets of >= 256 channels run by default) on top of the
-    named tiling mode -- planned sweeps meeting ragged calls, multi-block calls (which drop them) and clear()."""
+    named tiling mode -- planned sweeps meeting ragged calls, multi-block calls (which drop them) and clear().
+    third_*: third-level sweeps half way through every group of 8 tail blocks (knob tail_third; what sets of >= 256 channels run by
+    default) on top of the named mode."""
     spread = phases = 0
+    third = -1
+    if str(tiling).startswith("third_"):
+        third, tiling = 1, tiling[6:]
     if str(tiling).startswith("spread"):
         spread, tiling = int(tiling[6]), tiling[8:]
     elif str(tiling).startswith("phases_"):      # the tail tiles in channel groups out of phase (tail_phases; one group per channel here)
@@ -737,9 +744,11 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
         tiling = "force" if slack == 1 else "force2"
     if spread:
         bg = False                                               # (a tail job on the second stream is never spread)
-    with reevr_amd.tuning(k1=32 if tiling == "force2_k32" else 0, tail_slack=slack, tail_spread=spread, tail_phases=phases or -1):   # (k1 = 32: first-level tiles of 32 blocks)
+    with reevr_amd.tuning(k1=32 if tiling == "force2_k32" else 0, tail_slack=slack, tail_spread=spread, tail_phases=phases or -1, tail_third=third, head_third=third):   # (k1 = 32: first-level tiles of 32 blocks)
         s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling="force2" if tiling == "force2_k32" else tiling, fft_f32=slack > 0)
         assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
+    assert s.plan()["tail_third_level"] == (1 if third > 0 and s.tile_rows(1) else 0)
+    assert s.plan()["head_third_level"] == (1 if third > 0 and s.plan()["head_patch_in_launch"] else 0)
     if spread and s.tile_rows(1):
         assert s.plan()["tail_spread"] == ((spread if s.tile_rows(1) > 8 else spread & 1) if not phases else spread & 1)
     if phases and s.tile_rows(1):

@@ -50,7 +50,11 @@ def run_lockstep(nch, cfg, irs, xs, period, nblk, host_block, tail, subsets, che
     import torch
     full_irs = [irs[c % period] for c in range(nch)]
     dx = torch.from_numpy(np.stack(xs)).cuda().repeat(nch // period, 1)     # row c = xs[c % period]
-    s = reevr_amd.ConvolverSet(nch, tune=dict(tune or {}, subsets=subsets))
+    # (what the engine decides by the SIZE of the set is pinned to the bench's plan: the child sets, the zero-latency stage's third level)
+    by_size = dict(subsets=subsets)
+    if tune is None:
+        by_size["head_third"] = _bench().HEADLINE_PLANS[cfg].get("head_third_level", 0)
+    s = reevr_amd.ConvolverSet(nch, tune=dict(tune or {}, **by_size))
     ok = s.init(host_block, tail, full_irs, max_len=host_block) if tail else s.init_uniform(host_block, full_irs, max_len=host_block)
     assert ok, s.last_error_string
     if tune is None:

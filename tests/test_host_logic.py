@@ -97,11 +97,12 @@ def test_stage_plan_policy():
 class _SetGeometry:
     """what bench.executed_bytes asks a ConvolverSet for"""
 
-    def __init__(self, parts, tiles, tail_block, subsets=1, patch_in_launch=0, phases=1):
-        self._p, self._t, self.tail_block, self.subsets, self._pil, self._ph = parts, tiles, tail_block, subsets, patch_in_launch, phases
+    def __init__(self, parts, tiles, tail_block, subsets=1, patch_in_launch=0, phases=1, third=(0, 0)):
+        self._p, self._t, self.tail_block, self.subsets, self._pil, self._ph, self._third = parts, tiles, tail_block, subsets, patch_in_launch, phases, third
 
     def plan(self):
-        return {"head_patch_in_launch": self._pil, "tail_phase_groups": self._ph, "tail_spread": 0, "tail_sweep_slices": 1}
+        return {"head_patch_in_launch": self._pil, "tail_phase_groups": self._ph, "tail_spread": 0, "tail_sweep_slices": 1,
+                "head_third_level": self._third[0], "tail_third_level": self._third[1]}
 
     def partitions(self, stage):
         return self._p[stage]
@@ -117,12 +118,13 @@ def test_executed_bytes_model_against_the_committed_counter_passes():
     (profiles/r6_traffic.json, rocprofv3 FETCH_SIZE / WRITE_SIZE): within 5 % for every family, none missing. Round 6: the tail tiles run
     in 8 channel groups out of phase -- every sweep / patch launch of the tail stage covers an eighth of the channels. Round 5: the per-block
     launch of configs 1 / 2 / 3 (heads 512 / 512 / 256) patches its own block and hands the row over through LDS (no accumulator
-    round trip through memory); config 5's head of 4096 keeps the general per-block path."""
+    round trip through memory); config 5's head of 4096 keeps the general per-block path. Round 6, later: third-level sweeps (tail: all
+    four; zero-latency stage: configs 1 / 2) and the zero-latency stage's sweeps taking the newest row."""
     b = _bench()
-    cases = {2: (4096, 512, 8192, 480000, _SetGeometry((16, 58), (8, 32), 8192, patch_in_launch=1, phases=8)),
-             3: (2048, 256, 8192, 2880000, _SetGeometry((64, 175), (32, 32), 16384, patch_in_launch=1, phases=8)),
-             5: (4096, 4096, 8192, 240000, _SetGeometry((2, 29), (0, 16), 8192, phases=8)),
-             1: (8192, 512, 0, 48000, _SetGeometry((94, 0), (32, 0), 0, patch_in_launch=1))}
+    cases = {2: (4096, 512, 8192, 480000, _SetGeometry((16, 58), (8, 32), 8192, patch_in_launch=1, phases=8, third=(1, 1))),
+             3: (2048, 256, 8192, 2880000, _SetGeometry((64, 175), (32, 32), 16384, patch_in_launch=1, phases=8, third=(0, 1))),
+             5: (4096, 4096, 8192, 240000, _SetGeometry((2, 29), (0, 16), 8192, phases=8, third=(0, 1))),
+             1: (8192, 512, 0, 48000, _SetGeometry((94, 0), (32, 0), 0, patch_in_launch=1, third=(1, 0)))}
     for cfg, (nch, head, tail, ir_len, conv) in cases.items():
         exe = b.executed_bytes(conv, nch, head, tail, ir_len, head, True)
         traffic, src = b.load_traffic(nch, cfg, True)
@@ -215,6 +217,7 @@ def test_pmc_summary_kernel_families():
     assert fam("void rvc::k_fft8_inv_dif2<12, double>(rvc::InvArgs, int)") == "fft_inv_tail"
     # the sweeps' trailing NTH argument (IR rows non-temporal where the delay-line rows' loads are ordinary: big stages' second level)
     assert fam("void rvc::k_fdl_sweep<8, 1, 1, 4, 4, 3, false, true>(rvc::FirArgs, int)") == "sweep2_tail"
+    assert fam("void rvc::k_fdl_sweep<4, 1, 1, 4, 4, 4, false, true>(rvc::FirArgs, int)") == "sweep3_tail"     # round 6: third level
     assert fam("void rvc::k_fdl_sweep<8, 1, 0, 4, 4, 3, false, false>(rvc::FirArgs, int)") == "sweep2_head"
     assert fam("void rvc::k_fdl_sweep<8, 1, 0, 4, 4, 3, true, true>(rvc::FirArgs, int)") == "sweep_head"
     assert fam("void rvc::k_fdl_sweep<16, 1, 1, 4, 4, 2, true, true>(rvc::FirArgs, int)") == "sweep_tail"

@@ -34,6 +34,8 @@ def family(name: str, head_log: int, tail_log: int):
         st = "head" if m.group(3) == "0" else "tail"
         # second-level sweeps are exactly the own-tile K = 8 instantiation with ordinary loads (rvc_sweep.hip launch_stage)
         second = m.group(1) == "8" and m.group(2) == "1" and m.group(4) == "false"
+        if m.group(1) == "4":                # round 6: third-level sweeps (four blocks half way through a group of 8)
+            return "sweep3_" + st
         return ("sweep2_" if second else "sweep_") + st
     m = re.search(r"k_fdl_sweep_lds<\d+, \d+, \d+, (\d), (?:true|false), \d+(?:, (?:true|false))?>", name)   # <KW, NKW, A, STAGE, NT, LB, M3>: first level only
     if m:
