@@ -296,8 +296,9 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
             depth = [(j - K2 // 2) if (third and j >= K2 // 2) else j + (l1 if g == 0 else l2) for g in range(max(1, KT // K2)) for j in range(K2)]
             per = [2 * d + 2 for d in depth if d > 0]
             exe["fir_tail"] = float(np.mean(per)) * row_t
-            if G > 1:      # phase groups: ONE patch launch per tail block over all channels, every group at its own depth (depth 0: the row is copied)
-                exe["fir_tail"] = float(np.mean([2 * d + 2 for d in depth])) * row_t
+            if G > 1:      # phase groups: ONE patch launch per tail block over all channels, every group at its own depth (depth 0: the
+                # group's sweep of that block wrote the row in place, FirArgs::Y0 -- nothing to do)
+                exe["fir_tail"] = float(np.mean([2 * d + 2 if d > 0 else 0 for d in depth])) * row_t
         else:
             exe["fir_tail"] = (2.0 * PT + 1) * row_t
         exe["fft_fwd_tail"] = float(n1 * (4 * 2 * tail_x + 8 * tail_x))

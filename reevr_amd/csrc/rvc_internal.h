@@ -73,6 +73,8 @@ struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency
   const float2 *Ybase;      // sweep: optional rows added to the output rows
   long long ybase_chan_stride;
   unsigned ybase_row_mask;
+  float2 *Y0;               // sweep: optional [channel][B]: the row of block k0 -- complete when the sweep took every row that exists -- goes
+  long long y0_chan_stride; // HERE instead of its slot of Y (phase groups: straight into the row the inverse transform reads, no copy)
   int stream;               // sweep (set by launch_fdl_sweep): the stage's IR spectra of this launch exceed the last-level cache:
                             // accumulator rows are stored non-temporally, second-level sweeps load their IR rows non-temporally
   int stage_channels;       // sweeps and patches: this launch covers a SLICE of the channels of a stage of stage_channels of them (0: all of
@@ -80,7 +82,8 @@ struct FirArgs {            // Y[k] = sum_i H[i] * X[k - delay - i]   (frequency
 };
 
 // Patches of the phase groups of a tail stage in ONE launch (launch_fdl_patch_groups): channels [c0, c0 + n) of group g add P
-// recent partitions to the row Yadd + c * yadd_chan_stride (c = the channel's index in the launch); P = 0 copies the row.
+// recent partitions to the row Yadd + c * yadd_chan_stride (c = the channel's index in the launch); P = 0 copies the row, P < 0: nothing
+// to do (the group's sweep of this very block wrote the row where the patch would, FirArgs::Y0).
 struct PatchGroups {
   static constexpr int kMax = 8;
   int n_groups;

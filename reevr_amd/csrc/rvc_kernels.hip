@@ -2184,6 +2184,7 @@ __global__ void __launch_bounds__(256) k_fdl_patch_groups(const FirArgs a0, cons
 #pragma unroll
   for (int i = 1; i < PatchGroups::kMax; ++i)
     if (i < g.n_groups && c >= g.c0[i]) k = i;
+  if (g.P[k] < 0) return;                  // (the group's sweep of this block wrote the row itself: FirArgs::Y0)
   FirArgs a = a0;
   a.P = g.P[k]; a.Yadd = g.Yadd[k]; a.yadd_chan_stride = g.yadd_chan_stride[k];
   fdl_patch_any<NT>(a, rot ? (int)((blockIdx.x + blockIdx.y) % gridDim.x) : (int)blockIdx.x, c);
@@ -2695,8 +2696,12 @@ hipError_t launch_fir(const FirArgs &a, int channels, hipStream_t st) {
 
 hipError_t launch_fdl_patch_groups(const FirArgs &a, const PatchGroups &g, int channels, hipStream_t st) {
   if (channels <= 0 || g.n_groups <= 0 || (a.B % 2) != 0) return hipErrorInvalidValue;
-  for (int i = 0; i < g.n_groups; ++i)
-    if (g.P[i] < 0 || g.P[i] > kPatchMax || !g.Yadd[i]) return hipErrorInvalidValue;
+  bool any = false;
+  for (int i = 0; i < g.n_groups; ++i) {
+    if (g.P[i] > kPatchMax || !g.Yadd[i]) return hipErrorInvalidValue;
+    any = any || g.P[i] >= 0;                    // (P < 0: the group's row is in place already)
+  }
+  if (!any) return hipSuccess;
   const dim3 grid((a.B + 511) / 512, channels), block(256);
   const bool nt = launch_tune().patch_nt != 0 && (long long)channels * a.B >= (1ll << 20);
   const int rot = (grid.x >= 8 && launch_tune().tile_rot) ? 1 : 0;

@@ -306,24 +306,31 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
         a.stage_channels = s->nch;
         return a;
       };
+      // a sweep that starts at THIS block and took every row that exists leaves block m_lo's row complete: it writes that row where
+      // the patch launch would (FirArgs::Y0 = the group's rows of T.Y) and the group sits the patch launch out
+      bool row_done = false;
+      auto direct = [&](rvc::FirArgs a, bool complete) {
+        if (complete && a.k0 == m_lo) { a.Y0 = r.Y + (long long)q.c0 * r.y_chan_stride; a.y0_chan_stride = r.y_chan_stride; row_done = true; }
+        return a;
+      };
       t.load_phase(p);
       if (!launch_sweep_slice(s, t.ph[p].pend, 1 << 30, st)) return false;     // (what the calls in between did not carry of a spread sweep)
       if (!t.holds(m_lo)) {
         const int len = t.fresh ? std::max(1, t.K1 - q.phi) : t.K1;
         t.start(m_lo, len);
-        const rvc::FirArgs w = ranged(sweep1_args(s, true, m_lo, m_lo - td - t.lag1));
+        const rvc::FirArgs w = direct(ranged(sweep1_args(s, true, m_lo, m_lo - td - t.lag1)), t.lag1 == 0);
         Timer tm(s, 10, st);
         RVC_CK(rvc::launch_fdl_sweep(w, q.n, st));
       }
       const long long g0 = t.group(m_lo);
       if (g0 != t.t0 && t.s0 != g0) {
-        const rvc::FirArgs w = ranged(sweep2_args(s, true, g0));
+        const rvc::FirArgs w = direct(ranged(sweep2_args(s, true, g0)), t.lag2 == 0);
         Timer tm(s, 12, st);
         RVC_CK(rvc::launch_fdl_sweep(w, q.n, st));
         t.s0 = g0;
       }
       if (t.s3 && m_lo == g0 + rvc::kThirdRows && t.h0 != m_lo) {     // half way through the group: third-level sweep
-        const rvc::FirArgs w = ranged(sweep3_args(s, true, g0, m_lo));
+        const rvc::FirArgs w = direct(ranged(sweep3_args(s, true, g0, m_lo)), true);
         Timer tm(s, 13, st);
         RVC_CK(rvc::launch_fdl_sweep(w, q.n, st));
         t.h0 = m_lo;
@@ -334,6 +341,7 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
       const int gi = pg.n_groups++;
       pg.c0[gi] = q.c0; pg.n[gi] = q.n;
       pg.P[gi] = (int)std::min<long long>(t.third(m_lo) ? m_lo - t.h0 : m_lo - g0 + (g0 == t.t0 ? t.lag1 : 0), T.P);   // (a spread first-level sweep left its newest row out)
+      if (row_done) pg.P[gi] = -1;
       pg.Yadd[gi] = row; pg.yadd_chan_stride[gi] = stride;
       t.store_phase(p);
     }

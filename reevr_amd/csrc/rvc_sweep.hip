@@ -174,6 +174,7 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
   }
 
   float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
+  float2 *Y0c = a.Y0 ? a.Y0 + (long long)c * a.y0_chan_stride + bin : nullptr;                 // (FirArgs::Y0: where block k0's row goes)
   const float2 *Yb = a.Ybase ? a.Ybase + (long long)c * a.ybase_chan_stride + bin : nullptr;   // second level: + first-level rows
   if constexpr (SPLIT == 1) {
     if (active) {
@@ -181,7 +182,7 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
       for (int t = 0; t < K; ++t) {
         V r = acc[t];
         if (Yb) sweep_add(r, *reinterpret_cast<const V *>(Yb + (long long)((unsigned)(a.k0 + t) & a.ybase_row_mask) * B));
-        *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
+        *reinterpret_cast<V *>((t == 0 && Y0c) ? Y0c : Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
       }
     }
   } else {
@@ -195,7 +196,7 @@ __device__ __forceinline__ void fdl_sweep_body(const FirArgs &a, typename SweepV
 #pragma unroll
         for (int v = 1; v < SPLIT; ++v) sweep_add(r, red[v][t][lane]);
         if (Yb) sweep_add(r, *reinterpret_cast<const V *>(Yb + (long long)((unsigned)(a.k0 + t) & a.ybase_row_mask) * B));
-        *reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
+        *reinterpret_cast<V *>((t == 0 && Y0c) ? Y0c : Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B) = r;
       }
     }
   }
@@ -295,6 +296,7 @@ __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_til
   }
   if (active) {
     float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
+    float2 *Y0c = a.Y0 ? a.Y0 + (long long)c * a.y0_chan_stride + bin : nullptr;   // (FirArgs::Y0: block k0's row, read again at once: ordinary store)
     const bool nts = a.stream != 0;                  // (uniform)
     if (a.Ybase) {
       // second level: + the first-level rows. ALL K requests first, then the stores: written as load / add / store per row
@@ -308,11 +310,15 @@ __device__ __forceinline__ void fdl_sweep_own(const FirArgs &a, const int wg_til
       for (int t = 0; t < K; ++t) {
         V r = acc[t];
         sweep_add(r, yb[t]);
-        sweep_st(reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B), r, nts);
+        if (t == 0 && Y0c) sweep_st(reinterpret_cast<V *>(Y0c), r, false);
+        else sweep_st(reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B), r, nts);
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < K; ++t) sweep_st(reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B), acc[t], nts);
+      for (int t = 0; t < K; ++t) {
+        if (t == 0 && Y0c) sweep_st(reinterpret_cast<V *>(Y0c), acc[t], false);
+        else sweep_st(reinterpret_cast<V *>(Yc + (long long)((unsigned)(a.k0 + t) & a.y_row_mask) * B), acc[t], nts);
+      }
     }
   }
 }
@@ -543,6 +549,7 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
     for (int t = 0; t < KW; ++t) acc[t] = make_float2(acc[t].x - acc3[t], packed ? acc[t].y : acc[t].x + acc[t].y);
   }
   float2 *Yc = a.Y + (long long)c * a.y_chan_stride + bin;
+  float2 *Y0c = (a.Y0 && kw == 0) ? a.Y0 + (long long)c * a.y0_chan_stride + bin : nullptr;   // (FirArgs::Y0: block k0's row -- wave group 0's first)
   const bool nts = a.stream != 0;                   // (uniform; sweep_st)
   const long long k1 = a.k0 + (long long)kw * KW;
   if (a.Ybase) {                                    // (+ rows of a level below: all requests first, then the stores)
@@ -554,11 +561,15 @@ __global__ void __launch_bounds__(128 * NKW, LB) k_fdl_sweep_lds(const FirArgs a
     for (int t = 0; t < KW; ++t) {
       V r = acc[t];
       sweep_add(r, yb[t]);
-      sweep_st(Yc + (long long)((unsigned)(k1 + t) & a.y_row_mask) * B, r, nts);
+      if (t == 0 && Y0c) sweep_st(Y0c, r, false);
+      else sweep_st(Yc + (long long)((unsigned)(k1 + t) & a.y_row_mask) * B, r, nts);
     }
   } else {
 #pragma unroll
-    for (int t = 0; t < KW; ++t) sweep_st(Yc + (long long)((unsigned)(k1 + t) & a.y_row_mask) * B, acc[t], nts);
+    for (int t = 0; t < KW; ++t) {
+      if (t == 0 && Y0c) sweep_st(Y0c, acc[t], false);
+      else sweep_st(Yc + (long long)((unsigned)(k1 + t) & a.y_row_mask) * B, acc[t], nts);
+    }
   }
 }
 
