@@ -228,7 +228,7 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
     # (the tail block the set RUNS: long tails of many-channel sets are served at twice the requested block with delay 1)
     tail_x = int(conv.tail_block) if tail else 0
     row_h, row_t = 8.0 * head * n1, 8.0 * max(tail_x, 1) * n1   # bytes of one spectrum row of every channel of a launch
-    io_blk = n1 * (4.0 * 3 * head + 4.0 * 2 * head)        # per block: input + history + tail ring read, output + ring written
+    io_blk = n1 * (4.0 * (3 if tail else 2) * head + 4.0 * 2 * head)   # per block: input + history (+ tail ring) read, output + ring written
     if not tiled:
         exe = {
             # the per-block launch does one head block of the reference's head AND tail0 sub-convolvers
@@ -265,7 +265,8 @@ def executed_bytes(conv, nch: int, head: int, tail: int, ir_len: int, host_block
             # audio part (H0, H1, X_{k-1}, accumulator read; X_k written; samples) + on average (K2-1)/2 recent partitions patched
             exe["fused_block"] = 5 * row_h + io_blk + ((K2 - 1) / 2.0 * 2 + 2) * row_h * (K2 - 1) / K2
         # IR rows 2.. + arrived delay-line rows read once, KA partial rows written (the two newest partitions are the per-block launch's)
-        exe["sweep_head"] = ((PA - 2) + (PA - 2) + KA) * row_h
+        # (same-block sets: the sweep takes the newest row too -- one more delay-line row)
+        exe["sweep_head"] = ((PA - 2) + (PA - 2) + (1 if conv.plan()["head_patch_in_launch"] else 0) + KA) * row_h
         # (same-block sets: the stage's sweeps take the newest row -- lag 1 -- so a second-level walk is one partition shorter)
         exe["sweep2_head"] = sweep2_rows(KA, PA - 2, 3 if conv.plan()["head_patch_in_launch"] else 2) * row_h
     else:                                                    # zero-latency stage not tiled: every block reads all of it
