@@ -345,7 +345,9 @@ bool tail_rows(rvc_set *s, long long m_hi, hipStream_t st) {
       pg.Yadd[gi] = row; pg.yadd_chan_stride[gi] = stride;
       t.store_phase(p);
     }
-    {
+    bool any_patch = false;                        // (every group's row in place already -- all of them fresh after init / clear(): no launch)
+    for (int i = 0; i < pg.n_groups; ++i) any_patch = any_patch || pg.P[i] >= 0;
+    if (any_patch) {
       Timer tm(s, 5, st);
       RVC_CK(rvc::launch_fdl_patch_groups(r, pg, s->nch, st));
     }

@@ -142,10 +142,14 @@ void drop_jobs(rvc_set *s) {   // return the events of all queued tail jobs to t
 void fold_timing(rvc_set *s, int id) {
   auto &v = s->timed[id];
   if (v.empty()) return;
-  hipEventSynchronize(v.back().b);
+  if (hipEventSynchronize(v.back().b) != hipSuccess) (void)hipGetLastError();
   for (auto &t : v) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+    // (a pair no launch recorded -- a launcher that found nothing to do -- reads as an error: dropped, and the runtime's sticky
+    //  "last error" cleared so that it does not surface in whatever checks hipGetLastError next)
+    const hipError_t te = hipEventElapsedTime(&ms, t.a, t.b);
+    if (te != hipSuccess) (void)hipGetLastError();
+    if (te == hipSuccess) {
       s->timed_ms[id] += ms; ++s->timed_n[id];
       const hipEvent_t base = s->timed_parent ? s->timed_parent->timed_base : s->timed_base;
       float st = 0.f;

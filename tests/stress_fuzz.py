@@ -21,7 +21,12 @@ for seed in range(first, first + count):
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_force2_k32")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_shrink_force2")),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_widen")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "phases_force")),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "spread3_force2")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "spread1_force2_k32")),
-            (T.test_fuzz_block_synchronous_time_tiling, (seed, "phspread_force2_k32")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "phspread_shrink_force2"))]
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "phspread_force2_k32")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "phspread_shrink_force2")),
+            # round 6, late: third-level sweeps in both stages on top of those
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_force")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_force2_k32")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_phases_force2_k32")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_phases_shrink_force2")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_phases_widen")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_spread3_force2")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_phspread_force2_k32"))]
     for fn, a in jobs:
         runs += 1
         if os.environ.get("STRESS_LOG"):

@@ -1065,6 +1065,48 @@ def test_device_entry_with_misaligned_views_and_strides():
             assert rel_rms(got[c], want[c]) <= TOL
 
 
+@pytest.mark.parametrize("phases", [1, 8])
+def test_third_level_sweeps_run_where_planned_and_change_only_the_association(phases):
+    """Round 6: third-level sweeps (Tile::s3; knobs tail_third / head_third) on a 16-channel set at BASELINE config 2's geometry in the
+    delay-1 form (head 512 x 16, tail 8192 x 58: tail tiles of 32 blocks, head tiles of 8), block-synchronous for 70 tail blocks, with
+    and without phase groups: (1) the launches happen where the schedule says -- one third-level head sweep per 8 head blocks, one
+    third-level tail sweep per group of 8 tail blocks and phase group -- and the patch launches move fewer bytes with them than without
+    (timed families 13 / 14 / 5); (2) the samples equal the two-level schedule's to float association (<= 2e-6) and the oracle's
+    within the tolerance."""
+    import torch
+    nch, head, tail, nblk = 16, 512, 8192, 70 * 16
+    irs = [synth.synth_ir(480000 - 997 * (c % 5), 1, 70 + c % 3)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 500 + c % 4) for c in range(nch)])
+    dx = torch.from_numpy(x).cuda()
+    outs, counts = {}, {}
+    for third in (0, 1):
+        s = reevr_amd.ConvolverSet(nch, timing=True, tune=dict(tail_slack=2, tail_phases=phases, tail_third=third, head_third=third, k1=32),
+                                   time_tiling="force2", fft_f32=True)
+        assert s.init(head, tail, irs, max_len=head), s.last_error_string
+        pl = s.plan()
+        assert (pl["tail_third_level"], pl["head_third_level"]) == (third, third) and pl["tail_phase_groups"] == phases
+        assert pl["head_patch_in_launch"] == 1 and pl["tail_delay"] == 1 and (s.partitions(0), s.partitions(1)) == (16, 58)
+        outs[third] = s.process_device_blocks(dx, head).cpu().numpy()
+        assert s.last_error == 0, s.last_error_string
+        counts[third] = {k: s.kernel_time(k)[0] for k in (5, 10, 12, 13, 14)}
+        s.close()
+    assert counts[0][13] == 0 and counts[0][14] == 0
+    # head: tiles of 32 blocks (k1 = 32, forced two-level): every group of 8 has its half-way sweep
+    assert abs(counts[1][14] - nblk // 8) <= 2, counts
+    # tail: 70 tail blocks (the first is block 1: delay 1), one third-level sweep per group of 8 and phase group; a group's first tile is
+    # up to 31 blocks short
+    per_group = 70 // 8
+    assert phases * (per_group - 5) <= counts[1][13] <= phases * (per_group + 1), counts
+    # the patch launch: one per tail block in both schedules (phase groups: one for all groups)
+    assert counts[1][5] <= counts[0][5]
+    for c in range(nch):
+        assert rel_rms(outs[1][c], outs[0][c]) <= 2e-6, c
+    for c in (0, 7, 15):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(outs[1][c], o.process(x[c])) <= TOL, c
+
+
 @pytest.mark.parametrize("slack", [0, 1, 2, "1_phases"])
 def test_two_level_tiling_at_config3_geometry(slack):
     """(slack: what the tail's period of slack buys -- 0 the reference's structure, 1 the tail at block 16384 with delay 1 = what
