@@ -61,7 +61,9 @@ enum {
 #define RVC_FLAG_TIMING 2u      /* bracket every kernel launch with HIP events (rvc_set_kernel_time) */
 #define RVC_FLAG_FFT_F64 4u     /* run EVERY transform in double, spectra still stored as float -- the reference's
                                    precision (Ooura in double, AudioFFT.cpp:114-159). Largest partition
-                                   RVC_MAX_BLOCK/2. IR spectra are computed in double at init in any mode.
+                                   RVC_MAX_BLOCK/2. IR spectra are computed in double at init in any mode. (Per-block calls then
+                                   take three launches instead of one -- transform, time-tiled delay line, inverse transform --:
+                                   ~15 % below the default's rate at thousands of channels, a few us more per call for a pair.)
                                    Default (none of the three precision flags): stages with partitions below 2048 samples (and
                                    the 16384-sample ones, which do not fit one CU's LDS in double) transform in float; stages
                                    with partitions of 2048 ... 8192 samples run

@@ -78,15 +78,18 @@ struct Timer {   // brackets one launch with events when timing is on
 // (Round 6: a zero-latency stage whose per-block launch patches its OWN block -- same_block -- runs every sweep for blocks kb..
 //  when row kb - 1 exists: behind the launch that completed block kb - 1, or in front of block kb's. Its sweeps take that row too --
 //  it meets block kb + 1 in partition 2 -- and every patch is one partition shorter: lag 1.)
-int stage_lag(const rvc_set *s, bool tail) { return tail ? s->T.delay : (s->same_block ? 1 : 2); }
+// (head_gen -- the general per-block path, time-tiled: its sweeps and patches cover every partition from 0 on, and a block's sweep runs
+//  behind that block's own forward transform: lag 0.)
+int stage_lag(const rvc_set *s, bool tail) { return tail ? s->T.delay : (s->head_gen ? 0 : (s->same_block ? 1 : 2)); }
 rvc::FirArgs stage_line(rvc_set *s, bool tail) {
   Stage &g = tail ? s->T : s->A;
   const long long B = (long long)g.B;
   rvc::FirArgs r{};
   if (tail) { r.H = g.H + (long long)g.delay * B; r.h_chan_stride = (long long)g.PF * B; r.delay = g.delay; r.tag = 1; }
+  else if (s->head_gen) { r.H = g.H; r.h_chan_stride = (long long)g.P * B; r.delay = 0; r.tag = 0; }
   else { r.H = g.H + 2 * B; r.h_chan_stride = (long long)g.P * B; r.delay = 2; r.tag = 0; }
   r.X = g.X; r.x_chan_stride = (long long)g.rows * B; r.x_row_mask = g.rows - 1;
-  r.P = tail ? g.P : std::max(g.P - 2, 0); r.B = (int)B;
+  r.P = (tail || s->head_gen) ? g.P : std::max(g.P - 2, 0); r.B = (int)B;
   return r;
 }
 // first level: blocks [k0, k0 + K1), every partition, the input rows <= x_hi
@@ -484,14 +487,53 @@ bool head_stage(rvc_set *s, long long n0, long long na, long long nb, const floa
   const long long hb = (long long)A.B;
   const long long ka = na / hb, kb = (nb - 1) / hb;
   const int M = (int)(kb - ka + 1);
-  if (!head_spectra(s, head_fft_from(s, ka), kb, nb, src2, in_stride, n0, ring_from)) return false;
+  const long long fft_from = head_fft_from(s, ka);
+  if (!head_spectra(s, fft_from, kb, nb, src2, in_stride, n0, ring_from)) return false;
   s->xa_next = (nb % hb == 0) ? kb + 1 : kb;
   rvc::FirArgs r{};
   r.H = A.H; r.h_chan_stride = (long long)A.P * hb;
   r.X = A.X; r.x_chan_stride = (long long)A.rows * hb; r.x_row_mask = A.rows - 1;
   r.Y = A.Y; r.y_chan_stride = (long long)A.mcap * hb;
   r.k0 = ka; r.M = M; r.P = A.P; r.delay = 0; r.B = (int)hb;
-  {
+  const float2 *yrows = A.Y;                      // where the inverse transform reads the spectrum row(s)
+  // one WHOLE block in block order, time-tiled (head_gen): the block's row of the tile -- whose sweep runs now if the block starts a
+  // tile / a group / the second half of a group -- + the partitions whose input arrived since that sweep (tail_rows' schedule with
+  // delay 0: the block's own row exists). Anything else drops the tile and walks the whole delay line.
+  const bool tiled = s->head_gen && s->tA.on && M == 1 && na % hb == 0 && nb == na + hb && fft_from == ka;
+  if (s->head_gen && !tiled) s->tA.drop();
+  if (tiled) {
+    Tile &t = s->tA;
+    if (!t.holds(ka)) {
+      const rvc::FirArgs w = sweep1_args(s, false, ka, ka);
+      t.start(ka, t.K1);
+      Timer tm(s, 9, s->st_main);
+      RVC_CK(rvc::launch_fdl_sweep(w, s->nch, s->st_main));
+    }
+    const long long g0 = t.group(ka);
+    if (g0 != t.t0 && t.s0 != g0) {
+      const rvc::FirArgs w = sweep2_args(s, false, g0);
+      Timer tm(s, 11, s->st_main);
+      RVC_CK(rvc::launch_fdl_sweep(w, s->nch, s->st_main));
+      t.s0 = g0;
+    }
+    if (t.s3 && ka == g0 + rvc::kThirdRows && t.h0 != ka) {
+      const rvc::FirArgs w = sweep3_args(s, false, g0, ka);
+      Timer tm(s, 14, s->st_main);
+      RVC_CK(rvc::launch_fdl_sweep(w, s->nch, s->st_main));
+      t.h0 = ka;
+    }
+    long long stride = 0;
+    const float2 *row = tile_row(s, false, ka, &stride);
+    const long long recent = t.third(ka) ? ka - t.h0 : ka - g0;
+    if (recent > 0) {
+      r.P = (int)std::min<long long>(recent, (long long)A.P);
+      r.Yadd = row; r.yadd_chan_stride = stride;
+      Timer tm(s, 2, s->st_main);
+      RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
+    } else {                                     // the first block of a sweep: its row is complete
+      yrows = row; r.y_chan_stride = stride;
+    }
+  } else {
     Timer t(s, 2, s->st_main);
     RVC_CK(rvc::launch_fir(r, s->nch, s->st_main));
   }
@@ -500,7 +542,7 @@ bool head_stage(rvc_set *s, long long n0, long long na, long long nb, const floa
     else if (!tail_rows(s, (nb - 1) / (long long)T.B + 1, s->st_main)) return false;   // lazily, if skipped
   }
   rvc::InvArgs v{};
-  v.Y = A.Y; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(A.f64i); v.wsplit = A.wsp(A.f64i); v.tw8 = A.t8p(A.f64i); v.tw8_half = A.t8h(A.f64i); v.tw_half = A.twh(A.f64i);
+  v.Y = yrows; v.y_chan_stride = r.y_chan_stride; v.tw = A.twp(A.f64i); v.wsplit = A.wsp(A.f64i); v.tw8 = A.t8p(A.f64i); v.tw8_half = A.t8h(A.f64i); v.tw_half = A.twh(A.f64i);
   v.blk0 = ka;
   v.dst = d_out + (na - n0); v.dst_chan_stride = (long long)out_stride; v.dst_origin = na; v.dst_mask = ~0ull;
   v.lo = na; v.hi = nb;

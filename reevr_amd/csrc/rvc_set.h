@@ -257,6 +257,8 @@ struct rvc_set {
   bool same_block = false;       // time-tiled zero-latency stage whose folded launch is audio wave + patch wave in ONE workgroup
                                  // (head 128 / 256 / 512): the patch wave works on the SAME block and hands its row to the audio
                                  // wave through LDS -- the accumulator of a block never travels through memory (round 5)
+  bool head_gen = false;         // time-tiled zero-latency stage of a set whose per-block call takes the GENERAL path (transforms in double,
+                                 // large head blocks): sweeps / patches between the transform launches (head_stage), delay 0, lag 0
   bool fold = false;             // one launch per block: H_1 X_{k-1} folded into the fused kernel, ypre = sum_{i>=2}
   bool block_general = false;    // per-block calls take the general path (transform / delay line / inverse launches): many
                                  // channels with a LARGE head block, where the one-workgroup-per-channel latency kernel

@@ -483,6 +483,12 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
     tA = Tile(); tT = Tile();
     tA.on = tiling && s->fold && !s->block_general && A.B >= 64 &&
             (force ? pa >= 3 : (pa >= 8 && (size_t)s->nch * (pa - 2) * A.B * 16 >= ((size_t)4 << 20)));
+    // round 6: also where the per-block call takes the GENERAL path (a transform in double -- RVC_FLAG_FFT_F64, heads of 2048 .. 8192
+    // in larger sets --, many channels with a large head block): the delay-line launch between the two transform launches becomes
+    // sweep(s) + patch over the same tile state (head_stage; Stage A with delay 0: the block's own row exists when its sweep runs)
+    const bool general = s->block_general || !rvc::fused_supported(A.logB, A.f64());
+    s->head_gen = tiling && general && A.B >= 64 && (force ? pa >= 3 : (pa >= 8 && (size_t)s->nch * pa * A.B * 16 >= ((size_t)4 << 20)));
+    if (s->head_gen) tA.on = true;
     // (pa >= 8: a shrunk zero-latency stage of 8 partitions -- head 1024 under a tail of 8192 -- measured 9.1 Gsamples/s untiled
     //  against 14.9 tiled at 2048 channels, profiles/r4_tail_slack.txt; it was 16 while every many-channel stage had >= 16)
     tT.on = tiling && tb >= 64 && (force ? pt >= 1 : pt >= 16);
@@ -543,11 +549,11 @@ bool do_init(rvc_set *s, size_t head_block, size_t tail_block, bool two_stage,
       q.phi = G > 1 ? (p * rvc::kSweepRows / G + rvc::kSweepRows * (p % std::max(1, tT.K1 / rvc::kSweepRows)) + 2 * s->kid_index) % tT.K1 : 0;
     }
   }
-  s->same_block = s->tA.on && rvc::fused_same_block(A.logB) && s->tune.same_block != 0;
+  s->same_block = s->tA.on && !s->head_gen && rvc::fused_same_block(A.logB) && s->tune.same_block != 0;
   {
     // third-level sweeps of the zero-latency stage (Tile::s3; same-block sets only: their sweeps run when the newest row exists)
     const int nch_all = s->plan_nch ? s->plan_nch : s->nch;
-    const bool third = s->same_block && (s->tune.head_third >= 0 ? s->tune.head_third != 0
+    const bool third = (s->same_block || s->head_gen) && (s->tune.head_third >= 0 ? s->tune.head_third != 0
                                                                  : (kThirdDefault && (size_t)nch_all * A.B * sizeof(float2) >= kHeadThirdMinRowBytes));
     if (third) RVC_CK(dev_alloc(s, &s->tA.s3, sizeof(float2) * (size_t)s->nch * (size_t)rvc::kThirdRows * A.B));
   }

@@ -26,7 +26,10 @@ for seed in range(first, first + count):
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_force")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_force2_k32")),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_phases_force2_k32")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_phases_shrink_force2")),
             (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_phases_widen")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_spread3_force2")),
-            (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_phspread_force2_k32"))]
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "third_phspread_force2_k32")),
+            # ... and the general per-block path (every transform in double), time-tiled
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "f64_force")), (T.test_fuzz_block_synchronous_time_tiling, (seed, "f64_third_force2_k32")),
+            (T.test_fuzz_block_synchronous_time_tiling, (seed, "f64_third_phases_force2_k32"))]
     for fn, a in jobs:
         runs += 1
         if os.environ.get("STRESS_LOG"):

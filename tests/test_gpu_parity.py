@@ -690,7 +690,8 @@ def test_fuzz_geometry_and_call_pattern(seed, tiling):
                                     "phases_force2_k32", "phases_force2", "phases_shrink_force2", "phases_widen", "phases_force",
                                     "phspread_force2_k32", "phspread_shrink_force2", "phspread_widen",
                                     "third_force", "third_force2_k32", "third_phases_force2_k32", "third_phases_shrink_force2", "third_phases_widen",
-                                    "third_phases_force", "third_spread3_force2", "third_phspread_force2_k32"])
+                                    "third_phases_force", "third_spread3_force2", "third_phspread_force2_k32",
+                                    "f64_force", "f64_force2_k32", "f64_third_force", "f64_third_force2_k32", "f64_third_phases_force2_k32"])
 @pytest.mark.parametrize("seed", list(range(24)) + [226])   # 226: 3 tail partitions on 4 sweep waves (a wave without work)
 def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     """The plug-in's calling pattern -- one call per host block, now and then a ragged one, several calls inside one
@@ -703,6 +704,9 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     default) on top of the named mode."""
     spread = phases = 0
     third = -1
+    f64 = False
+    if str(tiling).startswith("f64_"):           # every transform in double: every call takes the GENERAL path, whose zero-latency stage is
+        f64, tiling = True, tiling[4:]           # time-tiled too (round 6: head_stage, rvc_set::head_gen)
     if str(tiling).startswith("third_"):
         third, tiling = 1, tiling[6:]
     if str(tiling).startswith("spread"):
@@ -745,10 +749,14 @@ def test_fuzz_block_synchronous_time_tiling(seed, tiling):
     if spread:
         bg = False                                               # (a tail job on the second stream is never spread)
     with reevr_amd.tuning(k1=32 if tiling == "force2_k32" else 0, tail_slack=slack, tail_spread=spread, tail_phases=phases or -1, tail_third=third, head_third=third):   # (k1 = 32: first-level tiles of 32 blocks)
-        s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling="force2" if tiling == "force2_k32" else tiling, fft_f32=slack > 0)
+        s = reevr_amd.ConvolverSet(nch, bg_stream=bg, time_tiling="force2" if tiling == "force2_k32" else tiling, fft_f32=slack > 0, fft_f64=f64)
         assert s.init(head, tail, irs, max_len=max(sched)), s.last_error_string
     assert s.plan()["tail_third_level"] == (1 if third > 0 and s.tile_rows(1) else 0)
-    assert s.plan()["head_third_level"] == (1 if third > 0 and s.plan()["head_patch_in_launch"] else 0)
+    if f64:
+        assert s.plan()["block_path"] == 1 and s.plan()["head_patch_in_launch"] == 0
+        assert (s.tile_rows(0) > 0) == (s.partitions(0) >= 3) and s.plan()["head_third_level"] == (1 if third > 0 and s.tile_rows(0) else 0)
+    else:
+        assert s.plan()["head_third_level"] == (1 if third > 0 and s.plan()["head_patch_in_launch"] else 0)
     if spread and s.tile_rows(1):
         assert s.plan()["tail_spread"] == ((spread if s.tile_rows(1) > 8 else spread & 1) if not phases else spread & 1)
     if phases and s.tile_rows(1):
@@ -1063,6 +1071,40 @@ def test_device_entry_with_misaligned_views_and_strides():
         got = big_out[:, off_out:off_out + frames].cpu().numpy()
         for c in range(2):
             assert rel_rms(got[c], want[c]) <= TOL
+
+
+@pytest.mark.parametrize("case", ["f64_512", "head2048"])
+def test_general_per_block_path_time_tiled_vs_oracle(case):
+    """Round 6: the zero-latency stage of sets whose per-block call takes the GENERAL path (forward transform / delay line / inverse
+    launches) is time-tiled as well -- by size, no flag: (f64_512) 256 channels of BASELINE config 2's geometry with every transform in
+    double (RVC_FLAG_FFT_F64: the mode at the reference's own precision; 16 head partitions: tiles of 8 with third-level sweeps);
+    (head2048) 512 channels, head 2048 / tail 16384 (many channels with a large head block; 8 head partitions). One process() per head
+    block through the device entry for 12 tail periods; the timed delay-line family must be patch launches with sweeps beside them, and
+    five channels must equal the oracle."""
+    import torch
+    if case == "f64_512":
+        nch, head, tail, kw = 256, 512, 8192, dict(fft_f64=True)
+    else:
+        nch, head, tail, kw = 512, 2048, 16384, {}
+    nblk = 12 * (tail // head)
+    irs = [synth.synth_ir(2 * tail + 5 * tail - 211 * (c % 6), 1, 30 + c % 5)[0] for c in range(nch)]
+    x = np.stack([synth.synth_input(head * nblk, 700 + c % 7) for c in range(nch)])
+    s = reevr_amd.ConvolverSet(nch, timing=True, **kw)
+    assert s.init(head, tail, irs, max_len=head), s.last_error_string
+    pl = s.plan()
+    assert pl["block_path"] == 1 and pl["head_patch_in_launch"] == 0 and pl["head_tile_blocks"] == 8 and s.partitions(0) >= 8, pl
+    got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
+    assert s.last_error == 0, s.last_error_string
+    n_fir, n_sweep, n_third = (s.kernel_time(k)[0] for k in (2, 9, 14))
+    s.close()
+    # one sweep per tile of 8 blocks, one third-level sweep per tile where the stage has them, a patch for every other block
+    assert abs(n_sweep - nblk // 8) <= 1 and n_third == (nblk // 8 if pl["head_third_level"] else 0), (n_sweep, n_third, nblk)
+    assert n_fir == nblk - n_sweep - n_third, (n_fir, n_sweep, n_third)
+    assert np.isfinite(got).all()
+    for c in (0, 1, nch // 2, nch - 2, nch - 1):
+        o = O.TwoStageFFTConvolver("orc")
+        assert o.init(head, tail, irs[c])
+        assert rel_rms(got[c], o.process(x[c])) <= TOL, c
 
 
 @pytest.mark.parametrize("phases", [1, 8])
