@@ -39,14 +39,21 @@ for seed in [226] + list(range(nseeds)):
     head, tail, nch, irs, sched, x = case(seed)
     # force2_k32: first-level tiles of 32 blocks = the LDS-fed sweeps; widen / shrink: the delay-1 tail stage of many-channel sets
     # round 6: phases = the tail tiles in channel groups out of phase (launches on channel sub-ranges); spread3 = sweeps in channel slices
-    for tiling in (False, True, "force", "force2", "force2_k32", "widen", "shrink", "phases", "phases_shrink", "spread3", "phases_spread"):
-        slack = {"widen": 1, "shrink": 2, "phases_shrink": 2, "phases_spread": 2}.get(tiling, -1)
-        extra = (dict(tail_phases=8, tail_spread=1) if tiling == "phases_spread" else dict(tail_phases=8) if str(tiling).startswith("phases")
+    # third*: third-level sweeps in both stages (the four-row sweep form, rows written in place); f64*: every transform in double = the general
+    # per-block path with its time-tiled zero-latency stage
+    for tiling in (False, True, "force", "force2", "force2_k32", "widen", "shrink", "phases", "phases_shrink", "spread3", "phases_spread",
+                   "third", "third_phases_shrink", "f64", "f64_third"):
+        slack = {"widen": 1, "shrink": 2, "phases_shrink": 2, "phases_spread": 2, "third_phases_shrink": 2}.get(tiling, -1)
+        extra = (dict(tail_phases=8, tail_spread=1) if tiling == "phases_spread" else dict(tail_phases=8) if "phases" in str(tiling)
                  else (dict(tail_spread=3) if tiling == "spread3" else {}))
-        with reevr_amd.tuning(guard=2, k1=32 if tiling == "force2_k32" else 0, tail_slack=slack, **extra):
-            s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1) and slack < 0 and not extra, fft_f32=slack > 0,
+        if "third" in str(tiling):
+            extra.update(tail_third=1, head_third=1)
+        f64 = str(tiling).startswith("f64")
+        with reevr_amd.tuning(guard=2, k1=32 if tiling in ("force2_k32", "third", "f64_third") else 0, tail_slack=slack, **extra):
+            s = reevr_amd.ConvolverSet(nch, bg_stream=bool(seed & 1) and slack < 0 and not extra, fft_f32=slack > 0, fft_f64=f64,
                                        time_tiling={"force2_k32": "force2", "widen": "force", "shrink": "force2", "phases": "force2",
-                                                    "phases_shrink": "force2", "spread3": "force2", "phases_spread": "force2"}.get(tiling, tiling))
+                                                    "phases_shrink": "force2", "spread3": "force2", "phases_spread": "force2",
+                                                    "third": "force2", "third_phases_shrink": "force2", "f64": "force", "f64_third": "force2"}.get(tiling, tiling))
             ok = s.init(head, tail, irs, max_len=max(sched))
         assert ok, s.last_error_string
         pos = 0
