@@ -1149,7 +1149,7 @@ def test_third_level_sweeps_run_where_planned_and_change_only_the_association(ph
         assert rel_rms(outs[1][c], o.process(x[c])) <= TOL, c
 
 
-@pytest.mark.parametrize("slack", [0, 1, 2, "1_phases"])
+@pytest.mark.parametrize("slack", [0, 1, 2, "1_phases", "1_phases_third"])
 def test_two_level_tiling_at_config3_geometry(slack):
     """(slack: what the tail's period of slack buys -- 0 the reference's structure, 1 the tail at block 16384 with delay 1 = what
     sets of >= 256 channels run at this geometry, 2 half the zero-latency stage; 1_phases: 1 with the tail tiles in 8 channel
@@ -1165,13 +1165,14 @@ def test_two_level_tiling_at_config3_geometry(slack):
     irs = [base[c % 2][:lens[c]].copy() for c in range(nch)]
     nblk = (352 + 24) * (tail // head)                       # all 350 tail partitions in use, then a few tiles more
     x = np.stack([synth.synth_input(head * nblk, 200 + c % 5) for c in range(nch)])
-    phases = 8 if slack == "1_phases" else -1
-    slack = 1 if slack == "1_phases" else slack
-    with reevr_amd.tuning(tail_slack=slack, tail_phases=phases):
+    third = 1 if slack == "1_phases_third" else -1          # (round 6: + third-level sweeps on the 16384-bin rows, what the bench's set runs)
+    phases = 8 if str(slack).startswith("1_phases") else -1
+    slack = 1 if str(slack).startswith("1_phases") else slack
+    with reevr_amd.tuning(tail_slack=slack, tail_phases=phases, tail_third=third):
         s = reevr_amd.ConvolverSet(nch, time_tiling="force")
         assert s.init(head, tail, irs, max_len=head), s.last_error_string
     assert (s.partitions(0), s.partitions(1), s.tail_block) == [(64, 350, 8192), (64, 175, 16384), (32, 351, 8192)][slack]
-    assert s.plan()["tail_phase_groups"] == (8 if phases > 0 else 1)
+    assert s.plan()["tail_phase_groups"] == (8 if phases > 0 else 1) and s.plan()["tail_third_level"] == (1 if third > 0 else 0)
     assert s.tile_rows(0) > 8 and s.tile_rows(1) > 8         # two levels on both stages
     got = s.process_device_blocks(torch.from_numpy(x).cuda(), head).cpu().numpy()
     assert s.last_error == 0, s.last_error_string
